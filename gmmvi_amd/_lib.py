@@ -1,0 +1,97 @@
+"""ctypes binding of libgmmvi_hip.so (C ABI: include/gmmvi_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing, or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgmmvi_hip.so")
+
+GAUSS, STUDENT_T = 0, 1
+SELF_NORMALIZED, OWN_SAMPLES_ONLY = 1, 2
+MAX_DIM = 64
+
+
+class GmmviError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_sz = C.c_size_t
+_u64 = C.c_uint64
+
+_PROTOS = {
+    "gmmvi_device_count": (_i, []),
+    "gmmvi_ctx_create": (_i, [C.POINTER(_p), _i]),
+    "gmmvi_ctx_destroy": (None, [_p]),
+    "gmmvi_last_error": (C.c_char_p, [_p]),
+    "gmmvi_sync": (_i, [_p]),
+    "gmmvi_malloc": (_i, [_p, _sz, C.POINTER(_p)]),
+    "gmmvi_free": (_i, [_p, _p]),
+    "gmmvi_upload": (_i, [_p, _p, _p, _sz]),
+    "gmmvi_download": (_i, [_p, _p, _p, _sz]),
+    "gmmvi_copy": (_i, [_p, _p, _p, _sz]),
+    "gmmvi_fill_f32": (_i, [_p, _p, _f, _sz]),
+    "gmmvi_event_create": (_i, [_p, C.POINTER(_p)]),
+    "gmmvi_event_destroy": (_i, [_p, _p]),
+    "gmmvi_event_record": (_i, [_p, _p]),
+    "gmmvi_event_elapsed_ms": (_i, [_p, _p, _p, C.POINTER(_f)]),
+    "gmmvi_packed_stride": (_sz, [_i]),
+    "gmmvi_pack_components": (_i, [_p, _i, _f, _i, _i, _p, _p, _p, _p]),
+    "gmmvi_cholesky": (_i, [_p, _i, _i, _p, _p, _p]),
+    "gmmvi_mixture_eval": (_i, [_p, _i, _f, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
+    "gmmvi_target_planar": (_i, [_p, _i, _p, _i, _p, _f, _p, _i, _p, _p]),
+    "gmmvi_sample_components": (_i, [_p, _i, _i, _p, _p, _p, _i, _u64, _u64, _i, _p, _p, _p]),
+    "gmmvi_philox_normals": (_i, [_p, _u64, _u64, _i, _i, _i, _p]),
+    "gmmvi_philox_uniforms": (_i, [_p, _u64, _u64, _i, _i, _p]),
+    "gmmvi_stein": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
+    "gmmvi_update_components_kl": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "gmmvi_update_components_direct": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p]),
+    "gmmvi_update_components_iblr": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p]),
+    "gmmvi_expected_log_ratios": (_i, [_p, _i, _i, _p, _p, _p, _p, _f, _p, _i, _p, _p, _p]),
+    "gmmvi_update_weights_kl": (_i, [_p, _i, _p, _p, _p, _f, _p]),
+    "gmmvi_update_weights_direct": (_i, [_p, _i, _p, _p, _p, _f]),
+    "gmmvi_component_stepsize_improvement": (_i, [_p, _i, _p, _p, _p, _f, _f, _f, _f]),
+    "gmmvi_weight_stepsize_improvement": (_i, [_p, _i, _p, _p, _p, _f, _f, _f, _f]),
+    "gmmvi_comm_unique_id": (_i, [C.c_char_p]),
+    "gmmvi_comm_init": (_i, [_p, C.c_char_p, _i, _i]),
+    "gmmvi_comm_destroy": (_i, [_p]),
+    "gmmvi_allgather_f32": (_i, [_p, _p, _p, _sz]),
+    "gmmvi_allreduce_f32": (_i, [_p, _p, _sz, _i]),
+    "gmmvi_combine_partials": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
+
+
+def load():
+    """Load the shared library (once).  Raises GmmviError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GmmviError(
+            f"{LIB_PATH} not found: build it with `make -C gmmvi_amd/csrc` (or __graft_entry__.build()). "
+            "There is no CPU fallback for the gmmvi hot path.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def device_count():
+    return int(load().gmmvi_device_count())
+
+
+def check(ctx_handle, rc):
+    if rc != 0:
+        msg = load().gmmvi_last_error(ctx_handle)
+        raise GmmviError(f"libgmmvi_hip error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,154 @@
+// Context, error, memory and event entry points of the C ABI (include/gmmvi_hip.h).
+#include "common.h"
+
+std::string g_gmmvi_global_err;
+
+int gmmvi_ws_reserve(gmmvi_ctx* ctx, size_t nbytes) {
+    if (nbytes <= ctx->ws_bytes) return GMMVI_OK;
+    // A grow frees the old block; earlier kernels on the stream may still read it, so drain first.
+    GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) GMMVI_HIP_CHECK(ctx, hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    size_t want = nbytes + nbytes / 2;
+    GMMVI_HIP_CHECK(ctx, hipMalloc(&ctx->ws, want));
+    ctx->ws_bytes = want;
+    return GMMVI_OK;
+}
+
+extern "C" {
+
+int gmmvi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gmmvi_ctx_create(gmmvi_ctx** out, int device) {
+    if (!out) return gmmvi_fail(nullptr, GMMVI_ERR_ARG, "gmmvi_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return gmmvi_fail(nullptr, GMMVI_ERR_HIP, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device < 0 || device >= n) return gmmvi_fail(nullptr, GMMVI_ERR_ARG, "device index out of range");
+    gmmvi_ctx* ctx = new gmmvi_ctx();
+    ctx->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        g_gmmvi_global_err = std::string("gmmvi_ctx_create: ") + hipGetErrorString(e);
+        delete ctx;
+        return GMMVI_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    *out = ctx;
+    return GMMVI_OK;
+}
+
+void gmmvi_ctx_destroy(gmmvi_ctx* ctx) {
+    if (!ctx) return;
+    gmmvi_comm_destroy(ctx);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    delete ctx;
+}
+
+const char* gmmvi_last_error(gmmvi_ctx* ctx) { return ctx ? ctx->err.c_str() : g_gmmvi_global_err.c_str(); }
+
+int gmmvi_sync(gmmvi_ctx* ctx) {
+    GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return GMMVI_OK;
+}
+
+int gmmvi_malloc(gmmvi_ctx* ctx, size_t nbytes, void** out_dev) {
+    GMMVI_ARG_CHECK(ctx, out_dev != nullptr);
+    *out_dev = nullptr;
+    if (nbytes == 0) nbytes = 4;
+    GMMVI_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    GMMVI_HIP_CHECK(ctx, hipMalloc(out_dev, nbytes));
+    return GMMVI_OK;
+}
+
+int gmmvi_free(gmmvi_ctx* ctx, void* dev) {
+    if (!dev) return GMMVI_OK;
+    // hipFree synchronises the device, so kernels still using the block have finished.
+    GMMVI_HIP_CHECK(ctx, hipFree(dev));
+    return GMMVI_OK;
+}
+
+int gmmvi_upload(gmmvi_ctx* ctx, void* dst_dev, const void* src_host, size_t nbytes) {
+    if (nbytes == 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, dst_dev && src_host);
+    // pageable host memory: the runtime stages the copy, the call returns when the source may be reused
+    GMMVI_HIP_CHECK(ctx, hipMemcpyAsync(dst_dev, src_host, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return GMMVI_OK;
+}
+
+int gmmvi_download(gmmvi_ctx* ctx, void* dst_host, const void* src_dev, size_t nbytes) {
+    if (nbytes == 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, dst_host && src_dev);
+    GMMVI_HIP_CHECK(ctx, hipMemcpyAsync(dst_host, src_dev, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return GMMVI_OK;
+}
+
+int gmmvi_copy(gmmvi_ctx* ctx, void* dst_dev, const void* src_dev, size_t nbytes) {
+    if (nbytes == 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, dst_dev && src_dev);
+    GMMVI_HIP_CHECK(ctx, hipMemcpyAsync(dst_dev, src_dev, nbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return GMMVI_OK;
+}
+
+__global__ void fill_f32_kernel(float* dst, float v, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = v;
+}
+
+int gmmvi_fill_f32(gmmvi_ctx* ctx, float* dst_dev, float value, size_t count) {
+    if (count == 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, dst_dev != nullptr);
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fill_f32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dst_dev, value, count);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+int gmmvi_event_create(gmmvi_ctx* ctx, void** out_event) {
+    GMMVI_ARG_CHECK(ctx, out_event != nullptr);
+    hipEvent_t ev;
+    GMMVI_HIP_CHECK(ctx, hipEventCreate(&ev));
+    *out_event = (void*)ev;
+    return GMMVI_OK;
+}
+
+int gmmvi_event_destroy(gmmvi_ctx* ctx, void* event) {
+    if (event) GMMVI_HIP_CHECK(ctx, hipEventDestroy((hipEvent_t)event));
+    return GMMVI_OK;
+}
+
+int gmmvi_event_record(gmmvi_ctx* ctx, void* event) {
+    GMMVI_HIP_CHECK(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
+    return GMMVI_OK;
+}
+
+int gmmvi_event_elapsed_ms(gmmvi_ctx* ctx, void* start, void* stop, float* out_ms) {
+    GMMVI_ARG_CHECK(ctx, out_ms != nullptr);
+    GMMVI_HIP_CHECK(ctx, hipEventSynchronize((hipEvent_t)stop));
+    GMMVI_HIP_CHECK(ctx, hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return GMMVI_OK;
+}
+
+size_t gmmvi_packed_stride(int D) {
+    int dp = gmmvi_padded_dim(D);
+    return dp < 0 ? 0 : gmmvi_packed_stride_dp(dp);
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// Expected log-ratios / component rewards (gmmvi_modules/weight_updater.py:56-75), the categorical trust-region
+// weight update (:164-279), the direct update (:123-141) and the improvement-based
+// stepsize rules (component_stepsize_adaptation.py:165-188, weight_stepsize_adaptation.py:141-156).
+#include "common.h"
+#include <cfloat>
+
+namespace {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// block-wide reductions for 256 threads (4 waves); result identical in every thread
+__device__ float block_max(float v, float* red) {
+    v = wmax(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ float block_sum(float v, float* red) {
+    v = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// One workgroup per component: E_k = sum_n softmax_n(ld[k,n] - bg[n]) * (tlp[n] - beta logq[n]).
+__global__ __launch_bounds__(256) void elr_kernel(int N, const float* __restrict__ ld, const float* __restrict__ bg,
+                                                  const float* __restrict__ tlp, const float* __restrict__ logq, float beta,
+                                                  const float* __restrict__ logw, int self_normalized,
+                                                  float* __restrict__ E_out, float* __restrict__ reward_out,
+                                                  float* __restrict__ ess_out) {
+    __shared__ float red[4];
+    const int k = blockIdx.x;
+    const float* row = ld + (size_t)k * N;
+    float m = -3.0e38f;
+    for (int n = threadIdx.x; n < N; n += 256) m = fmaxf(m, row[n] - bg[n]);
+    m = block_max(m, red);
+    float s = 0.f, se = 0.f, s2 = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float e = __expf(row[n] - bg[n] - m);
+        s += e;
+        s2 = fmaf(e, e, s2);
+        se = fmaf(e, tlp[n] - beta * logq[n], se);
+    }
+    s = block_sum(s, red);
+    se = block_sum(se, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        // plain importance weights (:66-71): 1/N sum_n exp(ld - bg) rho_n
+        const float E = self_normalized ? se / s : se * __expf(m) / (float)N;
+        if (E_out) E_out[k] = E;
+        if (reward_out) reward_out[k] = beta * logw[k] + E;                              // :73
+        if (ess_out) ess_out[k] = (s * s) / s2;                                          // sample_selector.py:154-158
+    }
+}
+
+// log-sum-exp over K values held in LDS by one wavefront
+__device__ float wave_lse(const float* v, int K) {
+    const int t = threadIdx.x;
+    float m = -3.0e38f;
+    for (int i = t; i < K; i += 64) m = fmaxf(m, v[i]);
+    m = wmax(m);
+    float s = 0.f;
+    for (int i = t; i < K; i += 64) s += __expf(v[i] - m);
+    s = wsum(s);
+    return m + __logf(s);
+}
+
+// kl() of TrustRegionBasedWeightUpdater (:164-191): writes new log weights into nl, returns KL(new || old).
+__device__ float weights_kl(float eta, float beta, const float* lw, const float* E, float* nl, int K) {
+    const int t = threadIdx.x;
+    const float a = (eta + 1.f) / (beta + eta), b = 1.f / (beta + eta);
+    for (int i = t; i < K; i += 64) nl[i] = a * lw[i] + b * E[i];                         // :184-185
+    __syncthreads();
+    float l = wave_lse(nl, K);
+    for (int i = t; i < K; i += 64) nl[i] = fmaxf(nl[i] - l, -69.07f);                    // :186-187
+    __syncthreads();
+    l = wave_lse(nl, K);
+    float kl = 0.f;
+    for (int i = t; i < K; i += 64) {
+        const float v = nl[i] - l;                                                        // :188
+        nl[i] = v;
+        kl = fmaf(__expf(v), v - lw[i], kl);                                              // :190
+    }
+    __syncthreads();
+    return wsum(kl);
+}
+
+// mode 0: trust region (:193-279); mode 1: direct (:123-141).  Single wavefront; lw/E/nl live in LDS.
+__global__ __launch_bounds__(64) void update_weights_kernel(int mode, int K, float* __restrict__ logw,
+                                                            const float* __restrict__ E_in, const float* __restrict__ stepsize,
+                                                            float beta, float* __restrict__ kl_eta_out) {
+    extern __shared__ float sm[];
+    float* lw = sm; float* E = sm + K; float* nl = sm + 2 * K;
+    const int t = threadIdx.x;
+    for (int i = t; i < K; i += 64) { lw[i] = logw[i]; E[i] = E_in[i]; nl[i] = logw[i]; }
+    __syncthreads();
+    if (K <= 1) return;                                                                   // :136 / :275
+    const float bound = stepsize[0];
+    float kl = -1.f, eta = -1.f;
+    bool updated = true;
+    if (mode == 1) {
+        for (int i = t; i < K; i += 64) nl[i] = lw[i] + bound / beta * E[i];              // :137
+        __syncthreads();
+        float l = wave_lse(nl, K);
+        for (int i = t; i < K; i += 64) nl[i] = fmaxf(nl[i] - l, -69.07f);                // :138-139
+        __syncthreads();
+        l = wave_lse(nl, K);
+        for (int i = t; i < K; i += 64) nl[i] -= l;                                       // :140
+        __syncthreads();
+    } else {
+        float lb = -45.f, ub = 45.f;                                                      // :276-277
+        float log_eta = 0.5f * (ub + lb);
+        bool ub_ok = false;
+        for (int it = 0; it < 50; ++it) {                                                 // :232
+            eta = expf(log_eta);
+            if (fabsf(expf(ub) - expf(lb)) < 1e-1f) break;                                // :234-236
+            kl = weights_kl(eta, beta, lw, E, nl, K);                                     // :238
+            if (fabsf(bound - kl) < 1e-1f * bound) { lb = ub; break; }                    // :240-243
+            if (bound > kl) { ub = log_eta; ub_ok = true; } else { lb = log_eta; }        // :245-249
+            log_eta = 0.5f * (ub + lb);
+        }
+        if (lb == ub) {
+            // :252-253 keep the last evaluated weights
+        } else if (ub_ok) {
+            eta = expf(ub);
+            kl = weights_kl(eta, beta, lw, E, nl, K);                                     // :256-258
+        } else {
+            updated = false;                                                              // :260
+            kl = -1.f; eta = -1.f;
+        }
+    }
+    if (!updated) {
+        for (int i = t; i < K; i += 64) nl[i] = lw[i];
+        __syncthreads();
+    }
+    // GMM.replace_weights (models/gmm.py:181): renormalise
+    const float l = wave_lse(nl, K);
+    for (int i = t; i < K; i += 64) logw[i] = nl[i] - l;
+    if (t == 0 && kl_eta_out) { kl_eta_out[0] = kl; kl_eta_out[1] = eta; }
+}
+
+__global__ void component_stepsize_kernel(int K, float* __restrict__ stepsizes, const float* __restrict__ prev,
+                                          const float* __restrict__ last, float mn, float mx, float inc, float dec) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float cur = stepsizes[k];
+    stepsizes[k] = (prev[k] >= last[k]) ? fmaxf(dec * cur, mn) : fminf(inc * cur, mx);    // :177-186
+}
+
+// ELBO proxy sum_k w_k R_k - sum_k w_k log w_k accumulated in fp64 and rounded to fp32 before the comparison
+// (DESIGN.md quirk Q-elbo: keeps the float32.min sentinel of a fresh reward history from flipping the first test).
+__global__ __launch_bounds__(64) void weight_stepsize_kernel(int K, const float* __restrict__ logw,
+                                                             const float* __restrict__ rewards_last, float* __restrict__ state,
+                                                             float mn, float mx, float inc, float dec) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < K; i += 64) {
+        const double w = exp((double)logw[i]);
+        a += w * (double)rewards_last[i] - w * (double)logw[i];                           // :147
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (threadIdx.x == 0) {
+        const float elbo = (float)a;
+        const float prev = state[1];
+        state[0] = (elbo > prev) ? fminf(inc * state[0], mx) : fmaxf(dec * state[0], mn);  // :149-156
+        state[1] = elbo;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gmmvi_expected_log_ratios(gmmvi_ctx* ctx, int K, int N, const float* ld_dev, const float* bg_dev,
+                              const float* tlp_dev, const float* logq_dev, float beta, const float* logw_dev,
+                              int self_normalized, float* E_out_dev, float* reward_out_dev, float* ess_out_dev) {
+    GMMVI_ARG_CHECK(ctx, K >= 1 && N >= 1);
+    GMMVI_ARG_CHECK(ctx, ld_dev && bg_dev && tlp_dev && logq_dev && logw_dev);
+    hipLaunchKernelGGL(elr_kernel, dim3(K), dim3(256), 0, ctx->stream, N, ld_dev, bg_dev, tlp_dev, logq_dev, beta,
+                       logw_dev, self_normalized, E_out_dev, reward_out_dev, ess_out_dev);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+static int launch_update_weights(gmmvi_ctx* ctx, int mode, int K, float* logw_dev, const float* E_dev,
+                                 const float* stepsize_dev, float beta, float* kl_eta_out_dev) {
+    GMMVI_ARG_CHECK(ctx, K >= 1 && K <= 4096);
+    GMMVI_ARG_CHECK(ctx, logw_dev && E_dev && stepsize_dev);
+    hipLaunchKernelGGL(update_weights_kernel, dim3(1), dim3(64), (size_t)3 * K * sizeof(float), ctx->stream, mode, K,
+                       logw_dev, E_dev, stepsize_dev, beta, kl_eta_out_dev);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+int gmmvi_update_weights_kl(gmmvi_ctx* ctx, int K, float* logw_dev, const float* E_dev, const float* stepsize_dev,
+                            float beta, float* kl_eta_out_dev) {
+    return launch_update_weights(ctx, 0, K, logw_dev, E_dev, stepsize_dev, beta, kl_eta_out_dev);
+}
+
+int gmmvi_update_weights_direct(gmmvi_ctx* ctx, int K, float* logw_dev, const float* E_dev,
+                                const float* stepsize_dev, float beta) {
+    return launch_update_weights(ctx, 1, K, logw_dev, E_dev, stepsize_dev, beta, nullptr);
+}
+
+int gmmvi_component_stepsize_improvement(gmmvi_ctx* ctx, int K, float* stepsizes_dev, const float* rewards_prev_dev,
+                                         const float* rewards_last_dev, float min_stepsize, float max_stepsize,
+                                         float inc_factor, float dec_factor) {
+    GMMVI_ARG_CHECK(ctx, K >= 1 && stepsizes_dev && rewards_prev_dev && rewards_last_dev);
+    hipLaunchKernelGGL(component_stepsize_kernel, dim3((K + 127) / 128), dim3(128), 0, ctx->stream, K, stepsizes_dev,
+                       rewards_prev_dev, rewards_last_dev, min_stepsize, max_stepsize, inc_factor, dec_factor);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+int gmmvi_weight_stepsize_improvement(gmmvi_ctx* ctx, int K, const float* logw_dev, const float* rewards_last_dev,
+                                      float* state_dev, float min_stepsize, float max_stepsize, float inc_factor,
+                                      float dec_factor) {
+    GMMVI_ARG_CHECK(ctx, K >= 1 && logw_dev && rewards_last_dev && state_dev);
+    hipLaunchKernelGGL(weight_stepsize_kernel, dim3(1), dim3(64), 0, ctx->stream, K, logw_dev, rewards_last_dev,
+                       state_dev, min_stepsize, max_stepsize, inc_factor, dec_factor);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+}  // extern "C"

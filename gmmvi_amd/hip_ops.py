@@ -1,0 +1,208 @@
+"""Shape-checked Python wrappers over the C ABI (include/gmmvi_hip.h).  Every wrapper validates operand shapes on
+the host before the launch, so a kernel never sees a grid/operand mismatch."""
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray
+
+F32, I32 = np.dtype(np.float32), np.dtype(np.int32)
+
+
+def _req(a, shape, dtype=F32, name="array"):
+    if not isinstance(a, DeviceArray):
+        raise TypeError(f"{name}: expected DeviceArray, got {type(a)}")
+    if a.dtype != dtype or tuple(a.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected {dtype}{tuple(shape)}, got {a.dtype}{a.shape}")
+    return a.ptr
+
+
+def _opt(a, shape, dtype=F32, name="array"):
+    return None if a is None else _req(a, shape, dtype, name)
+
+
+def packed_stride(d):
+    s = int(_lib.load().gmmvi_packed_stride(int(d)))
+    if s == 0:
+        raise _lib.GmmviError(f"dimension {d} is not supported by the register-resident kernels (D <= {_lib.MAX_DIM})")
+    return s
+
+
+def pack_components(ctx, means, chols, family=_lib.GAUSS, nu=0.0, want_inverse=False):
+    """-> (packed [K, stride], inv_chols [K,D,D] or None)."""
+    k, d = means.shape
+    _req(means, (k, d), name="means"); _req(chols, (k, d, d), name="chols")
+    packed = ctx.empty((k, packed_stride(d)))
+    inv = ctx.empty((k, d, d)) if want_inverse else None
+    ctx.check(ctx.lib.gmmvi_pack_components(ctx.handle, family, float(nu), k, d, means.ptr, chols.ptr, packed.ptr,
+                                            None if inv is None else inv.ptr))
+    return packed, inv
+
+
+def cholesky(ctx, covs):
+    k, d, _ = covs.shape
+    _req(covs, (k, d, d), name="covs")
+    chols = ctx.empty((k, d, d))
+    ok = ctx.empty((k,), np.int32)
+    ctx.check(ctx.lib.gmmvi_cholesky(ctx.handle, k, d, covs.ptr, chols.ptr, ok.ptr))
+    return chols, ok
+
+
+def mixture_eval(ctx, packed, logw, x, d, family=_lib.GAUSS, nu=0.0, want_ld=False, want_lp=True, want_grad=False):
+    """-> (ld [K,N] | None, lp [N] | None, grad [N,D] | None)."""
+    k = packed.shape[0]
+    n = x.shape[0]
+    _req(packed, (k, packed_stride(d)), name="packed"); _req(logw, (k,), name="logw"); _req(x, (n, d), name="x")
+    ld = ctx.empty((k, n)) if want_ld else None
+    lp = ctx.empty((n,)) if want_lp else None
+    grad = ctx.empty((n, d)) if want_grad else None
+    if n > 0:
+        ctx.check(ctx.lib.gmmvi_mixture_eval(ctx.handle, family, float(nu), k, d, packed.ptr, logw.ptr, x.ptr, n,
+                                             None if ld is None else ld.ptr, None if lp is None else lp.ptr,
+                                             None if grad is None else grad.ptr))
+    return ld, lp, grad
+
+
+def target_planar(ctx, prior_std, goals, likelihood_std, x, want_grad=True):
+    n, d = x.shape
+    g = goals.shape[0]
+    _req(prior_std, (d,), name="prior_std"); _req(goals, (g, 2), name="goals"); _req(x, (n, d), name="x")
+    lp = ctx.empty((n,))
+    grad = ctx.empty((n, d)) if want_grad else None
+    if n > 0:
+        ctx.check(ctx.lib.gmmvi_target_planar(ctx.handle, d, prior_std.ptr, g, goals.ptr, float(likelihood_std), x.ptr,
+                                              n, lp.ptr, None if grad is None else grad.ptr))
+    return lp, grad
+
+
+def sample_components(ctx, means, chols, offsets, n, seed=0, first_index=0, stream_id=0, eps=None):
+    """offsets: DeviceArray int32 [K+1] prefix sums with offsets[K] == n.  -> (x [n,D], mapping [n] int32)."""
+    k, d = means.shape
+    _req(means, (k, d), name="means"); _req(chols, (k, d, d), name="chols"); _req(offsets, (k + 1,), I32, "offsets")
+    if eps is not None:
+        _req(eps, (n, d), name="eps")
+    x = ctx.empty((n, d))
+    mapping = ctx.empty((n,), np.int32)
+    if n > 0:
+        ctx.check(ctx.lib.gmmvi_sample_components(ctx.handle, k, d, means.ptr, chols.ptr, offsets.ptr, n,
+                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_index), int(stream_id),
+                                                  None if eps is None else eps.ptr, x.ptr, mapping.ptr))
+    return x, mapping
+
+
+def philox_normals(ctx, seed, first_index, n, d, stream_id=0):
+    out = ctx.empty((n, d))
+    if n > 0:
+        ctx.check(ctx.lib.gmmvi_philox_normals(ctx.handle, int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_index),
+                                               int(stream_id), n, d, out.ptr))
+    return out
+
+
+def philox_uniforms(ctx, seed, first_index, n, stream_id=1):
+    out = ctx.empty((n,))
+    if n > 0:
+        ctx.check(ctx.lib.gmmvi_philox_uniforms(ctx.handle, int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_index),
+                                                int(stream_id), n, out.ptr))
+    return out
+
+
+def stein(ctx, packed, x, ld, qgrad, bg, tgrad, d, mapping=None, map_offset=0, self_normalized=True,
+          own_samples_only=False):
+    k = packed.shape[0]
+    n = x.shape[0]
+    _req(packed, (k, packed_stride(d)), name="packed"); _req(x, (n, d), name="x")
+    _req(qgrad, (n, d), name="qgrad"); _req(tgrad, (n, d), name="tgrad")
+    if own_samples_only:
+        _req(mapping, (n,), I32, "mapping")
+    else:
+        _req(ld, (k, n), name="ld"); _req(bg, (n,), name="bg")
+    flags = (_lib.SELF_NORMALIZED if self_normalized else 0) | (_lib.OWN_SAMPLES_ONLY if own_samples_only else 0)
+    h_neg = ctx.empty((k, d, d))
+    g_neg = ctx.empty((k, d))
+    ctx.check(ctx.lib.gmmvi_stein(ctx.handle, k, d, packed.ptr, x.ptr, n, None if ld is None else ld.ptr, qgrad.ptr,
+                                  None if bg is None else bg.ptr, tgrad.ptr,
+                                  None if mapping is None else mapping.ptr, int(map_offset), flags, h_neg.ptr,
+                                  g_neg.ptr))
+    return h_neg, g_neg
+
+
+def update_components_kl(ctx, means, chols, h_neg, g_neg, stepsizes, temperature, l2_init, last_eta, l2, num_updates,
+                         want_info=False):
+    k, d = means.shape
+    _req(means, (k, d), name="means"); _req(chols, (k, d, d), name="chols")
+    _req(h_neg, (k, d, d), name="h_neg"); _req(g_neg, (k, d), name="g_neg"); _req(stepsizes, (k,), name="stepsizes")
+    _req(last_eta, (k,), name="last_eta"); _req(l2, (k,), name="l2"); _req(num_updates, (k,), name="num_updates")
+    success = ctx.empty((k,), np.int32)
+    kl = ctx.empty((k,)) if want_info else None
+    probes = ctx.empty((k,), np.int32) if want_info else None
+    ctx.check(ctx.lib.gmmvi_update_components_kl(ctx.handle, k, d, means.ptr, chols.ptr, h_neg.ptr, g_neg.ptr,
+                                                 stepsizes.ptr, float(temperature), float(l2_init), last_eta.ptr,
+                                                 l2.ptr, num_updates.ptr, success.ptr,
+                                                 None if kl is None else kl.ptr,
+                                                 None if probes is None else probes.ptr))
+    return success, kl, probes
+
+
+def update_components_plain(ctx, mode, means, chols, h_neg, g_neg, stepsizes, l2_init, l2, num_updates):
+    k, d = means.shape
+    _req(means, (k, d), name="means"); _req(chols, (k, d, d), name="chols")
+    _req(h_neg, (k, d, d), name="h_neg"); _req(g_neg, (k, d), name="g_neg"); _req(stepsizes, (k,), name="stepsizes")
+    _req(l2, (k,), name="l2"); _req(num_updates, (k,), name="num_updates")
+    success = ctx.empty((k,), np.int32)
+    fn = ctx.lib.gmmvi_update_components_direct if mode == "direct" else ctx.lib.gmmvi_update_components_iblr
+    ctx.check(fn(ctx.handle, k, d, means.ptr, chols.ptr, h_neg.ptr, g_neg.ptr, stepsizes.ptr, float(l2_init), l2.ptr,
+                 num_updates.ptr, success.ptr))
+    return success
+
+
+def expected_log_ratios(ctx, ld, bg, tlp, logq, beta, logw, self_normalized=True, reward_out=None, want_ess=False):
+    k, n = ld.shape
+    _req(ld, (k, n), name="ld"); _req(bg, (n,), name="bg"); _req(tlp, (n,), name="tlp"); _req(logq, (n,), name="logq")
+    _req(logw, (k,), name="logw")
+    if reward_out is not None:
+        _req(reward_out, (k,), name="reward_out")
+    e = ctx.empty((k,))
+    ess = ctx.empty((k,)) if want_ess else None
+    ctx.check(ctx.lib.gmmvi_expected_log_ratios(ctx.handle, k, n, ld.ptr, bg.ptr, tlp.ptr, logq.ptr, float(beta),
+                                                logw.ptr, 1 if self_normalized else 0, e.ptr,
+                                                None if reward_out is None else reward_out.ptr,
+                                                None if ess is None else ess.ptr))
+    return e, ess
+
+
+def update_weights(ctx, mode, logw, e, stepsize, beta, want_info=False):
+    k = logw.shape[0]
+    _req(logw, (k,), name="logw"); _req(e, (k,), name="E"); _req(stepsize, (1,), name="stepsize")
+    info = ctx.empty((2,)) if (want_info and mode == "trust-region") else None
+    if mode == "trust-region":
+        ctx.check(ctx.lib.gmmvi_update_weights_kl(ctx.handle, k, logw.ptr, e.ptr, stepsize.ptr, float(beta),
+                                                  None if info is None else info.ptr))
+    else:
+        ctx.check(ctx.lib.gmmvi_update_weights_direct(ctx.handle, k, logw.ptr, e.ptr, stepsize.ptr, float(beta)))
+    return info
+
+
+def component_stepsize_improvement(ctx, stepsizes, prev, last, mn, mx, inc, dec):
+    k = stepsizes.shape[0]
+    _req(stepsizes, (k,), name="stepsizes"); _req(prev, (k,), name="prev"); _req(last, (k,), name="last")
+    ctx.check(ctx.lib.gmmvi_component_stepsize_improvement(ctx.handle, k, stepsizes.ptr, prev.ptr, last.ptr, float(mn),
+                                                           float(mx), float(inc), float(dec)))
+
+
+def weight_stepsize_improvement(ctx, logw, rewards_last, state, mn, mx, inc, dec):
+    k = logw.shape[0]
+    _req(logw, (k,), name="logw"); _req(rewards_last, (k,), name="rewards_last"); _req(state, (2,), name="state")
+    ctx.check(ctx.lib.gmmvi_weight_stepsize_improvement(ctx.handle, k, logw.ptr, rewards_last.ptr, state.ptr, float(mn),
+                                                        float(mx), float(inc), float(dec)))
+
+
+def combine_partials(ctx, lp_parts, grad_parts, d):
+    r, n = lp_parts.shape
+    _req(lp_parts, (r, n), name="lp_parts")
+    if grad_parts is not None:
+        _req(grad_parts, (r, n, d), name="grad_parts")
+    lp = ctx.empty((n,))
+    grad = ctx.empty((n, d)) if grad_parts is not None else None
+    ctx.check(ctx.lib.gmmvi_combine_partials(ctx.handle, r, n, d, lp_parts.ptr,
+                                             None if grad_parts is None else grad_parts.ptr, lp.ptr,
+                                             None if grad is None else grad.ptr))
+    return lp, grad

@@ -1,0 +1,188 @@
+/*
+ * gmmvi_hip.h -- C ABI of libgmmvi_hip.so: the MI355X (gfx950) implementation of the per-iteration hot path
+ * of OlegArenz/gmmvi (GMMVI.train_iter(): sample selection + background density -> model log-density/gradient
+ * -> Stein/MORE natural-gradient estimate -> per-component KL-constrained update -> weight update).
+ *
+ * The reference has no FFI: its boundary for this path is the Python plug-in surface of
+ * src/gmmvi/optimization/gmmvi.py:163-174 and the modules it calls.  Each entry point below names the
+ * reference call site (path:line relative to /root/reference/src/gmmvi) whose arithmetic it replaces; the
+ * Python classes in gmmvi_amd/ keep the reference's names and argument order and bind these symbols through
+ * ctypes (INTEGRATION.md shows the binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only, no C++/torch types, no exceptions across the boundary;
+ *   - every function returns 0 on success, a negative gmmvi_status otherwise; gmmvi_last_error() gives text;
+ *   - numerical rejection (non-positive Cholesky pivot, NaN) is reported through success[] outputs, never as
+ *     an error code (reference: NaN-Cholesky -> rejected update, ng_based_component_updater.py:320-324,:493);
+ *   - all array arguments are DEVICE pointers obtained from gmmvi_malloc (names end in _dev) unless the
+ *     parameter is documented as host; arrays are dense row-major fp32 (int32 for indices/flags);
+ *   - calls are asynchronous on the context's HIP stream; gmmvi_download / gmmvi_sync synchronise;
+ *   - one context per device per process; a context is not thread-safe (the reference caller is single
+ *     threaded).
+ */
+#ifndef GMMVI_HIP_H
+#define GMMVI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gmmvi_ctx gmmvi_ctx;
+
+enum gmmvi_status {
+    GMMVI_OK = 0,
+    GMMVI_ERR_HIP = -1,        /* a HIP runtime call failed */
+    GMMVI_ERR_ARG = -2,        /* invalid argument / unsupported shape */
+    GMMVI_ERR_RCCL = -3,       /* an RCCL call failed */
+    GMMVI_ERR_STATE = -4       /* call not valid in the context's current state */
+};
+
+enum gmmvi_family {
+    GMMVI_GAUSS = 0,           /* log N(x; m, L L^T)                           models/full_cov_gmm.py:56-62 */
+    GMMVI_STUDENT_T = 1        /* multivariate Student-t, scale operator L     target_distributions/student_t_mixture.py:40-44 */
+};
+
+enum gmmvi_stein_flags {
+    GMMVI_SELF_NORMALIZED = 1, /* ng_estimator.py:171-188 (else :154-169, not symmetrised) */
+    GMMVI_OWN_SAMPLES_ONLY = 2 /* ng_estimator.py:110-118 */
+};
+
+#define GMMVI_MAX_DIM 64       /* register-resident kernels: D <= 64 (D = 300 needs the blocked path) */
+
+/* ---- context, errors, memory ------------------------------------------------------------------------ */
+int gmmvi_device_count(void);
+int gmmvi_ctx_create(gmmvi_ctx** out, int device);
+void gmmvi_ctx_destroy(gmmvi_ctx* ctx);
+const char* gmmvi_last_error(gmmvi_ctx* ctx);          /* ctx may be NULL: last error of a failed create */
+int gmmvi_sync(gmmvi_ctx* ctx);
+int gmmvi_malloc(gmmvi_ctx* ctx, size_t nbytes, void** out_dev);
+int gmmvi_free(gmmvi_ctx* ctx, void* dev);
+int gmmvi_upload(gmmvi_ctx* ctx, void* dst_dev, const void* src_host, size_t nbytes);
+int gmmvi_download(gmmvi_ctx* ctx, void* dst_host, const void* src_dev, size_t nbytes);   /* synchronises */
+int gmmvi_copy(gmmvi_ctx* ctx, void* dst_dev, const void* src_dev, size_t nbytes);
+int gmmvi_fill_f32(gmmvi_ctx* ctx, float* dst_dev, float value, size_t count);
+/* timing helpers for bench.py: HIP events on the context's stream */
+int gmmvi_event_create(gmmvi_ctx* ctx, void** out_event);
+int gmmvi_event_destroy(gmmvi_ctx* ctx, void* event);
+int gmmvi_event_record(gmmvi_ctx* ctx, void* event);
+int gmmvi_event_elapsed_ms(gmmvi_ctx* ctx, void* start, void* stop, float* out_ms);       /* synchronises on stop */
+
+/* ---- component parameter blocks ---------------------------------------------------------------------- */
+/* Number of floats of one packed component block for dimension D (padded dimension, reciprocal diagonal,
+ * row- and column-packed strict lower triangle of L, log-normaliser). */
+size_t gmmvi_packed_stride(int D);
+/* Pack K components (means[K,D], chols[K,D,D] lower-triangular dense) for the density kernels.
+ * family/nu select the log-normaliser (Gaussian: full_cov_gmm.py:60-61; Student-t: student_t_mixture.py:40-44).
+ * Also writes inv_chols[K,D,D] = L^-1 when inv_chols_dev != NULL (sample_db.py:121 tf.linalg.inv(chols)). */
+int gmmvi_pack_components(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* means_dev,
+                          const float* chols_dev, float* packed_dev, float* inv_chols_dev);
+/* Batched Cholesky covs[K,D,D] -> chols[K,D,D] (full_cov_gmm.py:23, :64-68); ok[K] = 0 on a non-positive pivot. */
+int gmmvi_cholesky(gmmvi_ctx* ctx, int K, int D, const float* covs_dev, float* chols_dev, int32_t* ok_dev);
+
+/* ---- densities ----------------------------------------------------------------------------------------- */
+/* For every sample n and component k:  ld[k,n] = log f_k(x_n)  and, over components,
+ *   lp[n]   = logsumexp_k(logw[k] + ld[k,n])
+ *   grad[n] = sum_k softmax_k(logw[k] + ld[k,n]) * d/dx log f_k(x_n)
+ * Replaces FullCovGMM.component_log_densities (models/full_cov_gmm.py:56-62), GMM.log_density /
+ * log_densities_also_individual / log_density_and_grad (models/gmm.py:183-216,274-300), SampleDB.evaluate_background
+ * (optimization/sample_db.py:154-192, with logw = log(count/N)) and the GMM / Student-t targets with their
+ * autodiff gradient (target_distributions/gmm.py:38-40, student_t_mixture.py:66-68, sample_selector.py:74-77).
+ * Any of ld_out_dev[K,N], lp_out_dev[N], grad_out_dev[N,D] may be NULL. */
+int gmmvi_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed_dev,
+                       const float* logw_dev, const float* X_dev, int N, float* ld_out_dev, float* lp_out_dev,
+                       float* grad_out_dev);
+
+/* Planar n-link robot target (target_distributions/planar_robot.py:29-66) and its gradient. goals_dev[G,2]. */
+int gmmvi_target_planar(gmmvi_ctx* ctx, int D, const float* prior_std_dev, int G, const float* goals_dev,
+                        float likelihood_std, const float* X_dev, int N, float* lp_out_dev, float* grad_out_dev);
+
+/* ---- sampling -------------------------------------------------------------------------------------------- */
+/* x = mu_k + L_k eps for offsets[k] <= n < offsets[k+1] (component order), mapping[n] = k.
+ * Replaces GMM.sample_from_components_no_shuffle + FullCovGMM.sample_from_component
+ * (models/gmm.py:361-386, models/full_cov_gmm.py:36-39).  eps_dev[N,D] != NULL: host-provided normals
+ * (bit-reproducible parity runs); else Philox4x32-10 keyed by seed, counter = first_index + n, given stream. */
+int gmmvi_sample_components(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
+                            const int32_t* offsets_dev, int N, uint64_t seed, uint64_t first_index, int stream_id,
+                            const float* eps_dev, float* X_out_dev, int32_t* mapping_out_dev);
+/* Standard normals eps[N,D] of the same Philox stream (tests, GMM.sample). */
+int gmmvi_philox_normals(gmmvi_ctx* ctx, uint64_t seed, uint64_t first_index, int stream_id, int N, int D,
+                         float* eps_out_dev);
+/* Uniforms u[N] in (0,1): word 0 of block 0 (GMM.sample_categorical, models/gmm.py:134-137). */
+int gmmvi_philox_uniforms(gmmvi_ctx* ctx, uint64_t seed, uint64_t first_index, int stream_id, int N,
+                          float* u_out_dev);
+
+/* ---- natural-gradient estimate (Stein) --------------------------------------------------------------------- */
+/* SteinNgEstimator.get_expected_hessian_and_grad (gmmvi_modules/ng_estimator.py:204-263,171-188,154-169).
+ * Inputs: packed model components, samples X[N,D], component log-densities ld[K,N] and model gradient
+ * qgrad[N,D] (from gmmvi_mixture_eval on the same X), background densities bg[N], target gradients tgrad[N,D],
+ * mapping[N] (only read with GMMVI_OWN_SAMPLES_ONLY; map_offset = K-1-max(mapping), ng_estimator.py:244).
+ * Outputs: H_neg[K,D,D] = -E_k[...], g_neg[K,D]. */
+int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* X_dev, int N,
+                const float* ld_dev, const float* qgrad_dev, const float* bg_dev, const float* tgrad_dev,
+                const int32_t* mapping_dev, int map_offset, int flags, float* H_neg_out_dev, float* g_neg_out_dev);
+
+/* ---- component updates --------------------------------------------------------------------------------------- */
+/* KLConstrainedNgBasedComponentUpdater.apply_NG_update (gmmvi_modules/ng_based_component_updater.py:431-524,
+ * bracketing_search :335-429, kl :244-333) with the exact stop rules of SURVEY.md Appendix A.1.
+ * In/out: means[K,D], chols[K,D,D], last_eta[K] (stores eta, not log eta; -1 = none), l2[K].
+ * Out (may be NULL): success[K] (int32 0/1), kl[K], n_probes[K]. */
+int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_dev,
+                               const float* H_neg_dev, const float* g_neg_dev, const float* stepsizes_dev,
+                               float temperature, float l2_init, float* last_eta_dev, float* l2_dev,
+                               float* num_received_updates_dev, int32_t* success_out_dev, float* kl_out_dev,
+                               int32_t* n_probes_out_dev);
+/* DirectNgBasedComponentUpdater (:97-141) and NgBasedComponentUpdaterIblr (:160-223). */
+int gmmvi_update_components_direct(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_dev,
+                                   const float* H_neg_dev, const float* g_neg_dev, const float* stepsizes_dev,
+                                   float l2_init, float* l2_dev, float* num_received_updates_dev,
+                                   int32_t* success_out_dev);
+int gmmvi_update_components_iblr(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_dev,
+                                 const float* H_neg_dev, const float* g_neg_dev, const float* stepsizes_dev,
+                                 float l2_init, float* l2_dev, float* num_received_updates_dev,
+                                 int32_t* success_out_dev);
+
+/* ---- weights, rewards, stepsizes ---------------------------------------------------------------------------- */
+/* WeightUpdater._get_expected_log_ratios (gmmvi_modules/weight_updater.py:56-75), self-normalised branch when
+ * self_normalized != 0: E[k] = sum_n softmax_n(ld[k,n] - bg[n]) (tlp[n] - beta*logq[n]);
+ * reward[k] = beta*logw[k] + E[k] (:73).  ess_out_dev (may be NULL) receives 1/sum_n w^2 per component
+ * (sample_selector.py:154-158 uses the same weights). */
+int gmmvi_expected_log_ratios(gmmvi_ctx* ctx, int K, int N, const float* ld_dev, const float* bg_dev,
+                              const float* tlp_dev, const float* logq_dev, float beta, const float* logw_dev,
+                              int self_normalized, float* E_out_dev, float* reward_out_dev, float* ess_out_dev);
+/* TrustRegionBasedWeightUpdater (weight_updater.py:164-279) followed by GMM.replace_weights (models/gmm.py:173-181).
+ * stepsize_dev[1] is the KL bound.  kl_eta_out_dev[2] (may be NULL) = (kl, eta). No-op when K == 1 (:275). */
+int gmmvi_update_weights_kl(gmmvi_ctx* ctx, int K, float* logw_dev, const float* E_dev, const float* stepsize_dev,
+                            float beta, float* kl_eta_out_dev);
+/* DirectWeightUpdater (weight_updater.py:123-141). */
+int gmmvi_update_weights_direct(gmmvi_ctx* ctx, int K, float* logw_dev, const float* E_dev,
+                                const float* stepsize_dev, float beta);
+/* ImprovementBasedComponentStepsizeAdaptation.update_stepsize (component_stepsize_adaptation.py:165-188):
+ * rewards_prev/rewards_last are reward_history[:, -2] / [:, -1]. */
+int gmmvi_component_stepsize_improvement(gmmvi_ctx* ctx, int K, float* stepsizes_dev, const float* rewards_prev_dev,
+                                         const float* rewards_last_dev, float min_stepsize, float max_stepsize,
+                                         float inc_factor, float dec_factor);
+/* ImprovementBasedWeightStepsizeAdaptation._update_stepsize (weight_stepsize_adaptation.py:141-156).
+ * state_dev[2] = (stepsize, previous elbo proxy); updated in place. */
+int gmmvi_weight_stepsize_improvement(gmmvi_ctx* ctx, int K, const float* logw_dev, const float* rewards_last_dev,
+                                      float* state_dev, float min_stepsize, float max_stepsize, float inc_factor,
+                                      float dec_factor);
+
+/* ---- multi-GPU exchange (component shards) ----------------------------------------------------- */
+/* RCCL communicator over the ranks of one node; unique_id is the 128-byte ncclUniqueId produced by rank 0. */
+int gmmvi_comm_unique_id(char* out_id_128);
+int gmmvi_comm_init(gmmvi_ctx* ctx, const char* unique_id_128, int n_ranks, int rank);
+int gmmvi_comm_destroy(gmmvi_ctx* ctx);
+int gmmvi_allgather_f32(gmmvi_ctx* ctx, const float* send_dev, float* recv_dev, size_t count_per_rank);
+int gmmvi_allreduce_f32(gmmvi_ctx* ctx, float* buf_dev, size_t count, int op /* 0 sum, 1 max */);
+/* Combine per-rank partial mixtures: given gathered (lp_r[n], grad_r[n,D]) of R ranks, writes
+ * lp[n] = LSE_r lp_r[n], grad[n] = sum_r exp(lp_r[n]-lp[n]) grad_r[n]  (the E2/E3 exchange of SURVEY.md 8e). */
+int gmmvi_combine_partials(gmmvi_ctx* ctx, int R, int N, int D, const float* lp_parts_dev,
+                           const float* grad_parts_dev, float* lp_out_dev, float* grad_out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMMVI_HIP_H */

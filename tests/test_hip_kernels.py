@@ -1,0 +1,321 @@
+"""GPU parity of every HIP kernel against the fp64 oracle (BASELINE.md section 4 tolerances: kernel outputs rtol 1e-4 /
+atol 1e-5 unless a looser bound is stated with its reason).  All calls go through the C ABI (gmmvi_amd.hip_ops)."""
+import numpy as np
+import pytest
+from scipy.special import logsumexp
+
+from oracle import philox, gmm as ogmm, targets as otargets, stein as ostein, updaters as oupd, weights as oweights, \
+    stepsizes as osteps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from gmmvi_amd.device import get_context
+    return get_context()
+
+
+def ops():
+    from gmmvi_amd import hip_ops
+    return hip_ops
+
+
+def random_gmm(rng, k, d, spread=3.0, scale=1.0):
+    means = rng.normal(size=(k, d)) * spread
+    covs = []
+    for _ in range(k):
+        a = rng.normal(size=(d, d))
+        covs.append(scale * (a @ a.T / d + 0.3 * np.eye(d)))
+    w = rng.random(k) + 0.1
+    return ogmm.FullCovGMM(w / w.sum(), means, np.stack(covs))
+
+
+def upload_model(ctx, m):
+    return (ctx.asarray(m.log_weights), ctx.asarray(m.means), ctx.asarray(m.chol_cov))
+
+
+SHAPES = [(3, 4, 64), (1, 2, 5), (8, 20, 512), (5, 10, 200), (7, 3, 130), (20, 32, 300), (4, 50, 100), (3, 64, 70),
+          (40, 20, 1000)]
+
+
+def test_philox_bits_and_normals(ctx):
+    u = ops().philox_uniforms(ctx, 12345, 7, 1000, stream_id=1).numpy()
+    np.testing.assert_array_equal(u, philox.uniform01(12345, 7, 1000, 1, dtype=np.float32))   # bit-exact integers
+    e = ops().philox_normals(ctx, 99, 1 << 33, 257, 7, stream_id=0).numpy()
+    np.testing.assert_allclose(e, philox.normals(99, 1 << 33, 257, 7, 0), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("k,d,n", SHAPES)
+def test_pack_and_inverse(ctx, rng, k, d, n):
+    m = random_gmm(rng, k, d)
+    _, means, chols = upload_model(ctx, m)
+    packed, inv = ops().pack_components(ctx, means, chols, want_inverse=True)
+    np.testing.assert_allclose(inv.numpy(), np.linalg.inv(m.chol_cov), rtol=2e-4, atol=2e-5)
+    covs = ctx.asarray(m.covs)
+    ch, ok = ops().cholesky(ctx, covs)
+    assert ok.numpy().all()
+    np.testing.assert_allclose(ch.numpy(), m.chol_cov, rtol=2e-4, atol=2e-5)
+    bad = m.covs.copy(); bad[0] = -np.eye(d)
+    ch, ok = ops().cholesky(ctx, ctx.asarray(bad))
+    assert ok.numpy()[0] == 0 and np.isnan(ch.numpy()[0]).all() and ok.numpy()[1:].all()
+
+
+@pytest.mark.parametrize("k,d,n", SHAPES)
+def test_mixture_eval_gauss(ctx, rng, k, d, n):
+    m = random_gmm(rng, k, d)
+    x = m.means[rng.integers(0, k, n)] + rng.normal(size=(n, d)) * 1.5
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    ld, lp, grad = ops().mixture_eval(ctx, packed, logw, ctx.asarray(x), d, want_ld=True, want_lp=True, want_grad=True)
+    lq, g, cld = m.log_density_and_grad(x.astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(ld.numpy(), cld, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(lp.numpy(), lq, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(grad.numpy(), g, rtol=1e-3, atol=1e-3)
+    # no-grad variant gives the same densities
+    _, lp2, _ = ops().mixture_eval(ctx, packed, logw, ctx.asarray(x), d)
+    np.testing.assert_allclose(lp2.numpy(), lp.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_mixture_eval_far_samples_and_empty(ctx, rng):
+    m = random_gmm(rng, 6, 5)
+    x = rng.normal(size=(100, 5)) * 200                     # far tails: LSE must not underflow to -inf/NaN
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    _, lp, grad = ops().mixture_eval(ctx, packed, logw, ctx.asarray(x), 5, want_grad=True)
+    lq, g, _ = m.log_density_and_grad(x.astype(np.float32).astype(np.float64))
+    assert np.isfinite(lp.numpy()).all()
+    np.testing.assert_allclose(lp.numpy(), lq, rtol=2e-4)
+    np.testing.assert_allclose(grad.numpy(), g, rtol=2e-3, atol=1e-2)
+    _, lp0, _ = ops().mixture_eval(ctx, packed, logw, ctx.empty((0, 5)), 5)
+    assert lp0.shape == (0,)
+
+
+@pytest.mark.parametrize("d,c,n", [(6, 10, 300), (20, 10, 1000), (3, 2, 65)])
+def test_student_t_target(ctx, rng, d, c, n):
+    t = otargets.make_stm_target(d, rng)
+    x = t.means[rng.integers(0, t.means.shape[0], n)] + rng.normal(size=(n, d)) * 2
+    from gmmvi_amd import _lib
+    packed, _ = ops().pack_components(ctx, ctx.asarray(t.means), ctx.asarray(t.chols), family=_lib.STUDENT_T, nu=2.0)
+    _, lp, grad = ops().mixture_eval(ctx, packed, ctx.asarray(t.log_weights), ctx.asarray(x), d, family=_lib.STUDENT_T,
+                                     nu=2.0, want_grad=True)
+    rlp, rg = t.log_density_and_grad(x.astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(lp.numpy(), rlp, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(grad.numpy(), rg, rtol=2e-3, atol=2e-3)
+
+
+def test_planar_target(ctx, rng):
+    t = otargets.PlanarRobotTarget(10, 4)
+    th = rng.normal(size=(500, 10)) * t.prior_stds
+    lp, grad = ops().target_planar(ctx, ctx.asarray(t.prior_stds), ctx.asarray(t.goals), t.likelihood_std,
+                                   ctx.asarray(th))
+    rlp, rg = t.log_density_and_grad(th.astype(np.float32).astype(np.float64))
+    # log-likelihood values are O(1e5) (0.01 m goal std): relative tolerance only
+    np.testing.assert_allclose(lp.numpy(), rlp, rtol=2e-5)
+    np.testing.assert_allclose(grad.numpy(), rg, rtol=2e-3, atol=1.0)
+
+
+@pytest.mark.parametrize("k,d,n", SHAPES[:6])
+def test_sample_components(ctx, rng, k, d, n):
+    m = random_gmm(rng, k, d)
+    n_k = rng.multinomial(n, np.ones(k) / k)
+    offs = np.concatenate([[0], np.cumsum(n_k)]).astype(np.int32)
+    _, means, chols = upload_model(ctx, m)
+    eps = philox.normals(3, 100, n, d)
+    x, mp = ops().sample_components(ctx, means, chols, ctx.asarray(offs, np.int32), n, eps=ctx.asarray(eps))
+    rx, rmp = m.sample_from_components_no_shuffle(n_k, eps.astype(np.float32).astype(np.float64))
+    np.testing.assert_array_equal(mp.numpy(), rmp)
+    np.testing.assert_allclose(x.numpy(), rx, rtol=1e-5, atol=1e-5)
+    # device Philox stream == oracle Philox stream
+    x2, _ = ops().sample_components(ctx, means, chols, ctx.asarray(offs, np.int32), n, seed=3, first_index=100)
+    np.testing.assert_allclose(x2.numpy(), rx, rtol=1e-4, atol=1e-4)
+
+
+def _stein_inputs(rng, k, d, n):
+    m = random_gmm(rng, k, d)
+    n_k = rng.multinomial(n, np.ones(k) / k)
+    x, mapping = m.sample_from_components_no_shuffle(n_k, philox.normals(5, 0, n, d))
+    x = x.astype(np.float32).astype(np.float64)
+    tgt = otargets.make_gmm_target(d, rng, 3)
+    tlp, tg = tgt.log_density_and_grad(x)
+    tg = tg.astype(np.float32).astype(np.float64)
+    cnt = np.maximum(n_k, 1e-9)
+    bg = logsumexp(m.component_log_densities(x) + np.log(cnt / cnt.sum())[:, None], axis=0)
+    return m, x, mapping, tlp, tg, bg
+
+
+@pytest.mark.parametrize("k,d,n", [(3, 4, 64), (8, 20, 512), (5, 10, 700), (2, 2, 33), (6, 31, 300), (3, 40, 260),
+                                   (40, 20, 3000)])
+@pytest.mark.parametrize("snis", [True, False])
+def test_stein(ctx, rng, k, d, n, snis):
+    m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    xd = ctx.asarray(x)
+    ld, lp, qg = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_grad=True)
+    h, g = ops().stein(ctx, packed, xd, ld, qg, ctx.asarray(bg), ctx.asarray(tg), d, self_normalized=snis)
+    rh, rg = ostein.get_expected_hessian_and_grad(m, x, mapping, bg, tlp, tg, False, snis)
+    scale_h = np.abs(rh).max(axis=(1, 2), keepdims=True)
+    scale_g = np.abs(rg).max(axis=1, keepdims=True)
+    # importance weights exp(ld - bg) amplify the fp32 error of ld (abs ~1e-4): 1e-3 of the per-component magnitude
+    assert np.abs(h.numpy() - rh).max() <= 2e-3 * scale_h.max() or np.all(np.abs(h.numpy() - rh) <= 2e-3 * scale_h)
+    assert np.all(np.abs(h.numpy() - rh) <= 3e-3 * scale_h + 1e-6)
+    assert np.all(np.abs(g.numpy() - rg) <= 3e-3 * scale_g + 1e-6)
+
+
+def test_stein_own_samples(ctx, rng):
+    k, d, n = 4, 6, 400
+    m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    xd = ctx.asarray(x)
+    ld, lp, qg = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_grad=True)
+    mp = mapping + 7                                  # DB indices: offset so that max(mapping) -> K-1
+    h, g = ops().stein(ctx, packed, xd, ld, qg, ctx.asarray(bg), ctx.asarray(tg), d,
+                       mapping=ctx.asarray(mp, np.int32), map_offset=k - 1 - int(mp.max()), own_samples_only=True)
+    rh, rg = ostein.get_expected_hessian_and_grad(m, x, mp, bg, tlp, tg, True, True)
+    np.testing.assert_allclose(h.numpy(), rh, rtol=2e-3, atol=2e-3 * np.abs(rh).max())
+    np.testing.assert_allclose(g.numpy(), rg, rtol=2e-3, atol=2e-3 * np.abs(rg).max())
+
+
+def _update_inputs(rng, k, d):
+    m = random_gmm(rng, k, d)
+    hs = np.stack([(lambda b: b @ b.T / d)(rng.normal(size=(d, d))) for _ in range(k)])
+    if k > 2:
+        hs[2] = -0.01 * hs[2]
+    gs = rng.normal(size=(k, d))
+    return m, hs.astype(np.float32).astype(np.float64), gs.astype(np.float32).astype(np.float64)
+
+
+@pytest.mark.parametrize("k,d", [(3, 4), (8, 20), (5, 10), (1, 2), (4, 50), (2, 64)])
+def test_update_components_kl(ctx, rng, k, d):
+    m, hs, gs = _update_inputs(rng, k, d)
+    m32 = ogmm.FullCovGMM(m.weights, m.means.astype(np.float32), m.covs.astype(np.float32))
+    w = ogmm.GmmWrapper(m32, 0.1, 1e-12, 4)
+    w.stepsizes = np.linspace(0.05, 0.5, k)
+    logw, means, chols = upload_model(ctx, m32)
+    last_eta = ctx.asarray(w.last_log_etas); l2 = ctx.asarray(w.l2_regularizers)
+    nupd = ctx.asarray(w.num_received_updates); steps = ctx.asarray(w.stepsizes)
+    for round_ in range(2):                          # cold bracket, then warm start
+        succ, kl, probes = ops().update_components_kl(ctx, means, chols, ctx.asarray(hs), ctx.asarray(gs), steps, 1.0,
+                                                      1e-12, last_eta, l2, nupd, want_info=True)
+        rs, retas, rkls, rprobes = oupd.apply_ng_update_kl(w, hs, gs, w.stepsizes, 1.0, traces=[])
+        np.testing.assert_array_equal(succ.numpy().astype(bool), rs)
+        np.testing.assert_array_equal(probes.numpy(), rprobes)          # same bisection path
+        np.testing.assert_allclose(last_eta.numpy(), retas, rtol=1e-5)
+        np.testing.assert_allclose(kl.numpy(), rkls, rtol=5e-3, atol=1e-5)
+        np.testing.assert_allclose(means.numpy(), m32.means, rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(chols.numpy(), m32.chol_cov, rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(l2.numpy(), w.l2_regularizers, rtol=1e-6)
+        np.testing.assert_allclose(nupd.numpy(), w.num_received_updates)
+
+
+def test_update_components_kl_failure(ctx, rng):
+    m, hs, gs = _update_inputs(rng, 3, 5)
+    hs[0] = np.nan
+    hs[1] = -1e6 * np.eye(5)                         # hopelessly indefinite: no eta in the bracket is feasible ... or is
+    w = ogmm.GmmWrapper(m, 0.1, 1e-12, 4)
+    logw, means, chols = upload_model(ctx, m)
+    old_means, old_chols = means.numpy(), chols.numpy()
+    last_eta = ctx.asarray(w.last_log_etas); l2 = ctx.asarray(w.l2_regularizers); nupd = ctx.asarray(w.num_received_updates)
+    succ, kl, probes = ops().update_components_kl(ctx, means, chols, ctx.asarray(hs), ctx.asarray(gs),
+                                                  ctx.asarray(w.stepsizes), 1.0, 1e-12, last_eta, l2, nupd, want_info=True)
+    rs, retas, _, _ = oupd.apply_ng_update_kl(w, hs, gs, w.stepsizes, 1.0, traces=[])
+    np.testing.assert_array_equal(succ.numpy().astype(bool), rs)
+    assert not rs[0]
+    np.testing.assert_array_equal(means.numpy()[0], old_means[0])
+    np.testing.assert_array_equal(chols.numpy()[0], old_chols[0])
+    np.testing.assert_allclose(last_eta.numpy(), retas, rtol=1e-4)
+    np.testing.assert_allclose(l2.numpy(), w.l2_regularizers, rtol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["direct", "iblr"])
+def test_update_components_plain(ctx, rng, mode):
+    k, d = 4, 6
+    m, hs, gs = _update_inputs(rng, k, d)
+    w = ogmm.GmmWrapper(m, 0.1, 1e-12, 4)
+    steps = np.full(k, 0.3)
+    logw, means, chols = upload_model(ctx, m)
+    l2 = ctx.asarray(w.l2_regularizers); nupd = ctx.asarray(w.num_received_updates)
+    for round_ in range(2):
+        succ = ops().update_components_plain(ctx, mode, means, chols, ctx.asarray(hs), ctx.asarray(gs),
+                                             ctx.asarray(steps), 1e-12, l2, nupd)
+        rs = (oupd.apply_ng_update_direct if mode == "direct" else oupd.apply_ng_update_iblr)(w, hs, gs, steps)
+        np.testing.assert_array_equal(succ.numpy().astype(bool), rs)
+        np.testing.assert_allclose(means.numpy(), m.means, rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(chols.numpy(), m.chol_cov, rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(l2.numpy(), w.l2_regularizers, rtol=1e-6)
+
+
+@pytest.mark.parametrize("k,n", [(3, 64), (8, 512), (100, 3000), (1, 10)])
+def test_expected_log_ratios(ctx, rng, k, n):
+    ld = rng.normal(size=(k, n)) * 3 - 10
+    bg = logsumexp(ld, axis=0) - np.log(k) + rng.normal(size=n) * 0.1
+    tlp = rng.normal(size=n) * 5 - 20
+    logq = logsumexp(ld - np.log(k), axis=0)
+    logw = np.log(rng.dirichlet(np.ones(k)))
+    for snis in (True, False):
+        e, ess = ops().expected_log_ratios(ctx, ctx.asarray(ld), ctx.asarray(bg), ctx.asarray(tlp), ctx.asarray(logq),
+                                           1.0, ctx.asarray(logw), snis, want_ess=True)
+        lw = ld - bg[None]
+        if snis:
+            iw = np.exp(lw - logsumexp(lw, axis=1, keepdims=True))
+            ref = iw @ (tlp - logq)
+            np.testing.assert_allclose(ess.numpy(), 1 / np.sum(iw ** 2, axis=1), rtol=1e-3)
+        else:
+            ref = np.exp(lw) @ (tlp - logq) / n
+        np.testing.assert_allclose(e.numpy(), ref, rtol=2e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k", [2, 6, 100, 257])
+def test_update_weights(ctx, rng, k):
+    lw = np.log(rng.dirichlet(np.ones(k)))
+    lw = (lw - logsumexp(lw)).astype(np.float32).astype(np.float64)
+    elr = (rng.normal(size=k) * 3).astype(np.float32).astype(np.float64)
+    for eps in [0.01, 0.3, 1.0, 1e4]:
+        logw = ctx.asarray(lw)
+        info = ops().update_weights(ctx, "trust-region", logw, ctx.asarray(elr), ctx.asarray([eps]), 1.0, True)
+        kl, eta, nl = oweights.weights_bracketing_search(lw, elr, eps, 1.0)
+        nl = nl - logsumexp(nl)
+        np.testing.assert_allclose(info.numpy()[1], eta, rtol=1e-4)
+        np.testing.assert_allclose(logw.numpy(), nl, rtol=1e-4, atol=2e-4)
+    logw = ctx.asarray(lw)
+    ops().update_weights(ctx, "direct", logw, ctx.asarray(elr), ctx.asarray([0.5]), 1.0)
+    u = lw + 0.5 * elr
+    nl = np.maximum(u - logsumexp(u), -69.07); nl -= logsumexp(nl)
+    np.testing.assert_allclose(logw.numpy(), nl, rtol=1e-4, atol=2e-4)
+
+
+def test_stepsize_kernels(ctx, rng):
+    k = 37
+    steps = rng.random(k) * 0.9 + 0.002
+    prev, last = rng.normal(size=k), rng.normal(size=k)
+    prev[:5] = last[:5] = np.finfo(np.float32).min
+    s = ctx.asarray(steps)
+    ops().component_stepsize_improvement(ctx, s, ctx.asarray(prev), ctx.asarray(last), 0.001, 1.0, 1.15, 0.85)
+    ref = osteps.component_stepsize_improvement(steps.astype(np.float32), np.stack([prev, last], 1).astype(np.float32),
+                                                0.001, 1.0, 1.15, 0.85)
+    np.testing.assert_allclose(s.numpy(), ref, rtol=1e-6)
+
+    class W:
+        pass
+    w = W(); w.log_weights = np.log(np.ones(k) / k); w.weights = np.exp(w.log_weights)
+    w.reward_history = np.full((k, 2), np.finfo(np.float32).min)
+    a = osteps.WeightStepsizeImprovement(1.0, 1e-4, 1.0, 1.15, 0.85)
+    state = ctx.asarray([1.0, np.finfo(np.float32).min])
+    for rewards in [w.reward_history[:, -1], rng.normal(size=k) - 5, rng.normal(size=k) - 50, rng.normal(size=k)]:
+        w.reward_history = np.stack([rewards, rewards], 1)
+        ops().weight_stepsize_improvement(ctx, ctx.asarray(w.log_weights), ctx.asarray(rewards), state, 1e-4, 1.0, 1.15,
+                                          0.85)
+        ref = a.update_stepsize(w)
+        np.testing.assert_allclose(state.numpy()[0], ref, rtol=1e-6)
+
+
+def test_combine_partials(ctx, rng):
+    r, n, d = 4, 300, 5
+    lp = rng.normal(size=(r, n)) * 5
+    g = rng.normal(size=(r, n, d))
+    out_lp, out_g = ops().combine_partials(ctx, ctx.asarray(lp), ctx.asarray(g), d)
+    ref_lp = logsumexp(lp, axis=0)
+    np.testing.assert_allclose(out_lp.numpy(), ref_lp, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(out_g.numpy(), np.einsum('rn,rnd->nd', np.exp(lp - ref_lp[None]), g), rtol=1e-4, atol=1e-5)
