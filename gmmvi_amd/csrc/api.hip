@@ -121,6 +121,45 @@ int gmmvi_fill_f32(gmmvi_ctx* ctx, float* dst_dev, float value, size_t count) {
     return GMMVI_OK;
 }
 
+__global__ void gather_rows_kernel(const uint32_t* __restrict__ src, const int32_t* __restrict__ idx, int n_rows,
+                                   int row_words, uint32_t* __restrict__ dst) {
+    const long total = (long)n_rows * row_words;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / row_words, c = e % row_words;
+        dst[e] = src[(long)idx[r] * row_words + c];
+    }
+}
+
+int gmmvi_gather_rows(gmmvi_ctx* ctx, const void* src_dev, const int32_t* idx_dev, int n_rows, int row_words,
+                      void* dst_dev) {
+    GMMVI_ARG_CHECK(ctx, n_rows >= 0 && row_words >= 1);
+    if (n_rows == 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, src_dev && idx_dev && dst_dev);
+    long total = (long)n_rows * row_words;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t*)src_dev, idx_dev,
+                       n_rows, row_words, (uint32_t*)dst_dev);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+__global__ void exp_f32_kernel(float* dst, const float* src, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = expf(src[i]);
+}
+
+int gmmvi_exp_f32(gmmvi_ctx* ctx, float* dst_dev, const float* src_dev, size_t count) {
+    if (count == 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, dst_dev && src_dev);
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(exp_f32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dst_dev, src_dev, count);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
 int gmmvi_event_create(gmmvi_ctx* ctx, void** out_event) {
     GMMVI_ARG_CHECK(ctx, out_event != nullptr);
     hipEvent_t ev;

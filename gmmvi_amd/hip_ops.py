@@ -206,3 +206,24 @@ def combine_partials(ctx, lp_parts, grad_parts, d):
                                              None if grad_parts is None else grad_parts.ptr, lp.ptr,
                                              None if grad is None else grad.ptr))
     return lp, grad
+
+
+def gather_rows(ctx, src, idx):
+    """dst[i] = src[idx[i]] along axis 0 (idx: DeviceArray int32 or host array)."""
+    if not isinstance(idx, DeviceArray):
+        idx = ctx.asarray(np.asarray(idx, np.int32), np.int32)
+    n = idx.shape[0]
+    _req(idx, (n,), I32, "idx")
+    inner = src.shape[1:]
+    words = int(np.prod(inner, dtype=np.int64)) if inner else 1
+    dst = ctx.empty((n,) + tuple(inner), src.dtype)
+    if n > 0:
+        ctx.check(ctx.lib.gmmvi_gather_rows(ctx.handle, src.ptr, idx.ptr, n, words, dst.ptr))
+    return dst
+
+
+def exp_into(ctx, dst, src):
+    if dst.shape != src.shape or dst.dtype != F32 or src.dtype != F32:
+        raise ValueError("exp_into: shape/dtype mismatch")
+    ctx.check(ctx.lib.gmmvi_exp_f32(ctx.handle, dst.ptr, src.ptr, src.size))
+    return dst

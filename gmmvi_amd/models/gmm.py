@@ -1,0 +1,156 @@
+"""Host-side mirror of the reference's GMM base class (reference: src/gmmvi/models/gmm.py:5-418).
+
+Parameters live in HBM as ``DeviceArray``s (log_weights [K], means [K,D], chol_cov [K,D,D]); every density /
+sampling method launches the HIP kernels of libgmmvi_hip.so.  Method names, argument order and return tuples are
+the reference's; returned arrays are device resident and offer ``.numpy()``.
+"""
+import numpy as np
+
+from .. import _lib, hip_ops
+from ..device import DeviceArray, get_context
+
+STREAM_COMPONENT_NORMALS = 0   # oracle/philox.py documents the stream layout
+STREAM_CATEGORICAL = 1
+STREAM_MIXTURE_NORMALS = 2
+
+
+class GMM:
+    def __init__(self, log_weights, means, chol_covs, ctx=None):
+        self.ctx = ctx if ctx is not None else get_context()
+        self.means = self.ctx.asarray(means)
+        self.chol_cov = self.ctx.asarray(chol_covs)
+        self.diagonal_covs = self.chol_cov.ndim == 2
+        self.num_dimensions = int(self.means.shape[1])
+        self._const_log_det = 0.5 * self.num_dimensions * np.log(2 * np.pi)
+        self.log_weights = self.ctx.asarray(log_weights)
+        self._packed = None
+        self.seed = 0                 # Philox key for sample(); the runner sets it from the config seed
+        self._sample_counter = 0      # index into the mixture-sampling Philox streams
+        self.replace_weights(self.log_weights)                                   # gmm.py:34
+
+    # ---- packed parameter blocks for the kernels (rebuilt lazily after every component change) -----------
+    def _invalidate(self):
+        self._packed = None
+
+    @property
+    def packed(self):
+        if self._packed is None:
+            self._packed, _ = hip_ops.pack_components(self.ctx, self.means, self.chol_cov)
+        return self._packed
+
+    # ---- properties -------------------------------------------------------------------------------------
+    @property
+    def num_components(self):
+        return int(self.log_weights.shape[0])
+
+    @property
+    def weights(self):
+        """gmm.py:165-171 (host array: used for metrics only)."""
+        return np.exp(self.log_weights.numpy())
+
+    @property
+    def covs(self):
+        raise NotImplementedError
+
+    # ---- densities (gmm.py:183-216, 274-300) ----------------------------------------------------------------
+    def _x(self, samples):
+        return self.ctx.asarray(samples)
+
+    def component_log_densities(self, samples):
+        raise NotImplementedError
+
+    def log_densities_also_individual(self, samples):
+        ld, lp, _ = hip_ops.mixture_eval(self.ctx, self.packed, self.log_weights, self._x(samples),
+                                         self.num_dimensions, want_ld=True, want_lp=True)
+        return lp, ld
+
+    def log_density(self, samples):
+        _, lp, _ = hip_ops.mixture_eval(self.ctx, self.packed, self.log_weights, self._x(samples),
+                                        self.num_dimensions, want_lp=True)
+        return lp
+
+    def density(self, samples):
+        return np.exp(self.log_density(samples).numpy())
+
+    def log_density_and_grad(self, samples):
+        """-> (log q [N], grad_x log q [N,D], component log densities [K,N])."""
+        ld, lp, grad = hip_ops.mixture_eval(self.ctx, self.packed, self.log_weights, self._x(samples),
+                                            self.num_dimensions, want_ld=True, want_lp=True, want_grad=True)
+        return lp, grad, ld
+
+    def marginal_log_density(self, samples, dimension):
+        """gmm.py:218-234 (plots only: evaluated on the host from downloaded parameters)."""
+        from scipy.special import logsumexp
+        ld = self.component_marginal_log_densities(samples, dimension)
+        return logsumexp(ld + self.log_weights.numpy()[:, None], axis=0)
+
+    # ---- entropies (gmm.py:249-272) ---------------------------------------------------------------------------
+    def gaussian_entropy(self, chol):
+        raise NotImplementedError
+
+    def component_entropies(self):
+        chols = self.chol_cov.numpy()
+        return np.array([self.gaussian_entropy(c) for c in chols], dtype=np.float32)
+
+    def get_average_entropy(self):
+        return float(np.sum(self.weights * self.component_entropies()))
+
+    # ---- sampling -----------------------------------------------------------------------------------------------
+    def sample_from_components_no_shuffle(self, samples_per_component, seed=None, first_index=0, eps=None,
+                                          stream_id=STREAM_COMPONENT_NORMALS):
+        """gmm.py:361-386: component-ordered samples and their mapping.  ``samples_per_component`` is a host
+        int array [K]; normals come from the Philox stream (seed, first_index + n) or from ``eps`` [N,D]."""
+        n_k = np.asarray(samples_per_component, dtype=np.int64).reshape(-1)
+        if n_k.shape[0] != self.num_components:
+            raise ValueError("samples_per_component must have one entry per component")
+        offsets = np.concatenate([[0], np.cumsum(n_k)]).astype(np.int32)
+        n = int(offsets[-1])
+        return hip_ops.sample_components(self.ctx, self.means, self.chol_cov, self.ctx.asarray(offsets, np.int32), n,
+                                         seed=self.seed if seed is None else seed, first_index=first_index,
+                                         stream_id=stream_id,
+                                         eps=None if eps is None else self.ctx.asarray(eps))
+
+    def sample_from_component(self, index, num_samples):
+        n_k = np.zeros(self.num_components, np.int64)
+        n_k[index] = num_samples
+        first = self._sample_counter
+        self._sample_counter += int(num_samples)
+        return self.sample_from_components_no_shuffle(n_k, first_index=first, stream_id=STREAM_MIXTURE_NORMALS)[0]
+
+    def sample_categorical(self, num_samples):
+        """gmm.py:124-137: first cumulative-weight threshold exceeding a uniform draw."""
+        u = hip_ops.philox_uniforms(self.ctx, self.seed, self._sample_counter, num_samples, STREAM_CATEGORICAL).numpy()
+        thresholds = np.cumsum(np.exp(self.log_weights.numpy().astype(np.float64)))
+        return np.argmax(u.astype(np.float64)[:, None] < thresholds[None, :], axis=1).astype(np.int32)
+
+    def sample(self, num_samples):
+        """gmm.py:139-163: (samples grouped by component, component index of every *draw*)."""
+        num_samples = int(num_samples)
+        comp = self.sample_categorical(num_samples)
+        counts = np.bincount(comp, minlength=self.num_components)
+        first = self._sample_counter
+        self._sample_counter += num_samples
+        x, _ = self.sample_from_components_no_shuffle(counts, first_index=first, stream_id=STREAM_MIXTURE_NORMALS)
+        return x, comp
+
+    # ---- mutation -----------------------------------------------------------------------------------------------
+    def replace_weights(self, new_log_weights):
+        """gmm.py:173-181: normalises by log-sum-exp."""
+        from scipy.special import logsumexp
+        lw = np.asarray(new_log_weights.numpy() if isinstance(new_log_weights, DeviceArray) else new_log_weights,
+                        dtype=np.float64)
+        self.log_weights = self.ctx.asarray((lw - logsumexp(lw)).astype(np.float32))
+
+    def replace_components(self, new_means, new_chols):
+        """gmm.py:401-418."""
+        self.means = self.ctx.asarray(new_means)
+        self.chol_cov = self.ctx.asarray(new_chols)
+        self._invalidate()
+
+    def remove_component(self, idx):
+        """gmm.py:388-398."""
+        idx = int(idx)
+        self.replace_weights(np.delete(self.log_weights.numpy(), idx))
+        self.means = self.ctx.asarray(np.delete(self.means.numpy(), idx, axis=0))
+        self.chol_cov = self.ctx.asarray(np.delete(self.chol_cov.numpy(), idx, axis=0))
+        self._invalidate()

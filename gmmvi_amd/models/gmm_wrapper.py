@@ -1,0 +1,157 @@
+"""GmmWrapper: per-component learner state beside the model (reference: src/gmmvi/models/gmm_wrapper.py:4-182).
+
+State the kernels read/write every iteration lives in HBM (stepsizes, l2_regularizers, last_log_etas,
+num_received_updates, and the reward / weight histories as *ring buffers* [H, K] instead of the reference's
+concat-shift of a [K, 10000] tensor twice per iteration, gmm_wrapper.py:158,:182).  ``reward_history`` and
+``weight_history`` materialise the reference's [K, H] layout (newest entry last) on demand.
+"""
+import numpy as np
+
+from .. import hip_ops
+from .gmm import GMM
+
+FLOAT32_MIN = float(np.finfo(np.float32).min)
+
+
+class GmmWrapper:
+    @staticmethod
+    def build_from_config(model: GMM, config: dict):
+        """gmm_wrapper.py:33-58."""
+        nca = config["num_component_adapter_config"]
+        max_reward_history_length = 2 * max(2, nca["del_iters"]) if "del_iters" in nca else 2
+        initial_regularizer = config["ng_estimator_config"].get("initial_l2_regularizer", 1e-12)
+        initial_stepsize = config["component_stepsize_adapter_config"]["initial_stepsize"]
+        return GmmWrapper(model, initial_stepsize, initial_regularizer, max_reward_history_length)
+
+    def __init__(self, model: GMM, initial_stepsize: float, initial_regularizer: float,
+                 max_reward_history_length: int):
+        self.model = model
+        ctx = model.ctx
+        k = model.num_components
+        self.initial_regularizer = float(initial_regularizer)
+        self.initial_last_eta = -1
+        self.initial_stepsize = float(initial_stepsize)
+        self.max_reward_history_length = int(max_reward_history_length)
+        self.l2_regularizers = ctx.full((k,), self.initial_regularizer)          # :68
+        self.last_log_etas = ctx.full((k,), float(self.initial_last_eta))        # :69 (stores eta)
+        self.num_received_updates = ctx.zeros((k,))                              # :70
+        self.stepsizes = ctx.full((k,), self.initial_stepsize)                   # :71
+        h = self.max_reward_history_length
+        self._reward_ring = ctx.full((h, k), FLOAT32_MIN)                        # :72
+        self._weight_ring = ctx.full((h, k), FLOAT32_MIN)                        # :74
+        self._t_reward = 0          # number of store_rewards() calls
+        self._t_weight = 0          # number of replace_weights() calls
+        self.unique_component_ids = np.arange(k, dtype=np.int32)                 # :76
+        self.max_component_id = int(self.unique_component_ids.max()) if k else -1
+        self.adding_thresholds = -np.ones(k, np.float32)                         # :79
+        self.initial_entropies = model.component_entropies()                     # :80
+
+    def __getattr__(self, name):                                                 # :83-88
+        return getattr(self.__dict__["model"], name)
+
+    # ---- ring helpers -----------------------------------------------------------------------------------------
+    def _slot(self, t):
+        return t % self.max_reward_history_length
+
+    def reward_slot(self, back):
+        """Device view [K] of reward_history[:, -1-back] (back = 0: newest)."""
+        s = self._slot(self._t_reward - 1 - back)
+        return self._reward_ring.rows(s, s + 1).reshape(-1)
+
+    def next_reward_slot(self):
+        """Device view the next store_rewards() writes to; advance with commit_rewards()."""
+        s = self._slot(self._t_reward)
+        return self._reward_ring.rows(s, s + 1).reshape(-1)
+
+    def commit_rewards(self):
+        self._t_reward += 1
+
+    def _materialise(self, ring, t, last_n=None):
+        h = self.max_reward_history_length
+        n = h if last_n is None else min(int(last_n), h)
+        start = (t - n) % h                                  # oldest requested slot
+        if start + n <= h:
+            host = ring.rows(start, start + n).numpy()
+        else:                                                # wraps around the ring: two contiguous pieces
+            host = np.concatenate([ring.rows(start, h).numpy(), ring.rows(0, start + n - h).numpy()])
+        return np.ascontiguousarray(host.T)                  # [K, n], newest last
+
+    @property
+    def reward_history(self):
+        return self._materialise(self._reward_ring, self._t_reward)
+
+    @property
+    def weight_history(self):
+        return self._materialise(self._weight_ring, self._t_weight)
+
+    def reward_window(self, n):
+        return self._materialise(self._reward_ring, self._t_reward, n)
+
+    def weight_window(self, n):
+        return self._materialise(self._weight_ring, self._t_weight, n)
+
+    # ---- reference API ------------------------------------------------------------------------------------------
+    def store_rewards(self, rewards):
+        """:150-158."""
+        self.next_reward_slot().copy_from(self.model.ctx.asarray(rewards))
+        self.commit_rewards()
+
+    def update_stepsizes(self, new_stepsizes):
+        """:160-168."""
+        new = self.model.ctx.asarray(new_stepsizes)
+        if new is not self.stepsizes:
+            self.stepsizes = new
+
+    def record_weights(self):
+        """weight_history shift of :182 for weights already normalised on the device."""
+        s = self._slot(self._t_weight)
+        hip_ops.exp_into(self.model.ctx, self._weight_ring.rows(s, s + 1).reshape(-1), self.model.log_weights)
+        self._t_weight += 1
+
+    def replace_weights(self, new_log_weights):
+        """:170-182."""
+        self.model.replace_weights(new_log_weights)
+        self.record_weights()
+
+    def _rebuild_rings(self, rh, wh):
+        ctx = self.model.ctx
+        self._reward_ring = ctx.asarray(np.ascontiguousarray(rh.T))
+        self._weight_ring = ctx.asarray(np.ascontiguousarray(wh.T))
+        self._t_reward = self._t_weight = 0                  # slot 0 = oldest again
+
+    def add_component(self, initial_weight, initial_mean, initial_cov, adding_threshold, initial_entropy):
+        """:90-127."""
+        ctx = self.model.ctx
+        rh, wh = self.reward_history, self.weight_history
+        self.model.add_component(initial_weight, initial_mean, initial_cov)
+        self.max_component_id += 1
+        self.unique_component_ids = np.append(self.unique_component_ids, np.int32(self.max_component_id))
+        app = lambda dev, v: ctx.asarray(np.append(dev.numpy(), np.float32(v)))
+        self.l2_regularizers = app(self.l2_regularizers, self.initial_regularizer)
+        self.last_log_etas = app(self.last_log_etas, self.initial_last_eta)
+        self.num_received_updates = app(self.num_received_updates, 0.0)
+        self.stepsizes = app(self.stepsizes, self.initial_stepsize)
+        h = self.max_reward_history_length
+        rh = np.concatenate([rh, np.full((1, h), FLOAT32_MIN, np.float32)], axis=0)
+        wh = np.concatenate([wh, np.full((1, h), np.float32(initial_weight), np.float32)], axis=0)
+        self._rebuild_rings(rh, wh)
+        self.adding_thresholds = np.append(self.adding_thresholds,
+                                           np.asarray(adding_threshold, np.float32).reshape(-1))
+        self.initial_entropies = np.append(self.initial_entropies,
+                                           np.asarray(initial_entropy, np.float32).reshape(-1))
+
+    def remove_component(self, idx):
+        """:129-148."""
+        ctx = self.model.ctx
+        idx = int(idx)
+        rh, wh = self.reward_history, self.weight_history
+        self.model.remove_component(idx)
+        self.unique_component_ids = np.delete(self.unique_component_ids, idx)
+        rm = lambda dev: ctx.asarray(np.delete(dev.numpy(), idx))
+        self.l2_regularizers = rm(self.l2_regularizers)
+        self.last_log_etas = rm(self.last_log_etas)
+        self.num_received_updates = rm(self.num_received_updates)
+        self.stepsizes = rm(self.stepsizes)
+        self._rebuild_rings(np.delete(rh, idx, axis=0), np.delete(wh, idx, axis=0))
+        self.adding_thresholds = np.delete(self.adding_thresholds, idx)
+        self.initial_entropies = np.delete(self.initial_entropies, idx)

@@ -1,0 +1,97 @@
+"""GMMVI orchestrator (reference: src/gmmvi/optimization/gmmvi.py:16-174).
+
+Same constructor, ``build_from_config`` and ``train_iter`` as the reference; the module objects are the device-backed
+mirrors in ``gmmvi_modules``.  ``train_iter`` issues the whole iteration asynchronously on the context's HIP stream
+(no host synchronisation on the SAMTRON path with a zero reuse ratio); results become visible to the host through
+``.numpy()`` on any returned array.
+"""
+from ..models.gmm_wrapper import GmmWrapper
+from .gmmvi_modules.component_stepsize_adaptation import ComponentStepsizeAdaptation
+from .gmmvi_modules.component_adaptation import ComponentAdaptation
+from .gmmvi_modules.ng_based_component_updater import NgBasedComponentUpdater
+from .gmmvi_modules.ng_estimator import NgEstimator
+from .gmmvi_modules.sample_selector import SampleSelector
+from .gmmvi_modules.weight_stepsize_adaptation import WeightStepsizeAdaptation
+from .gmmvi_modules.weight_updater import WeightUpdater
+from .sample_db import SampleDB
+
+
+class _Counter:
+    """num_updates with the tf.Variable-like surface the reference callers touch (gmmvi.py:87, :174)."""
+    def __init__(self):
+        self.value = 0
+    def assign_add(self, n):
+        self.value += int(n)
+    def numpy(self):
+        return self.value
+    def __int__(self):
+        return self.value
+    def __index__(self):
+        return self.value
+    def __eq__(self, other):
+        return self.value == int(other)
+    def __gt__(self, other):
+        return self.value > int(other)
+    def __mod__(self, other):
+        return self.value % int(other)
+    def __repr__(self):
+        return str(self.value)
+
+
+class GMMVI:
+    def __init__(self, model: GmmWrapper, sample_db: SampleDB, temperature, sample_selector: SampleSelector,
+                 num_component_adapter: ComponentAdaptation, component_stepsize_adapter: ComponentStepsizeAdaptation,
+                 ng_estimator: NgEstimator, ng_based_updater: NgBasedComponentUpdater,
+                 weight_stepsize_adapter: WeightStepsizeAdaptation, weight_updater: WeightUpdater):
+        self.temperature = temperature
+        self.model = model
+        self.num_dimensions = self.model.num_dimensions
+        self.sample_db = sample_db
+        self.sample_selector = sample_selector
+        self.num_component_adapter = num_component_adapter
+        self.component_stepsize_adapter = component_stepsize_adapter
+        self.ng_estimator = ng_estimator
+        self.ng_based_updater = ng_based_updater
+        self.weight_stepsize_adapter = weight_stepsize_adapter
+        self.weight_updater = weight_updater
+        self.num_updates = _Counter()
+
+    @staticmethod
+    def build_from_config(config: dict, target_distribution, model: GmmWrapper):
+        """gmmvi.py:105-144."""
+        sample_db = SampleDB.build_from_config(config, model.num_dimensions)
+        ng_estimator = NgEstimator.build_from_config(config, config['temperature'], model)
+        ng_based_updater = NgBasedComponentUpdater.build_from_config(config, model)
+        num_component_adapter = ComponentAdaptation.build_from_config(
+            config, model, sample_db, target_distribution=target_distribution,
+            prior_mean=config["model_initialization"]["prior_mean"],
+            initial_cov=config["model_initialization"]["initial_cov"])
+        component_stepsize_adapter = ComponentStepsizeAdaptation.build_from_config(config, model)
+        sample_selector = SampleSelector.build_from_config(config, model, sample_db, target_distribution)
+        weight_updater = WeightUpdater.build_from_config(config, model)
+        weight_stepsize_adapter = WeightStepsizeAdaptation.build_from_config(config, model)
+        return GMMVI(model, sample_db, config['temperature'], sample_selector, num_component_adapter,
+                     component_stepsize_adapter, ng_estimator, ng_based_updater, weight_stepsize_adapter,
+                     weight_updater)
+
+    def train_iter(self):
+        """gmmvi.py:146-161."""
+        samples, mapping, sample_dist_densities, target_lnpdfs, target_lnpdf_grads = \
+            self.sample_selector.select_samples()
+        self._run_updates(samples, mapping, sample_dist_densities, target_lnpdfs, target_lnpdf_grads)
+        self.num_component_adapter.adapt_number_of_components(self.num_updates)
+
+    def _run_updates(self, samples, mapping, sample_dist_densities, target_lnpdfs, target_lnpdf_grads):
+        """gmmvi.py:163-174 -- the ordering contract of the hot path."""
+        # update components
+        new_component_stepsizes = self.component_stepsize_adapter.update_stepsize(self.model.stepsizes)
+        self.model.update_stepsizes(new_component_stepsizes)
+        # hint for only_use_own_samples: the newest sample was drawn by the newest DB component
+        self.model._mapping_max_hint = self.sample_db.means.shape[0] - 1
+        expected_hessian_neg, expected_grad_neg = self.ng_estimator.get_expected_hessian_and_grad(
+            samples, mapping, sample_dist_densities, target_lnpdfs, target_lnpdf_grads)
+        self.ng_based_updater.apply_NG_update(expected_hessian_neg, expected_grad_neg, self.model.stepsizes)
+        # update weights
+        weight_stepsize = self.weight_stepsize_adapter.update_stepsize()
+        self.weight_updater.update_weights(samples, sample_dist_densities, target_lnpdfs, weight_stepsize)
+        self.num_updates.assign_add(1)

@@ -1,0 +1,223 @@
+"""SampleDB on the MI355X (reference: src/gmmvi/optimization/sample_db.py:30-228).
+
+Samples, target log-densities/gradients and the (mean, chol) snapshot of every sampling component stay in HBM in
+capacity-doubling buffers (the reference re-concatenates every tensor on each add, sample_db.py:115-124).  The
+int32 ``mapping`` is mirrored on the host: it is produced deterministically from the per-component sample counts,
+so ``unique_with_counts`` (sample_db.py:221) costs no device round trip.  Background densities are evaluated by the
+same fused density kernel as the model (log-weights = log(count / N), sample_db.py:221-227).
+"""
+import numpy as np
+
+from .. import hip_ops
+from ..device import DeviceArray, get_context
+
+
+class _Growable:
+    """Device buffer with logical length ``n`` along axis 0 and amortised O(1) append."""
+
+    def __init__(self, ctx, inner, dtype=np.float32):
+        self.ctx, self.inner, self.dtype = ctx, tuple(inner), dtype
+        self.buf = ctx.empty((0,) + self.inner, dtype)
+        self.n = 0
+
+    def view(self, start=0, stop=None):
+        stop = self.n if stop is None else stop
+        return self.buf.rows(start, stop)
+
+    def append(self, arr):
+        m = arr.shape[0]
+        if self.n + m > self.buf.shape[0]:
+            cap = max(2 * self.buf.shape[0], self.n + m, 1024)
+            new = self.ctx.empty((cap,) + self.inner, self.dtype)
+            if self.n:
+                new.rows(0, self.n).copy_from(self.buf.rows(0, self.n))
+            self.buf = new
+        if m:
+            self.buf.rows(self.n, self.n + m).copy_from(arr)
+        self.n += m
+
+    def assign(self, arr):
+        self.buf = arr
+        self.n = arr.shape[0]
+
+
+class SampleDB:
+    def __init__(self, dim, diagonal_covariances, keep_samples, max_samples=None, ctx=None):
+        if diagonal_covariances:
+            raise NotImplementedError("diagonal GMMs are outside the hot-path scope (DESIGN.md, out of scope)")
+        self.ctx = ctx if ctx is not None else get_context()
+        self._dim = int(dim)
+        self.diagonal_covariances = False
+        self.keep_samples = keep_samples
+        self.max_samples = max_samples
+        d = self._dim
+        self._samples = _Growable(self.ctx, (d,))
+        self._target_lnpdfs = _Growable(self.ctx, ())
+        self._target_grads = _Growable(self.ctx, (d,))
+        self._mapping_dev = _Growable(self.ctx, (), np.int32)
+        self._means = _Growable(self.ctx, (d,))
+        self._chols = _Growable(self.ctx, (d, d))
+        self._packed = _Growable(self.ctx, (hip_ops.packed_stride(d),))
+        self._mapping_host = np.zeros(0, np.int32)
+        self._num_samples_written = 0
+        self._logw_cache = {}
+
+    @staticmethod
+    def build_from_config(config, num_dimensions):
+        """sample_db.py:48-61."""
+        return SampleDB(num_dimensions, config["model_initialization"]["use_diagonal_covs"],
+                        config["use_sample_database"], config["max_database_size"])
+
+    # ---- reference attributes (device views) ----------------------------------------------------------------
+    @property
+    def samples(self):
+        return self._samples.view()
+
+    @property
+    def means(self):
+        return self._means.view()
+
+    @property
+    def chols(self):
+        return self._chols.view()
+
+    @property
+    def inv_chols(self):
+        """sample_db.py:121: explicit inverses (API compatibility; the density kernels solve with L directly)."""
+        if self._means.n == 0:
+            return self.ctx.empty((0, self._dim, self._dim))
+        return hip_ops.pack_components(self.ctx, self.means, self.chols, want_inverse=True)[1]
+
+    @property
+    def target_lnpdfs(self):
+        return self._target_lnpdfs.view()
+
+    @property
+    def target_grads(self):
+        return self._target_grads.view()
+
+    @property
+    def mapping(self):
+        return self._mapping_dev.view()
+
+    class _Counter:
+        """num_samples_written with the ``.numpy()`` / ``assign_add`` the reference callers use."""
+        def __init__(self, db):
+            self._db = db
+        def numpy(self):
+            return self._db._num_samples_written
+        def assign_add(self, n):
+            self._db._num_samples_written += int(n)
+        def __int__(self):
+            return self._db._num_samples_written
+        def __index__(self):
+            return self._db._num_samples_written
+
+    @property
+    def num_samples_written(self):
+        return SampleDB._Counter(self)
+
+    # ---- mutation --------------------------------------------------------------------------------------------------
+    def remove_every_nth_sample(self, N):
+        """sample_db.py:63-79."""
+        n = self._samples.n
+        keep = np.arange(0, n, int(N), dtype=np.int32)
+        idx = self.ctx.asarray(keep, np.int32)
+        self._samples.assign(hip_ops.gather_rows(self.ctx, self.samples, idx))
+        self._target_lnpdfs.assign(hip_ops.gather_rows(self.ctx, self.target_lnpdfs, idx))
+        self._target_grads.assign(hip_ops.gather_rows(self.ctx, self.target_grads, idx))
+        mp = self._mapping_host[keep]
+        uniq, first = np.unique(mp, return_index=True)
+        used = uniq[np.argsort(first)].astype(np.int32)                       # tf.unique: first-occurrence order
+        remap = np.full(int(mp.max()) + 1 if mp.size else 0, -1, np.int64)
+        remap[used] = np.arange(len(used))
+        self._mapping_host = remap[mp].astype(np.int32)
+        self._mapping_dev.assign(self.ctx.asarray(self._mapping_host, np.int32))
+        uidx = self.ctx.asarray(used, np.int32)
+        self._means.assign(hip_ops.gather_rows(self.ctx, self.means, uidx))
+        self._chols.assign(hip_ops.gather_rows(self.ctx, self.chols, uidx))
+        self._packed.assign(hip_ops.gather_rows(self.ctx, self._packed.view(), uidx))
+
+    def add_samples(self, samples, means, chols, target_lnpdfs, target_grads, mapping, mapping_host=None,
+                    packed=None):
+        """sample_db.py:81-135.  ``mapping_host`` (NumPy int32) and ``packed`` (component blocks of ``means``/
+        ``chols``) are optional accelerators used by the built-in sample selectors."""
+        ctx = self.ctx
+        samples = ctx.asarray(samples)
+        n_new = samples.shape[0]
+        if self.max_samples is not None and n_new + self._samples.n > self.max_samples:
+            self.remove_every_nth_sample(2)                                                   # :111-112
+        self._num_samples_written += n_new                                                     # :113
+        means = ctx.asarray(means); chols = ctx.asarray(chols)
+        if mapping_host is None:
+            mapping_host = np.asarray(mapping.numpy() if isinstance(mapping, DeviceArray) else mapping, np.int32)
+        if packed is None:
+            packed, _ = hip_ops.pack_components(ctx, means, chols)
+        tl = ctx.asarray(target_lnpdfs); tg = ctx.asarray(target_grads)
+        if self.keep_samples:
+            offset = self._means.n                                                             # :115
+            self._mapping_host = np.concatenate([self._mapping_host, mapping_host + offset]).astype(np.int32)
+            self._mapping_dev.append(ctx.asarray(mapping_host + offset, np.int32))
+            self._means.append(means); self._chols.append(chols); self._packed.append(packed)
+            self._samples.append(samples); self._target_lnpdfs.append(tl); self._target_grads.append(tg)
+        else:                                                                                  # :125-135
+            self._mapping_host = mapping_host.copy()
+            self._mapping_dev.assign(ctx.asarray(mapping_host, np.int32))
+            self._means.assign(means.copy()); self._chols.assign(chols.copy()); self._packed.assign(packed)
+            self._samples.assign(samples); self._target_lnpdfs.assign(tl); self._target_grads.assign(tg)
+
+    def get_random_sample(self, N, rng=None):
+        """sample_db.py:137-152 (tf.random.shuffle -> NumPy Generator permutation)."""
+        rng = np.random.default_rng() if rng is None else rng
+        idx = rng.permutation(self._samples.n)[:int(N)].astype(np.int32)
+        didx = self.ctx.asarray(idx, np.int32)
+        return hip_ops.gather_rows(self.ctx, self.samples, didx), hip_ops.gather_rows(self.ctx, self.target_lnpdfs, didx)
+
+    # ---- background density ------------------------------------------------------------------------------------------
+    def evaluate_background(self, weights, means, chols, inv_chols, samples):
+        """sample_db.py:164-192: log sum_j w_j N(x; mu_j, Sigma_j).  ``inv_chols`` is accepted for signature
+        compatibility; the kernel solves with ``chols``."""
+        ctx = self.ctx
+        means = ctx.asarray(means); chols = ctx.asarray(chols)
+        packed, _ = hip_ops.pack_components(ctx, means, chols)
+        w = np.asarray(weights.numpy() if hasattr(weights, "numpy") else weights, np.float64)
+        _, lp, _ = hip_ops.mixture_eval(ctx, packed, ctx.asarray(np.log(w).astype(np.float32)), ctx.asarray(samples),
+                                        self._dim, want_lp=True)
+        return lp
+
+    def _active_components(self, start):
+        mp = self._mapping_host[start:]
+        uniq, first, counts = np.unique(mp, return_index=True, return_counts=True)
+        order = np.argsort(first)
+        return uniq[order], counts[order]
+
+    def get_newest_samples(self, N):
+        """sample_db.py:194-228 -> (log_pdfs, samples, mapping, target_lnpdfs, target_grads)."""
+        ctx, d = self.ctx, self._dim
+        N = int(N)
+        if self._samples.n == 0 or N == 0:                                                     # :213-214
+            return (ctx.empty((0,)), ctx.empty((0, d)), ctx.empty((0,), np.int32), ctx.empty((0,)),
+                    ctx.empty((0, d)))
+        start = max(0, self._samples.n - N)                                                    # :216
+        xs = self._samples.view(start)
+        active, counts = self._active_components(start)                                        # :221
+        lo, hi = int(active.min()), int(active.max()) + 1
+        if hi - lo == len(active) and np.all(np.diff(active) == 1):
+            packed = self._packed.view(lo, hi)                 # contiguous snapshot range: no gather
+        else:
+            packed = hip_ops.gather_rows(ctx, self._packed.view(), active.astype(np.int32))
+        key = counts.tobytes()
+        logw = self._logw_cache.get(key)
+        if logw is None:
+            w = counts.astype(np.float64) / counts.sum()                                       # :225-226
+            logw = ctx.asarray(np.log(w).astype(np.float32))
+            if len(self._logw_cache) > 64:
+                self._logw_cache.clear()
+            self._logw_cache[key] = logw
+        _, bg, _ = hip_ops.mixture_eval(ctx, packed, logw, xs, d, want_lp=True)                # :227
+        return (bg, xs, self._mapping_dev.view(start), self._target_lnpdfs.view(start),
+                self._target_grads.view(start))
+
+    def newest_mapping_host(self, N):
+        start = max(0, self._samples.n - int(N))
+        return self._mapping_host[start:]

@@ -64,6 +64,12 @@ int gmmvi_upload(gmmvi_ctx* ctx, void* dst_dev, const void* src_host, size_t nby
 int gmmvi_download(gmmvi_ctx* ctx, void* dst_host, const void* src_dev, size_t nbytes);   /* synchronises */
 int gmmvi_copy(gmmvi_ctx* ctx, void* dst_dev, const void* src_dev, size_t nbytes);
 int gmmvi_fill_f32(gmmvi_ctx* ctx, float* dst_dev, float value, size_t count);
+/* dst[i, :] = src[idx[i], :] for rows of row_words 4-byte words (fp32 or int32): SampleDB.remove_every_nth_sample /
+ * get_random_sample / background-component gather (optimization/sample_db.py:63-79,137-152,222-224 tf.gather). */
+int gmmvi_gather_rows(gmmvi_ctx* ctx, const void* src_dev, const int32_t* idx_dev, int n_rows, int row_words,
+                      void* dst_dev);
+/* dst[i] = exp(src[i])  (GMM.weights, models/gmm.py:171; weight history, models/gmm_wrapper.py:182). */
+int gmmvi_exp_f32(gmmvi_ctx* ctx, float* dst_dev, const float* src_dev, size_t count);
 /* timing helpers for bench.py: HIP events on the context's stream */
 int gmmvi_event_create(gmmvi_ctx* ctx, void** out_event);
 int gmmvi_event_destroy(gmmvi_ctx* ctx, void* event);

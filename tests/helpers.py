@@ -1,0 +1,109 @@
+"""Shared builders for the GPU-vs-oracle end-to-end tests and for generating tests/golden/*.npz."""
+import numpy as np
+
+from oracle import targets as otargets, train as otrain
+
+
+def samtron_config(desired_samples, reuse_ratio=0.0, initial_stepsize=0.1, adaptive=None, updater="trust-region",
+                   weight_updater="trust-region", snis=True, own=False, wstep=1.0):
+    """SAMTRON-style config dict with the keys of the reference's example_config.yml."""
+    cfg = {
+        "temperature": 1.0, "use_sample_database": True, "max_database_size": 10000000, "seed": 0,
+        "model_initialization": {"use_diagonal_covs": False, "prior_mean": 0., "initial_cov": 1.0},
+        "ng_estimator_type": "Stein",
+        "ng_estimator_config": {"only_use_own_samples": own, "use_self_normalized_importance_weights": snis},
+        "sample_selector_type": "component-based",
+        "sample_selector_config": {"desired_samples_per_component": desired_samples,
+                                   "ratio_reused_samples_to_desired": reuse_ratio},
+        "ng_based_updater_type": updater, "ng_based_updater_config": {},
+        "component_stepsize_adapter_type": "improvement-based",
+        "component_stepsize_adapter_config": {"initial_stepsize": initial_stepsize, "min_stepsize": 0.001,
+                                              "max_stepsize": 1.0, "stepsize_inc_factor": 1.15,
+                                              "stepsize_dec_factor": 0.85},
+        "weight_stepsize_adapter_type": "improvement_based",
+        "weight_stepsize_adapter_config": {"initial_stepsize": wstep, "min_stepsize": 0.0001, "max_stepsize": 1.0,
+                                           "stepsize_inc_factor": 1.15, "stepsize_dec_factor": 0.85},
+        "weight_updater_type": weight_updater,
+        "weight_updater_config": {"use_self_normalized_importance_weights": snis},
+    }
+    if adaptive:
+        cfg["num_component_adapter_type"] = "adaptive"
+        cfg["num_component_adapter_config"] = dict(adaptive)
+    else:
+        cfg["num_component_adapter_type"] = "fixed"
+        cfg["num_component_adapter_config"] = {}
+    return cfg
+
+
+def make_oracle_target(kind, d, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "stm":
+        return otargets.make_stm_target(d, rng)
+    if kind == "gmm":
+        return otargets.make_gmm_target(d, rng, num_components=4)
+    if kind == "gauss":
+        a = rng.normal(size=(d, d))
+        return otargets.GmmTarget([1.0], [rng.normal(size=d) * 3], [a @ a.T + np.eye(d)])
+    if kind == "planar":
+        return otargets.PlanarRobotTarget(d, 4)
+    raise ValueError(kind)
+
+
+def init_params(kind, d, k, seed):
+    """(prior_scale, initial_cov) following the reference's experiment configs, scaled for small tests."""
+    if kind == "planar":
+        return [1.0] + [0.2] * (d - 1), [0.0625] + [0.0025] * (d - 1)
+    if kind == "stm":
+        return 10.0, 30.0
+    if kind == "gmm":
+        return 30.0, 100.0
+    return 5.0, 10.0
+
+
+def make_oracle(kind, d, k, s, seed, cfg, dtype=np.float64):
+    tgt = make_oracle_target(kind, d, seed)
+    ps, ic = init_params(kind, d, k, seed)
+    model = otrain.construct_initial_mixture(d, k, 0.0, ps, ic, np.random.default_rng(seed + 1), dtype=dtype)
+    algo = otrain.OracleGMMVI(
+        tgt, model, temperature=cfg["temperature"], seed=seed,
+        desired_samples_per_component=cfg["sample_selector_config"]["desired_samples_per_component"],
+        ratio_reused_samples_to_desired=cfg["sample_selector_config"]["ratio_reused_samples_to_desired"],
+        only_use_own_samples=cfg["ng_estimator_config"]["only_use_own_samples"],
+        use_self_normalized_importance_weights=cfg["ng_estimator_config"]["use_self_normalized_importance_weights"],
+        updater=cfg["ng_based_updater_type"] if cfg["ng_based_updater_type"] != "iBLR" else "iblr",
+        component_stepsize_config=cfg["component_stepsize_adapter_config"],
+        weight_updater=cfg["weight_updater_type"],
+        weight_stepsize_config=cfg["weight_stepsize_adapter_config"],
+        adaptive=(dict(cfg["num_component_adapter_config"], prior_mean=0.0, initial_cov=ic)
+                  if cfg["num_component_adapter_type"] == "adaptive" else None),
+        max_reward_history_length=400,
+        host_rng=np.random.default_rng(seed))
+    return algo
+
+
+def make_device(kind, d, k, s, seed, cfg, oracle_algo):
+    """Device GMMVI initialised with exactly the oracle's target / initial mixture / seed."""
+    from gmmvi_amd.models.full_cov_gmm import FullCovGMM
+    from gmmvi_amd.models.gmm_wrapper import GmmWrapper
+    from gmmvi_amd.optimization.gmmvi import GMMVI
+    from gmmvi_amd.experiments.target_distributions.gmm import GMM_LNPDF
+    from gmmvi_amd.experiments.target_distributions.student_t_mixture import StudentTMixture_LNPDF
+    from gmmvi_amd.experiments.target_distributions.planar_robot import PlanarRobot
+    t = oracle_algo.target
+    if kind == "stm":
+        tgt = StudentTMixture_LNPDF(t.weights, t.means, t.covs, alpha=2)
+    elif kind in ("gmm", "gauss"):
+        tgt = GMM_LNPDF(t.weights, t.means, t.covs)
+    else:
+        tgt = PlanarRobot(d, 4)
+    om = oracle_algo.model.model
+    model = FullCovGMM(om.weights, om.means.astype(np.float32), om.covs.astype(np.float32))
+    model.seed = seed
+    wrapper = GmmWrapper(model, cfg["component_stepsize_adapter_config"]["initial_stepsize"], 1e-12, 400)
+    cfg = dict(cfg)
+    ps, ic = init_params(kind, d, k, seed)
+    cfg["model_initialization"] = dict(cfg["model_initialization"], prior_mean=0.0, initial_cov=ic)
+    g = GMMVI.build_from_config(cfg, tgt, wrapper)
+    if cfg["num_component_adapter_type"] == "adaptive":
+        g.num_component_adapter.rng = np.random.default_rng(seed)
+    return g
