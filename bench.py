@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- gmmvi hot path on MI355X: `python bench.py --gpus N --steps K --warmup W`.
+
+A "step" is one GMMVI.train_iter() (sample selection + target evaluation + background density -> model density and
+gradient -> Stein natural-gradient estimate -> KL-constrained component update -> weight update) on synthetic inputs.
+Metric (BASELINE.json): samples*components/sec (= N_samples * K_components / t_iter, whole job) with train_iter/sec
+beside it.  Workload at 1 GPU: the north-star shape, 20-D Student-t mixture target, K = 100 components, 100 samples per
+component (N = 10 000 samples/iter), SAMTRON design choices with a fixed number of components and reuse ratio 0.
+With --gpus N > 1 the components are sharded over the ranks (100 per GPU, weak scaling at a fixed ~10 000 samples per
+iteration: desired samples per component = ceil(100 / N)); one process per GPU, RCCL exchanges (gmmvi_amd/sharded.py).
+
+One JSON line on stdout (rank 0).  Extra objects: "roofline" (dominant kernel, algorithmic FLOPs / HIP-event time),
+"cpu_baseline" (the NumPy oracle = CPU port of the reference algorithm, timed on this host on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_FP32_TFLOPS = 157.3      # MI355X fp32 vector == f32-input MFMA rate (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # id: (target kind, D, K per GPU, samples per component at 1 GPU)
+    "ns": ("stm", 20, 100, 100),       # north star: K=100, D=20, N=10k
+    "c2": ("stm", 20, 50, 100),        # BASELINE configs[1]: K=50, N=5000
+    "c3": ("gmm", 50, 100, 100),       # BASELINE configs[2]: GMM target D=50, K=100, N=10k
+    "c4": ("planar", 10, 200, 100),    # BASELINE configs[3] on one GPU: planar-4, K=200, N=20k
+}
+
+
+def kernel_flops(name, n, k, d):
+    """Algorithmic FLOPs of one launch (DESIGN.md section 'kernels'): pairs P = n*k."""
+    p = float(n) * k
+    return {
+        "mixture_eval": p * (d * d + 4 * d),              # forward substitution + square-sum + LSE
+        "mixture_eval_grad": p * (2 * d * d + 8 * d),     # + backward substitution + responsibility-weighted gradient
+        "stein_partial": p * (4 * d * d + 6 * d),         # recompute y (2D^2) + rank-1 accumulate (2D^2)
+    }.get(name)
+
+
+def build(workload, n_gpus, rank, seed=0):
+    from helpers import samtron_config
+    import gmmvi_amd  # noqa: F401
+    from gmmvi_amd.models.full_cov_gmm import FullCovGMM
+    from gmmvi_amd.models.gmm_wrapper import GmmWrapper
+    from gmmvi_amd.optimization.gmmvi import GMMVI
+    from gmmvi_amd.experiments.target_distributions.gmm import GMM_LNPDF
+    from gmmvi_amd.experiments.target_distributions.student_t_mixture import StudentTMixture_LNPDF
+    from gmmvi_amd.experiments.target_distributions.planar_robot import PlanarRobot
+    kind, d, k_per_gpu, s1 = WORKLOADS[workload]
+    k_total = k_per_gpu * n_gpus
+    s = int(np.ceil(s1 / n_gpus))
+    rng = np.random.default_rng(seed)
+    from oracle import targets as otargets
+    if kind == "stm":
+        ot = otargets.make_stm_target(d, rng)
+        tgt = StudentTMixture_LNPDF(ot.weights, ot.means, ot.covs, alpha=2)
+        prior_scale, initial_cov = 100.0, 300.0                    # stm20.yml:9-14
+    elif kind == "gmm":
+        ot = otargets.make_gmm_target(d, rng)
+        tgt = GMM_LNPDF(ot.weights, ot.means, ot.covs)
+        prior_scale, initial_cov = 31.63, 1000.0                   # gmm20.yml:7-12
+    else:
+        ot = otargets.PlanarRobotTarget(d, 4)
+        tgt = PlanarRobot(d, 4)
+        prior_scale, initial_cov = [1.0] + [0.2] * (d - 1), [0.0625] + [0.0025] * (d - 1)   # planar_robot_4.yml
+    init_rng = np.random.default_rng(seed + 1)
+    means = (np.asarray(prior_scale) * init_rng.standard_normal((k_total, d))).astype(np.float32)
+    covs = np.broadcast_to((np.asarray(initial_cov) * np.eye(d)).astype(np.float32), (k_total, d, d))
+    cfg = samtron_config(s, initial_stepsize=0.1)
+    cfg["model_initialization"].update(prior_mean=0.0, initial_cov=initial_cov)
+    return dict(kind=kind, d=d, k_total=k_total, s=s, n_total=k_total * s, cfg=cfg, target=tgt, oracle_target=ot,
+                means=means, covs=np.ascontiguousarray(covs), seed=seed + 2, FullCovGMM=FullCovGMM,
+                GmmWrapper=GmmWrapper, GMMVI=GMMVI)
+
+
+def make_gmmvi(w, n_gpus, rank):
+    if n_gpus == 1:
+        model = w["FullCovGMM"](np.ones(w["k_total"]) / w["k_total"], w["means"], w["covs"])
+        model.seed = w["seed"]
+        wrapper = w["GmmWrapper"](model, 0.1, 1e-12, 10000)        # setup_experiment.py:40-41 history length
+        return w["GMMVI"].build_from_config(w["cfg"], w["target"], wrapper)
+    from gmmvi_amd.sharded import ShardedGMMVI
+    return ShardedGMMVI.build(w, n_gpus, rank)
+
+
+def make_oracle(w):
+    from oracle import train as otrain, gmm as ogmm
+    cfg = w["cfg"]
+    model = ogmm.FullCovGMM(np.ones(w["k_total"]) / w["k_total"], w["means"], w["covs"])
+    return otrain.OracleGMMVI(w["oracle_target"], model, seed=w["seed"],
+                              desired_samples_per_component=w["s"], ratio_reused_samples_to_desired=0.0,
+                              component_stepsize_config=cfg["component_stepsize_adapter_config"],
+                              weight_stepsize_config=cfg["weight_stepsize_adapter_config"])
+
+
+def parse_profile(ctx):
+    import ctypes
+    buf = ctypes.create_string_buffer(1 << 16)
+    ctx.check(ctx.lib.gmmvi_profile_report(ctx.handle, buf, len(buf)))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms = line.split()
+        out[name] = (int(cnt), float(ms))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    if world != n_gpus and not (world == 1 and n_gpus == 1):
+        if world == 1:
+            raise SystemExit(f"--gpus {n_gpus} needs {n_gpus} ranks: launch with python -m torch.distributed.run "
+                             f"--nproc-per-node {n_gpus} bench.py --gpus {n_gpus} ...")
+        n_gpus = world
+
+    from gmmvi_amd.device import get_context
+    ctx = get_context()
+    w = build(args.workload, n_gpus, rank)
+    algo = make_gmmvi(w, n_gpus, rank)
+    exchange = getattr(algo, "exchange", None)
+
+    def barrier():
+        ctx.sync()
+        if exchange is not None:
+            exchange.barrier()
+            ctx.sync()
+
+    for _ in range(args.warmup):
+        algo.train_iter()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        algo.train_iter()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if exchange is not None:
+        elapsed = exchange.max_scalar(elapsed)
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # ---- roofline leg: the same steps again with per-kernel HIP events on the compute stream ---------------------
+    ctx.check(ctx.lib.gmmvi_profile_enable(ctx.handle, 1))
+    prof_steps = min(args.steps, 50)
+    for _ in range(prof_steps):
+        algo.train_iter()
+    prof = parse_profile(ctx)
+    ctx.check(ctx.lib.gmmvi_profile_enable(ctx.handle, 0))
+    kernels = {name: {"launches_per_step": c / prof_steps, "avg_us": 1e3 * ms / c} for name, (c, ms) in prof.items()}
+    k_local = w["k_total"] // n_gpus
+    dominant = max(kernels, key=lambda nme: kernels[nme]["avg_us"] * kernels[nme]["launches_per_step"])
+    roof_name = max((nme for nme in kernels if kernel_flops(nme, 1, 1, 1) is not None),
+                    key=lambda nme: kernels[nme]["avg_us"] * kernels[nme]["launches_per_step"])
+    fl = kernel_flops(roof_name, w["n_total"], k_local, w["d"])
+    achieved = fl / (kernels[roof_name]["avg_us"] * 1e-6) / 1e12
+    d, n_tot, k_tot = w["d"], w["n_total"], w["k_total"]
+    f_alg_iter = float(n_tot) * k_tot * (8 * d * d + 12 * d)                   # SURVEY.md 8d (probes reported apart)
+    b_alg_iter = 4.0 * (3 * n_tot * d + 3 * n_tot + 2 * k_tot * (d * d + d + 1))
+
+    result = {
+        "metric": "samples_components_per_sec", "value": n_tot * k_tot / (elapsed / args.steps),
+        "unit": "samples*components/s", "train_iter_per_sec": args.steps / elapsed,
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {w['kind']} target D={d}, K={k_tot} components "
+                               f"({k_local}/GPU), {w['s']} samples/component, N={n_tot} samples/iter, SAMTRON "
+                               f"(Stein, fixed K, reuse ratio 0, KL trust regions, improvement-based stepsizes)",
+                   "K": k_tot, "D": d, "N": n_tot, "parallelism": f"component-shard x{n_gpus}"},
+        "roofline": {"kernel": roof_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                     "avg_us": kernels[roof_name]["avg_us"], "flops_per_launch": fl,
+                     "note": "fp32 FMA path (vector substitution + f32 MFMA contraction); peak = fp32 vector == f32 "
+                             "MFMA rate. Algorithmic HBM bytes per iteration are tiny (see iter_roofline): the "
+                             "north star's >=50% HBM roofline is unreachable on algorithmic bytes (SURVEY.md 8d)."},
+        "iter_roofline": {"flops_alg": f_alg_iter, "bytes_alg": b_alg_iter,
+                          "frac_fp32_peak": f_alg_iter / (elapsed / args.steps) / (PEAK_FP32_TFLOPS * 1e12 * n_gpus),
+                          "frac_hbm_peak": b_alg_iter / (elapsed / args.steps) / (PEAK_HBM_GBS * 1e9 * n_gpus)},
+        "kernels": kernels, "dominant_kernel": dominant,
+    }
+
+    # ---- CPU baseline + matched-ELBO check (rank 0, 1 GPU only) -------------------------------------------------
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        except Exception:
+            threads = os.cpu_count()
+        o = make_oracle(w)
+        t_start = time.perf_counter()
+        o.train_iter()
+        first = time.perf_counter() - t_start
+        n_more = int(max(1, min(8, (args.cpu_seconds - first) // max(first, 1e-3))))
+        ts = [first]
+        for _ in range(n_more):
+            t1 = time.perf_counter(); o.train_iter(); ts.append(time.perf_counter() - t1)
+        cpu_iters = len(ts)
+        t_cpu = float(np.median(ts))
+        # matched ELBO: a fresh device run of the same number of iterations from the same seed, both models scored
+        # by the oracle on the same 20 000 Philox draws
+        g = make_gmmvi(build(args.workload, 1, 0), 1, 0)
+        for _ in range(cpu_iters):
+            g.train_iter()
+        elbo_cpu = o.elbo(20000, seed=12345)[0]
+        om = o.model.model
+        om.means = g.model.means.numpy().astype(np.float64)
+        om.chol_cov = g.model.chol_cov.numpy().astype(np.float64)
+        om.log_weights = g.model.log_weights.numpy().astype(np.float64)
+        elbo_gpu = o.elbo(20000, seed=12345)[0]
+        result["cpu_baseline"] = {"value": n_tot * k_tot / t_cpu, "unit": "samples*components/s",
+                                  "train_iter_per_sec": 1.0 / t_cpu, "cores": int(threads), "kind": "port",
+                                  "sample": f"{cpu_iters} train_iter() of the same workload (fp64 NumPy/SciPy oracle "
+                                            f"restating the reference's algorithm), median iteration time"}
+        result["matched_elbo"] = {"iters": cpu_iters, "gpu_fp32": elbo_gpu, "cpu_fp64": elbo_cpu,
+                                  "abs_diff": abs(elbo_gpu - elbo_cpu)}
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,8 @@ _PROTOS = {
     "gmmvi_event_destroy": (_i, [_p, _p]),
     "gmmvi_event_record": (_i, [_p, _p]),
     "gmmvi_event_elapsed_ms": (_i, [_p, _p, _p, C.POINTER(_f)]),
+    "gmmvi_profile_enable": (_i, [_p, _i]),
+    "gmmvi_profile_report": (_i, [_p, C.c_char_p, _sz]),
     "gmmvi_packed_stride": (_sz, [_i]),
     "gmmvi_pack_components": (_i, [_p, _i, _f, _i, _i, _p, _p, _p, _p]),
     "gmmvi_cholesky": (_i, [_p, _i, _i, _p, _p, _p]),

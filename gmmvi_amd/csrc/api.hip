@@ -185,6 +185,37 @@ int gmmvi_event_elapsed_ms(gmmvi_ctx* ctx, void* start, void* stop, float* out_m
     return GMMVI_OK;
 }
 
+int gmmvi_profile_enable(gmmvi_ctx* ctx, int on) {
+    ctx->prof = on != 0;
+    return GMMVI_OK;
+}
+
+int gmmvi_profile_report(gmmvi_ctx* ctx, char* buf, size_t buf_size) {
+    GMMVI_ARG_CHECK(ctx, buf && buf_size > 0);
+    GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<std::string> names;
+    std::vector<double> total;
+    std::vector<long> count;
+    for (auto& r : ctx->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) ms = 0.f;
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+        size_t i = 0;
+        for (; i < names.size(); ++i) if (names[i] == r.name) break;
+        if (i == names.size()) { names.push_back(r.name); total.push_back(0.0); count.push_back(0); }
+        total[i] += ms;
+        count[i] += 1;
+    }
+    ctx->prof_recs.clear();
+    std::string out;
+    for (size_t i = 0; i < names.size(); ++i)
+        out += names[i] + " " + std::to_string(count[i]) + " " + std::to_string(total[i]) + "\n";
+    if (out.size() + 1 > buf_size) return gmmvi_fail(ctx, GMMVI_ERR_ARG, "gmmvi_profile_report: buffer too small");
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return GMMVI_OK;
+}
+
 size_t gmmvi_packed_stride(int D) {
     int dp = gmmvi_padded_dim(D);
     return dp < 0 ? 0 : gmmvi_packed_stride_dp(dp);

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <cstdint>
 #include <string>
+#include <vector>
 #include "../../include/gmmvi_hip.h"
 
 struct gmmvi_ctx {
@@ -17,7 +18,24 @@ struct gmmvi_ctx {
     void* comm = nullptr;        // ncclComm_t
     int n_ranks = 1, rank = 0;
     int num_cus = 256;
+    // optional per-kernel HIP-event timing (bench.py roofline leg): events are recorded on ctx->stream
+    bool prof = false;
+    struct ProfRec { const char* name; hipEvent_t start, stop; };
+    std::vector<ProfRec> prof_recs;
 };
+
+struct GmmviProfScope {
+    gmmvi_ctx* ctx; hipEvent_t stop = nullptr;
+    GmmviProfScope(gmmvi_ctx* c, const char* name) : ctx(c) {
+        if (!c->prof) return;
+        hipEvent_t start;
+        if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) { stop = nullptr; return; }
+        (void)hipEventRecord(start, c->stream);
+        c->prof_recs.push_back({name, start, stop});
+    }
+    ~GmmviProfScope() { if (stop) (void)hipEventRecord(stop, ctx->stream); }
+};
+#define GMMVI_PROF(ctx, name) GmmviProfScope prof_scope__(ctx, name)
 
 extern std::string g_gmmvi_global_err;
 

@@ -222,6 +222,7 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     while (nw > 4 && (long)tiles * nw > 8L * 4 * ctx->num_cus) nw >>= 1;
     size_t shmem = (size_t)nw * per_wave_floats * 4;
     dim3 grid(tiles), block(nw * 64);
+    GMMVI_PROF(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval");
 #define GMMVI_LAUNCH_ME(FAM, G)                                                                              \
     hipLaunchKernelGGL((mixture_eval_kernel<DP, FAM, G>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
                        logw, X, N, ld, lp, grad)
@@ -244,6 +245,7 @@ int gmmvi_pack_components(gmmvi_ctx* ctx, int family, float nu, int K, int D, co
     if (K == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && packed_dev);
     int dp = gmmvi_padded_dim(D);
+    GMMVI_PROF(ctx, "pack_components");
     GMMVI_DISPATCH_DP(dp, hipLaunchKernelGGL((pack_kernel<DP>), dim3(K), dim3(64), 0, ctx->stream, family, nu, K, D,
                                              means_dev, chols_dev, packed_dev, inv_chols_dev));
     GMMVI_LAUNCH_CHECK(ctx);

@@ -70,6 +70,7 @@ int gmmvi_sample_components(gmmvi_ctx* ctx, int K, int D, const float* means_dev
     GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM && N >= 0);
     if (N == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && offsets_dev && X_out_dev);
+    GMMVI_PROF(ctx, "sample_components");
     hipLaunchKernelGGL(sample_components_kernel, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, K, D, means_dev,
                        chols_dev, offsets_dev, N, seed, first_index, (uint32_t)stream_id, eps_dev, X_out_dev,
                        mapping_out_dev);

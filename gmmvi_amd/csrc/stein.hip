@@ -220,9 +220,13 @@ static int launch_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         attr_set = true;
     }
+    {
+    GMMVI_PROF(ctx, "stein_partial");
     hipLaunchKernelGGL((stein_partial_kernel<DP, NB>), dim3(R, K), dim3(256), shmem, ctx->stream, K, D, packed, X, N,
                        range_size, ld, qgrad, bg, tgrad, mapping, map_offset, flags, part, part_m);
+    }
     GMMVI_LAUNCH_CHECK(ctx);
+    GMMVI_PROF(ctx, "stein_finalize");
     hipLaunchKernelGGL(stein_finalize_kernel, dim3(K), dim3(256), (size_t)D1 * D1 * sizeof(float), ctx->stream, D, R,
                        N, flags, part, part_m, H_neg, g_neg);
     GMMVI_LAUNCH_CHECK(ctx);

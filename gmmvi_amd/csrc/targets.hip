@@ -48,6 +48,7 @@ extern "C" int gmmvi_target_planar(gmmvi_ctx* ctx, int D, const float* prior_std
     GMMVI_ARG_CHECK(ctx, D >= 1 && D <= GMMVI_MAX_DIM && G >= 1 && N >= 0 && likelihood_std > 0.f);
     if (N == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, prior_std_dev && goals_dev && X_dev);
+    GMMVI_PROF(ctx, "target_planar");
     hipLaunchKernelGGL(planar_kernel, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, D, prior_std_dev, G, goals_dev,
                        likelihood_std, X_dev, N, lp_out_dev, grad_out_dev);
     GMMVI_LAUNCH_CHECK(ctx);

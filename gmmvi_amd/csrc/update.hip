@@ -355,6 +355,7 @@ int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* means_dev, f
     if (shmem > 64 * 1024)
         GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)update_kl_kernel,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    GMMVI_PROF(ctx, "update_kl");
     hipLaunchKernelGGL(update_kl_kernel, dim3(K), dim3(64), shmem, ctx->stream, D, means_dev, chols_dev, H_neg_dev,
                        g_neg_dev, stepsizes_dev, temperature, l2_init, last_eta_dev, l2_dev, num_received_updates_dev,
                        success_out_dev, kl_out_dev, n_probes_out_dev);
@@ -372,6 +373,7 @@ static int launch_plain(gmmvi_ctx* ctx, int mode, int K, int D, float* means_dev
     if (shmem > 64 * 1024)
         GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)update_plain_kernel,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    GMMVI_PROF(ctx, "update_plain");
     hipLaunchKernelGGL(update_plain_kernel, dim3(K), dim3(64), shmem, ctx->stream, mode, D, means_dev, chols_dev,
                        H_neg_dev, g_neg_dev, stepsizes_dev, l2_init, l2_dev, num_received_updates_dev, success_out_dev);
     GMMVI_LAUNCH_CHECK(ctx);

@@ -187,6 +187,7 @@ int gmmvi_expected_log_ratios(gmmvi_ctx* ctx, int K, int N, const float* ld_dev,
                               int self_normalized, float* E_out_dev, float* reward_out_dev, float* ess_out_dev) {
     GMMVI_ARG_CHECK(ctx, K >= 1 && N >= 1);
     GMMVI_ARG_CHECK(ctx, ld_dev && bg_dev && tlp_dev && logq_dev && logw_dev);
+    GMMVI_PROF(ctx, "expected_log_ratios");
     hipLaunchKernelGGL(elr_kernel, dim3(K), dim3(256), 0, ctx->stream, N, ld_dev, bg_dev, tlp_dev, logq_dev, beta,
                        logw_dev, self_normalized, E_out_dev, reward_out_dev, ess_out_dev);
     GMMVI_LAUNCH_CHECK(ctx);
@@ -197,6 +198,7 @@ static int launch_update_weights(gmmvi_ctx* ctx, int mode, int K, float* logw_de
                                  const float* stepsize_dev, float beta, float* kl_eta_out_dev) {
     GMMVI_ARG_CHECK(ctx, K >= 1 && K <= 4096);
     GMMVI_ARG_CHECK(ctx, logw_dev && E_dev && stepsize_dev);
+    GMMVI_PROF(ctx, "update_weights");
     hipLaunchKernelGGL(update_weights_kernel, dim3(1), dim3(64), (size_t)3 * K * sizeof(float), ctx->stream, mode, K,
                        logw_dev, E_dev, stepsize_dev, beta, kl_eta_out_dev);
     GMMVI_LAUNCH_CHECK(ctx);
@@ -217,6 +219,7 @@ int gmmvi_component_stepsize_improvement(gmmvi_ctx* ctx, int K, float* stepsizes
                                          const float* rewards_last_dev, float min_stepsize, float max_stepsize,
                                          float inc_factor, float dec_factor) {
     GMMVI_ARG_CHECK(ctx, K >= 1 && stepsizes_dev && rewards_prev_dev && rewards_last_dev);
+    GMMVI_PROF(ctx, "component_stepsize");
     hipLaunchKernelGGL(component_stepsize_kernel, dim3((K + 127) / 128), dim3(128), 0, ctx->stream, K, stepsizes_dev,
                        rewards_prev_dev, rewards_last_dev, min_stepsize, max_stepsize, inc_factor, dec_factor);
     GMMVI_LAUNCH_CHECK(ctx);
@@ -227,6 +230,7 @@ int gmmvi_weight_stepsize_improvement(gmmvi_ctx* ctx, int K, const float* logw_d
                                       float* state_dev, float min_stepsize, float max_stepsize, float inc_factor,
                                       float dec_factor) {
     GMMVI_ARG_CHECK(ctx, K >= 1 && logw_dev && rewards_last_dev && state_dev);
+    GMMVI_PROF(ctx, "weight_stepsize");
     hipLaunchKernelGGL(weight_stepsize_kernel, dim3(1), dim3(64), 0, ctx->stream, K, logw_dev, rewards_last_dev,
                        state_dev, min_stepsize, max_stepsize, inc_factor, dec_factor);
     GMMVI_LAUNCH_CHECK(ctx);

@@ -199,6 +199,10 @@ class DeviceArray:
 
     def reshape(self, *shape):
         shape = shape[0] if len(shape) == 1 and not np.isscalar(shape[0]) else shape
+        shape = tuple(int(s) for s in shape)
+        if shape.count(-1) == 1:
+            known = int(np.prod([s for s in shape if s != -1], dtype=np.int64))
+            shape = tuple(self.size // max(known, 1) if s == -1 else s for s in shape)
         if int(np.prod(shape, dtype=np.int64)) != self.size:
             raise ValueError("reshape: size mismatch")
         return DeviceArray._view(self, self.ptr, shape)

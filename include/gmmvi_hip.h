@@ -76,6 +76,12 @@ int gmmvi_event_destroy(gmmvi_ctx* ctx, void* event);
 int gmmvi_event_record(gmmvi_ctx* ctx, void* event);
 int gmmvi_event_elapsed_ms(gmmvi_ctx* ctx, void* start, void* stop, float* out_ms);       /* synchronises on stop */
 
+/* Per-kernel timing for bench.py's roofline leg: while enabled, every kernel-launching entry point brackets its
+ * launches with HIP events on the context's stream.  gmmvi_profile_report synchronises, writes one line per kernel
+ * name ("name count total_ms\n") into buf and clears the records. */
+int gmmvi_profile_enable(gmmvi_ctx* ctx, int on);
+int gmmvi_profile_report(gmmvi_ctx* ctx, char* buf, size_t buf_size);
+
 /* ---- component parameter blocks ---------------------------------------------------------------------- */
 /* Number of floats of one packed component block for dimension D (padded dimension, reciprocal diagonal,
  * row- and column-packed strict lower triangle of L, log-normaliser). */
