@@ -144,6 +144,22 @@ int gmmvi_gather_rows(gmmvi_ctx* ctx, const void* src_dev, const int32_t* idx_de
     return GMMVI_OK;
 }
 
+__global__ void add_scalar_i32_kernel(int32_t* dst, const int32_t* src, int32_t v, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[i] + v;
+}
+
+int gmmvi_add_scalar_i32(gmmvi_ctx* ctx, int32_t* dst_dev, const int32_t* src_dev, int32_t value, size_t count) {
+    if (count == 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, dst_dev && src_dev);
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(add_scalar_i32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dst_dev, src_dev, value, count);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
 __global__ void exp_f32_kernel(float* dst, const float* src, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;

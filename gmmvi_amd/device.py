@@ -34,6 +34,38 @@ class Context:
         self.device = device
         self.n_ranks = 1
         self.rank = 0
+        # Stream-ordered caching allocator: every kernel of this context runs on ONE stream, so a block released
+        # by the host can be handed to a later launch without synchronising (hipMalloc / hipFree would stall the
+        # stream every iteration).  Blocks are bucketed by size rounded up to 512 B.
+        self._pool = {}
+        self._pool_bytes = 0
+        self._small_cache = {}
+
+    def _alloc_bytes(self, nbytes):
+        size = max(512, (int(nbytes) + 511) // 512 * 512)
+        free = self._pool.get(size)
+        if free:
+            self._pool_bytes -= size
+            return free.pop(), size
+        p = C.c_void_p()
+        self.check(self.lib.gmmvi_malloc(self.handle, size, C.byref(p)))
+        return p.value, size
+
+    def _release_bytes(self, ptr, size):
+        if self._pool_bytes + size > (8 << 30):           # keep at most 8 GiB parked
+            self.lib.gmmvi_free(self.handle, ptr)
+            return
+        self._pool.setdefault(size, []).append(ptr)
+        self._pool_bytes += size
+
+    def cached_const(self, key, builder):
+        """Small read-only device arrays (offset tables, log-count weights) uploaded once and reused."""
+        a = self._small_cache.get(key)
+        if a is None:
+            if len(self._small_cache) > 256:
+                self._small_cache.clear()
+            a = self._small_cache[key] = builder()
+        return a
 
     def check(self, rc):
         if rc != 0:
@@ -102,7 +134,7 @@ def get_context():
 
 class DeviceArray:
     """Dense row-major fp32 / int32 array in HBM."""
-    __slots__ = ("ctx", "ptr", "shape", "dtype", "_owner", "_base", "__weakref__")
+    __slots__ = ("ctx", "ptr", "shape", "dtype", "_owner", "_base", "_cap", "__weakref__")
     __array_priority__ = 100
 
     def __init__(self):
@@ -116,22 +148,22 @@ class DeviceArray:
         if dtype not in (np.dtype(np.float32), np.dtype(np.int32)):
             raise TypeError(f"DeviceArray supports float32 and int32, not {dtype}")
         nbytes = int(np.prod(shape, dtype=np.int64)) * 4
-        p = C.c_void_p()
-        ctx.check(ctx.lib.gmmvi_malloc(ctx.handle, max(nbytes, 4), C.byref(p)))
-        self.ctx, self.ptr, self.shape, self.dtype, self._owner, self._base = ctx, p.value, shape, dtype, True, None
+        ptr, cap = ctx._alloc_bytes(nbytes)
+        self.ctx, self.ptr, self.shape, self.dtype, self._owner, self._base = ctx, ptr, shape, dtype, True, None
+        self._cap = cap
         return self
 
     @classmethod
     def _view(cls, base, ptr, shape):
         self = object.__new__(cls)
         self.ctx, self.ptr, self.shape, self.dtype = base.ctx, ptr, tuple(int(s) for s in shape), base.dtype
-        self._owner, self._base = False, base
+        self._owner, self._base, self._cap = False, base, 0
         return self
 
     def __del__(self):
         try:
             if getattr(self, "_owner", False) and self.ptr:
-                self.ctx.lib.gmmvi_free(self.ctx.handle, self.ptr)
+                self.ctx._release_bytes(self.ptr, self._cap)
                 self.ptr = None
         except Exception:
             pass

@@ -105,7 +105,9 @@ class GMM:
             raise ValueError("samples_per_component must have one entry per component")
         offsets = np.concatenate([[0], np.cumsum(n_k)]).astype(np.int32)
         n = int(offsets[-1])
-        return hip_ops.sample_components(self.ctx, self.means, self.chol_cov, self.ctx.asarray(offsets, np.int32), n,
+        offsets_dev = self.ctx.cached_const(("offsets", offsets.tobytes()),
+                                            lambda: self.ctx.asarray(offsets, np.int32))
+        return hip_ops.sample_components(self.ctx, self.means, self.chol_cov, offsets_dev, n,
                                          seed=self.seed if seed is None else seed, first_index=first_index,
                                          stream_id=stream_id,
                                          eps=None if eps is None else self.ctx.asarray(eps))

@@ -74,7 +74,11 @@ class VipsSampleSelector(SampleSelector):
         new_samples, mapping = self.model.sample_from_components_no_shuffle(
             n_add, first_index=first, eps=eps, stream_id=STREAM_COMPONENT_NORMALS)
         new_target_grads, new_target_lnpdfs = self.get_target_grads(new_samples)
-        self._last_mapping_host = np.repeat(np.arange(k, dtype=np.int32), n_add)
+        key = n_add.tobytes()
+        if getattr(self, "_mapping_key", None) != key:
+            self._mapping_key = key
+            self._last_mapping_host = np.repeat(np.arange(k, dtype=np.int32), n_add)
+        self._last_counts = n_add
         return new_samples, new_target_lnpdfs, new_target_grads, mapping
 
     def select_samples(self):
@@ -84,7 +88,8 @@ class VipsSampleSelector(SampleSelector):
         num_reused = samples.shape[0]
         new_samples, new_lp, new_grads, mapping = self.sample_where_needed(samples, oldsamples_pdf)
         self.sample_db.add_samples(new_samples, self.model.means, self.model.chol_cov, new_lp, new_grads, mapping,
-                                   mapping_host=self._last_mapping_host, packed=self.model.packed)
+                                   mapping_host=self._last_mapping_host, packed=self.model.packed,
+                                   counts=self._last_counts)
         num_new = new_samples.shape[0]
         oldsamples_pdf, samples, mapping, target_lnpdfs, target_grads = \
             self.sample_db.get_newest_samples(num_reused + num_new)

@@ -3,8 +3,10 @@
 Samples, target log-densities/gradients and the (mean, chol) snapshot of every sampling component stay in HBM in
 capacity-doubling buffers (the reference re-concatenates every tensor on each add, sample_db.py:115-124).  The
 int32 ``mapping`` is mirrored on the host: it is produced deterministically from the per-component sample counts,
-so ``unique_with_counts`` (sample_db.py:221) costs no device round trip.  Background densities are evaluated by the
-same fused density kernel as the model (log-weights = log(count / N), sample_db.py:221-227).
+so ``unique_with_counts`` (sample_db.py:221) costs no device round trip; for the common case that the requested
+window ends on an append boundary the answer is read off the append log without touching the mapping at all.
+Background densities are evaluated by the same fused density kernel as the model (log-weights = log(count / N),
+sample_db.py:221-227).  Steady-state iterations issue no host<->device synchronisation.
 """
 import numpy as np
 
@@ -24,14 +26,17 @@ class _Growable:
         stop = self.n if stop is None else stop
         return self.buf.rows(start, stop)
 
-    def append(self, arr):
-        m = arr.shape[0]
+    def reserve(self, m):
         if self.n + m > self.buf.shape[0]:
             cap = max(2 * self.buf.shape[0], self.n + m, 1024)
             new = self.ctx.empty((cap,) + self.inner, self.dtype)
             if self.n:
                 new.rows(0, self.n).copy_from(self.buf.rows(0, self.n))
             self.buf = new
+
+    def append(self, arr):
+        m = arr.shape[0]
+        self.reserve(m)
         if m:
             self.buf.rows(self.n, self.n + m).copy_from(arr)
         self.n += m
@@ -39,6 +44,28 @@ class _Growable:
     def assign(self, arr):
         self.buf = arr
         self.n = arr.shape[0]
+
+
+class _HostGrowable:
+    def __init__(self, dtype):
+        self.buf = np.zeros(1024, dtype)
+        self.n = 0
+
+    def view(self, start=0):
+        return self.buf[start:self.n]
+
+    def append(self, arr):
+        m = arr.shape[0]
+        if self.n + m > self.buf.shape[0]:
+            new = np.zeros(max(2 * self.buf.shape[0], self.n + m), self.buf.dtype)
+            new[:self.n] = self.buf[:self.n]
+            self.buf = new
+        self.buf[self.n:self.n + m] = arr
+        self.n += m
+
+    def assign(self, arr):
+        self.buf = np.array(arr, self.buf.dtype)
+        self.n = self.buf.shape[0]
 
 
 class SampleDB:
@@ -58,9 +85,10 @@ class SampleDB:
         self._means = _Growable(self.ctx, (d,))
         self._chols = _Growable(self.ctx, (d, d))
         self._packed = _Growable(self.ctx, (hip_ops.packed_stride(d),))
-        self._mapping_host = np.zeros(0, np.int32)
+        self._mapping_host = _HostGrowable(np.int32)
         self._num_samples_written = 0
-        self._logw_cache = {}
+        # append log: (first sample, first component, per-component counts); cleared when the DB is thinned out
+        self._segments = []
 
     @staticmethod
     def build_from_config(config, num_dimensions):
@@ -126,22 +154,25 @@ class SampleDB:
         self._samples.assign(hip_ops.gather_rows(self.ctx, self.samples, idx))
         self._target_lnpdfs.assign(hip_ops.gather_rows(self.ctx, self.target_lnpdfs, idx))
         self._target_grads.assign(hip_ops.gather_rows(self.ctx, self.target_grads, idx))
-        mp = self._mapping_host[keep]
+        mp = self._mapping_host.view()[keep]
         uniq, first = np.unique(mp, return_index=True)
         used = uniq[np.argsort(first)].astype(np.int32)                       # tf.unique: first-occurrence order
         remap = np.full(int(mp.max()) + 1 if mp.size else 0, -1, np.int64)
         remap[used] = np.arange(len(used))
-        self._mapping_host = remap[mp].astype(np.int32)
-        self._mapping_dev.assign(self.ctx.asarray(self._mapping_host, np.int32))
+        new_mp = remap[mp].astype(np.int32)
+        self._mapping_host.assign(new_mp)
+        self._mapping_dev.assign(self.ctx.asarray(new_mp, np.int32))
         uidx = self.ctx.asarray(used, np.int32)
         self._means.assign(hip_ops.gather_rows(self.ctx, self.means, uidx))
         self._chols.assign(hip_ops.gather_rows(self.ctx, self.chols, uidx))
         self._packed.assign(hip_ops.gather_rows(self.ctx, self._packed.view(), uidx))
+        self._segments = []
 
     def add_samples(self, samples, means, chols, target_lnpdfs, target_grads, mapping, mapping_host=None,
-                    packed=None):
-        """sample_db.py:81-135.  ``mapping_host`` (NumPy int32) and ``packed`` (component blocks of ``means``/
-        ``chols``) are optional accelerators used by the built-in sample selectors."""
+                    packed=None, counts=None):
+        """sample_db.py:81-135.  ``mapping_host`` (NumPy int32), ``packed`` (component blocks of ``means``/``chols``)
+        and ``counts`` (samples per component, component order) are optional accelerators used by the built-in
+        sample selectors."""
         ctx = self.ctx
         samples = ctx.asarray(samples)
         n_new = samples.shape[0]
@@ -154,15 +185,25 @@ class SampleDB:
         if packed is None:
             packed, _ = hip_ops.pack_components(ctx, means, chols)
         tl = ctx.asarray(target_lnpdfs); tg = ctx.asarray(target_grads)
+        mapping = ctx.asarray(mapping, np.int32)
         if self.keep_samples:
             offset = self._means.n                                                             # :115
-            self._mapping_host = np.concatenate([self._mapping_host, mapping_host + offset]).astype(np.int32)
-            self._mapping_dev.append(ctx.asarray(mapping_host + offset, np.int32))
+            if counts is not None:
+                self._segments.append((self._samples.n, offset, np.asarray(counts, np.int64)))
+            else:
+                self._segments = []
+            self._mapping_host.append(mapping_host + offset)
+            self._mapping_dev.reserve(n_new)
+            if n_new:
+                dst = self._mapping_dev.buf.rows(self._mapping_dev.n, self._mapping_dev.n + n_new)
+                ctx.check(ctx.lib.gmmvi_add_scalar_i32(ctx.handle, dst.ptr, mapping.ptr, int(offset), n_new))
+            self._mapping_dev.n += n_new
             self._means.append(means); self._chols.append(chols); self._packed.append(packed)
             self._samples.append(samples); self._target_lnpdfs.append(tl); self._target_grads.append(tg)
         else:                                                                                  # :125-135
-            self._mapping_host = mapping_host.copy()
-            self._mapping_dev.assign(ctx.asarray(mapping_host, np.int32))
+            self._segments = [(0, 0, np.asarray(counts, np.int64))] if counts is not None else []
+            self._mapping_host.assign(mapping_host)
+            self._mapping_dev.assign(mapping.copy())
             self._means.assign(means.copy()); self._chols.assign(chols.copy()); self._packed.assign(packed)
             self._samples.assign(samples); self._target_lnpdfs.assign(tl); self._target_grads.assign(tg)
 
@@ -186,7 +227,18 @@ class SampleDB:
         return lp
 
     def _active_components(self, start):
-        mp = self._mapping_host[start:]
+        """unique_with_counts of mapping[start:] in first-occurrence order (sample_db.py:221)."""
+        # fast path: the window is a whole number of recorded appends
+        acc_active, acc_counts = [], []
+        for s0, c0, counts in reversed(self._segments):
+            if s0 < start:
+                break
+            nz = counts > 0
+            acc_active.append(c0 + np.nonzero(nz)[0])
+            acc_counts.append(counts[nz])
+            if s0 == start:
+                return np.concatenate(acc_active[::-1]), np.concatenate(acc_counts[::-1])
+        mp = self._mapping_host.view(start)
         uniq, first, counts = np.unique(mp, return_index=True, return_counts=True)
         order = np.argsort(first)
         return uniq[order], counts[order]
@@ -201,23 +253,20 @@ class SampleDB:
         start = max(0, self._samples.n - N)                                                    # :216
         xs = self._samples.view(start)
         active, counts = self._active_components(start)                                        # :221
-        lo, hi = int(active.min()), int(active.max()) + 1
-        if hi - lo == len(active) and np.all(np.diff(active) == 1):
+        lo, hi = int(active[0]), int(active[-1]) + 1
+        if hi - lo == len(active) and (len(active) == 1 or np.all(np.diff(active) == 1)):
             packed = self._packed.view(lo, hi)                 # contiguous snapshot range: no gather
         else:
             packed = hip_ops.gather_rows(ctx, self._packed.view(), active.astype(np.int32))
-        key = counts.tobytes()
-        logw = self._logw_cache.get(key)
-        if logw is None:
+
+        def build():
             w = counts.astype(np.float64) / counts.sum()                                       # :225-226
-            logw = ctx.asarray(np.log(w).astype(np.float32))
-            if len(self._logw_cache) > 64:
-                self._logw_cache.clear()
-            self._logw_cache[key] = logw
+            return ctx.asarray(np.log(w).astype(np.float32))
+        logw = ctx.cached_const(("bg_logw", counts.tobytes()), build)
         _, bg, _ = hip_ops.mixture_eval(ctx, packed, logw, xs, d, want_lp=True)                # :227
         return (bg, xs, self._mapping_dev.view(start), self._target_lnpdfs.view(start),
                 self._target_grads.view(start))
 
     def newest_mapping_host(self, N):
         start = max(0, self._samples.n - int(N))
-        return self._mapping_host[start:]
+        return self._mapping_host.view(start)

@@ -68,6 +68,8 @@ int gmmvi_fill_f32(gmmvi_ctx* ctx, float* dst_dev, float value, size_t count);
  * get_random_sample / background-component gather (optimization/sample_db.py:63-79,137-152,222-224 tf.gather). */
 int gmmvi_gather_rows(gmmvi_ctx* ctx, const void* src_dev, const int32_t* idx_dev, int n_rows, int row_words,
                       void* dst_dev);
+/* dst[i] = src[i] + value: the mapping offset of SampleDB.add_samples (optimization/sample_db.py:115). */
+int gmmvi_add_scalar_i32(gmmvi_ctx* ctx, int32_t* dst_dev, const int32_t* src_dev, int32_t value, size_t count);
 /* dst[i] = exp(src[i])  (GMM.weights, models/gmm.py:171; weight history, models/gmm_wrapper.py:182). */
 int gmmvi_exp_f32(gmmvi_ctx* ctx, float* dst_dev, const float* src_dev, size_t count);
 /* timing helpers for bench.py: HIP events on the context's stream */
