@@ -1,0 +1,282 @@
+"""Component-sharded train_iter over the GPUs of one node (the reference has no multi-GPU code).
+
+Partition: rank r owns components [r*Kl, (r+1)*Kl) -- their means, Cholesky factors, stepsizes, etas and the
+samples they draw.  Every component needs all N samples (``only_use_own_samples: False``), so one iteration has
+three exchange steps, each an RCCL all-gather over xGMI followed by a local combine:
+
+  E1  samples, target log-densities and target gradients of the locally drawn samples      [N/R, 2D+1] per rank
+  E2  per-sample partial mixtures over the local components: background (max,sum) folded into one log value,
+      model log q partial and its responsibility-weighted gradient partial                  [N, D+2]   per rank
+  E3  post-update log q partial [N] and the per-component expected log-ratios / rewards    [N] + [2 Kl] per rank
+
+Stein estimate and the KL-constrained component update are local to the owner.  The mixture weights [K], the
+reward history and the weight trust-region step are replicated (every rank computes the identical [K]-sized update
+from the gathered expected log-ratios), so no broadcast is needed.  Philox sample indices are global (rank offset
+folded into the counter), hence a sharded run draws exactly the samples of the single-GPU run on the same seed.
+
+Scope: the SAMTRON hot path with a fixed number of components and reuse ratio 0 (the configuration bench.py scales).
+The orchestration is written against a small ``ops`` / ``exchange`` interface so that the exchange logic is
+exercised by world-size-2 gloo tests on CPU (tests/test_sharded_cpu.py); on the GPU ``HipOps`` + ``RcclExchange``.
+"""
+import os
+import time
+
+import numpy as np
+
+FLOAT32_MIN = float(np.finfo(np.float32).min)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GPU back end
+# ---------------------------------------------------------------------------------------------------------------------
+class HipOps:
+    """hip_ops behind the interface ShardedGMMVI uses (DeviceArrays in HBM)."""
+
+    def __init__(self, ctx, target):
+        from . import hip_ops
+        self.ctx, self.h, self.target = ctx, hip_ops, target
+
+    def asarray(self, x, dtype=np.float32):
+        return self.ctx.asarray(x, dtype)
+
+    def full(self, shape, v):
+        return self.ctx.full(shape, v)
+
+    def rows(self, a, lo, hi):
+        return a.rows(lo, hi)
+
+    def to_host(self, a):
+        return a.numpy()
+
+    def copy_into(self, dst, src):
+        dst.copy_from(src)
+
+    def sample(self, means, chols, counts, seed, first_index):
+        offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        od = self.ctx.cached_const(("offsets", offsets.tobytes()), lambda: self.ctx.asarray(offsets, np.int32))
+        return self.h.sample_components(self.ctx, means, chols, od, int(offsets[-1]), seed=seed,
+                                        first_index=first_index)[0]
+
+    def target_eval(self, x):
+        lp, grad = self.target.log_density_and_grad(x)
+        return self.ctx.asarray(lp), self.ctx.asarray(grad)
+
+    def pack(self, means, chols):
+        return self.h.pack_components(self.ctx, means, chols)[0]
+
+    def mixture(self, packed, logw, x, d, want_ld=False, want_grad=False):
+        return self.h.mixture_eval(self.ctx, packed, logw, x, d, want_ld=want_ld, want_lp=True, want_grad=want_grad)
+
+    def combine(self, lp_parts, grad_parts, d):
+        return self.h.combine_partials(self.ctx, lp_parts, grad_parts, d)
+
+    def component_stepsize(self, steps, prev, last, c):
+        self.h.component_stepsize_improvement(self.ctx, steps, prev, last, c["min_stepsize"], c["max_stepsize"],
+                                              c["stepsize_inc_factor"], c["stepsize_dec_factor"])
+
+    def stein(self, packed, x, ld, qgrad, bg, tgrad, d):
+        return self.h.stein(self.ctx, packed, x, ld, qgrad, bg, tgrad, d)
+
+    def update_kl(self, means, chols, h_neg, g_neg, steps, temperature, l2_init, last_eta, l2, nupd):
+        return self.h.update_components_kl(self.ctx, means, chols, h_neg, g_neg, steps, temperature, l2_init, last_eta,
+                                           l2, nupd)[0]
+
+    def elr(self, ld, bg, tlp, logq, beta, logw_loc):
+        k = ld.shape[0]
+        reward = self.ctx.empty((k,))
+        e, _ = self.h.expected_log_ratios(self.ctx, ld, bg, tlp, logq, beta, logw_loc, True, reward_out=reward)
+        return e, reward
+
+    def weight_stepsize(self, logw, rewards_last, state, c):
+        self.h.weight_stepsize_improvement(self.ctx, logw, rewards_last, state, c["min_stepsize"], c["max_stepsize"],
+                                           c["stepsize_inc_factor"], c["stepsize_dec_factor"])
+
+    def update_weights(self, logw, e, stepsize_view, beta):
+        self.h.update_weights(self.ctx, "trust-region", logw, e, stepsize_view, beta)
+
+
+class RcclExchange:
+    """RCCL all-gather / all-reduce over the ranks of one node (one process per GPU).  The 128-byte ncclUniqueId
+    travels through a file in the node-local temp directory keyed by the launcher's MASTER_PORT / run id."""
+
+    def __init__(self, ctx, n_ranks, rank, tag=None, timeout=120.0):
+        import ctypes as C
+        self.ctx, self.n_ranks, self.rank = ctx, n_ranks, rank
+        # all ranks of one launch share the launcher as parent process: a stale file of an earlier run never matches
+        tag = tag or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gmmvi_rccl_id_{tag}_{n_ranks}.bin")
+        if rank == 0:
+            buf = C.create_string_buffer(128)
+            rc = ctx.lib.gmmvi_comm_unique_id(buf)
+            if rc != 0:
+                ctx.check(rc)
+            tmp = path + f".tmp{os.getpid()}"
+            with open(tmp, "wb") as f:
+                f.write(buf.raw)
+            os.replace(tmp, path)
+            uid = buf.raw
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    if os.path.getsize(path) == 128 and os.path.getmtime(path) > time.time() - 3600:
+                        with open(path, "rb") as f:
+                            uid = f.read()
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > timeout:
+                    raise TimeoutError(f"rank {rank}: no RCCL id at {path}")
+                time.sleep(0.02)
+        ctx.check(ctx.lib.gmmvi_comm_init(ctx.handle, uid, n_ranks, rank))
+        ctx.n_ranks, ctx.rank = n_ranks, rank
+        self._scalar = ctx.empty((1,))
+        self.barrier()
+        if rank == 0:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+    def allgather(self, arr):
+        """[m, ...] per rank -> [R*m, ...] in rank order."""
+        out = self.ctx.empty((self.n_ranks * arr.shape[0],) + tuple(arr.shape[1:]), arr.dtype)
+        self.ctx.check(self.ctx.lib.gmmvi_allgather_f32(self.ctx.handle, arr.ptr, out.ptr, arr.size))
+        return out
+
+    def barrier(self):
+        self._scalar.set(np.zeros(1, np.float32))
+        self.ctx.check(self.ctx.lib.gmmvi_allreduce_f32(self.ctx.handle, self._scalar.ptr, 1, 0))
+        self.ctx.sync()
+
+    def max_scalar(self, v):
+        self._scalar.set(np.array([v], np.float32))
+        self.ctx.check(self.ctx.lib.gmmvi_allreduce_f32(self.ctx.handle, self._scalar.ptr, 1, 1))
+        return float(self._scalar.numpy()[0])
+
+
+class LocalExchange:
+    """Single-rank stand-in (n_ranks == 1): the sharded code path without a communicator."""
+    n_ranks, rank = 1, 0
+
+    def allgather(self, arr):
+        return arr
+
+    def barrier(self):
+        pass
+
+    def max_scalar(self, v):
+        return v
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# orchestration (back-end agnostic)
+# ---------------------------------------------------------------------------------------------------------------------
+class ShardedGMMVI:
+    def __init__(self, ops, exchange, d, k_total, means_loc, chols_loc, samples_per_component, seed, cfg,
+                 history_length=64):
+        self.ops, self.exchange = ops, exchange
+        self.R, self.rank = exchange.n_ranks, exchange.rank
+        if k_total % self.R:
+            raise ValueError("the number of components must be divisible by the number of ranks")
+        self.d, self.K, self.Kl = d, k_total, k_total // self.R
+        self.S = int(samples_per_component)
+        self.Nl, self.N = self.Kl * self.S, k_total * self.S
+        self.lo, self.hi = self.rank * self.Kl, (self.rank + 1) * self.Kl
+        self.seed = seed
+        self.temperature = float(cfg["temperature"])
+        self.cs = cfg["component_stepsize_adapter_config"]
+        self.ws = cfg["weight_stepsize_adapter_config"]
+        o = ops
+        self.means, self.chols = o.asarray(means_loc), o.asarray(chols_loc)
+        self.log_weights = o.asarray(np.full(k_total, -np.log(k_total), np.float32))      # replicated
+        self.stepsizes = o.full((self.Kl,), float(self.cs["initial_stepsize"]))
+        self.last_eta = o.full((self.Kl,), -1.0)
+        self.l2 = o.full((self.Kl,), 1e-12)
+        self.num_received_updates = o.full((self.Kl,), 0.0)
+        self.H = int(history_length)
+        self.reward_ring = o.full((self.H, k_total), FLOAT32_MIN)                         # replicated
+        self.t_reward = 0
+        self.wstate = o.asarray(np.array([self.ws["initial_stepsize"], FLOAT32_MIN], np.float32))
+        self.logc_loc = o.asarray(np.full(self.Kl, np.log(self.S / self.N), np.float32))   # background log-counts
+        self.counts_loc = np.full(self.Kl, self.S, np.int64)
+        self.num_samples_written = 0
+        self.num_updates = 0
+        self.last_success = None
+
+    # reward ring helpers (same convention as GmmWrapper)
+    def _slot(self, back):
+        s = (self.t_reward - 1 - back) % self.H
+        return self.ops.rows(self.reward_ring, s, s + 1)
+
+    def train_iter(self):
+        o, ex, d, R, N = self.ops, self.exchange, self.d, self.R, self.N
+        # ---- sampling + target (local components) and exchange E1 -------------------------------------------------
+        first = self.num_samples_written + self.rank * self.Nl
+        x_loc = o.sample(self.means, self.chols, self.counts_loc, self.seed, first)
+        tlp_loc, tgrad_loc = o.target_eval(x_loc)
+        x = ex.allgather(x_loc)
+        tlp = ex.allgather(tlp_loc)
+        tgrad = ex.allgather(tgrad_loc)
+        self.num_samples_written += N
+        # ---- partial background / model densities over the local components, exchange E2 --------------------------
+        packed = o.pack(self.means, self.chols)
+        logw_loc = o.rows(self.log_weights, self.lo, self.hi)
+        _, bg_part, _ = o.mixture(packed, self.logc_loc, x, d)
+        ld, lq_part, qg_part = o.mixture(packed, logw_loc, x, d, want_ld=True, want_grad=True)
+        if R > 1:
+            bg, _ = o.combine(self._stack(ex.allgather(bg_part), N), None, d)
+            logq, qgrad = o.combine(self._stack(ex.allgather(lq_part), N), self._stack(ex.allgather(qg_part), N, d), d)
+        else:
+            bg, logq, qgrad = bg_part, lq_part, qg_part
+        # ---- component updates (local) ----------------------------------------------------------------------------------
+        prev, last = (o.rows(self._row1d(self._slot(1)), self.lo, self.hi),
+                      o.rows(self._row1d(self._slot(0)), self.lo, self.hi))
+        o.component_stepsize(self.stepsizes, prev, last, self.cs)
+        h_neg, g_neg = o.stein(packed, x, ld, qgrad, bg, tgrad, d)
+        self.last_success = o.update_kl(self.means, self.chols, h_neg, g_neg, self.stepsizes, self.temperature, 1e-12,
+                                        self.last_eta, self.l2, self.num_received_updates)
+        # ---- weight update: post-update density, exchange E3 -------------------------------------------------------------
+        o.weight_stepsize(self.log_weights, self._row1d(self._slot(0)), self.wstate, self.ws)
+        packed = o.pack(self.means, self.chols)
+        ld2, lq2_part, _ = o.mixture(packed, logw_loc, x, d, want_ld=True)
+        logq2 = o.combine(self._stack(ex.allgather(lq2_part), N), None, d)[0] if R > 1 else lq2_part
+        e_loc, reward_loc = o.elr(ld2, bg, tlp, logq2, self.temperature, logw_loc)
+        e = ex.allgather(e_loc)
+        reward = ex.allgather(reward_loc)
+        s = self.t_reward % self.H
+        o.copy_into(self._row1d(o.rows(self.reward_ring, s, s + 1)), reward)
+        self.t_reward += 1
+        o.update_weights(self.log_weights, e, o.rows(self.wstate, 0, 1), self.temperature)
+        self.num_updates += 1
+
+    @staticmethod
+    def _row1d(a):
+        return a.reshape(-1)
+
+    @staticmethod
+    def _stack(a, n, d=None):
+        """[R*n(,d)] gathered buffer -> [R, n(,d)] view."""
+        r = a.shape[0] // n
+        return a.reshape((r, n) if d is None else (r, n, d))
+
+    # ---- bench.py factory ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def build(w, n_ranks, rank):
+        """From bench.py's workload dict: shard the K initial components over the ranks and connect RCCL."""
+        from .device import get_context
+        from . import hip_ops
+        ctx = get_context()
+        k_total = w["k_total"]
+        kl = k_total // n_ranks
+        lo, hi = rank * kl, (rank + 1) * kl
+        chols, ok = hip_ops.cholesky(ctx, ctx.asarray(w["covs"][lo:hi]))
+        exchange = RcclExchange(ctx, n_ranks, rank) if n_ranks > 1 else LocalExchange()
+        return ShardedGMMVI(HipOps(ctx, w["target"]), exchange, w["d"], k_total, w["means"][lo:hi], chols, w["s"],
+                            w["seed"], w["cfg"])
+
+    # ---- host views (tests / metrics) -----------------------------------------------------------------------------------
+    def gather_model(self):
+        """(log_weights [K], means [K,D], chols [K,D,D]) on the host, gathered from all ranks."""
+        o, ex = self.ops, self.exchange
+        return (o.to_host(self.log_weights), o.to_host(ex.allgather(self.means)), o.to_host(ex.allgather(self.chols)))
