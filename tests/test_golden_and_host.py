@@ -1,0 +1,137 @@
+"""CPU suite (-m "not gpu"): oracle against the committed golden trajectories, host logic (config merge, alias
+package), and the C-ABI library: loads and exports every symbol include/gmmvi_hip.h declares (no compute calls)."""
+import glob
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+from helpers import samtron_config, make_oracle  # noqa: E402
+
+GOLDEN = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "samtron_*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_reproduces_golden(path):
+    g = np.load(path)
+    kind, d, k, s, seed = str(g["kind"]), int(g["d"]), int(g["k"]), int(g["s"]), int(g["seed"])
+    iters = min(int(g["iters"]), 8 if d > 10 else 20)
+    o = make_oracle(kind, d, k, s, seed, samtron_config(s))
+    np.testing.assert_allclose(o.model.means, g["init_means"], rtol=1e-12)
+    for it in range(iters):
+        info = o.train_iter()
+        np.testing.assert_allclose(o.model.means, g["means"][it], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(o.model.chol_cov, g["chols"][it], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(o.model.log_weights, g["log_weights"][it], rtol=1e-7, atol=1e-9)
+        np.testing.assert_array_equal(info["success"], g["success"][it])
+        np.testing.assert_array_equal(info["n_probes"], g["n_probes"][it])
+        np.testing.assert_allclose(o.model.stepsizes, g["stepsizes"][it], rtol=1e-12)
+
+
+def test_golden_files_hold_data_only():
+    for p in GOLDEN:
+        g = np.load(p)
+        assert {"init_means", "init_covs", "means", "chols", "log_weights", "success", "elbo"} <= set(g.files)
+        assert os.path.getsize(p) < 1 << 20
+
+
+# ---------------------------------------------------------------------------------------------- C ABI
+@pytest.fixture(scope="session")
+def built_lib():
+    from gmmvi_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "gmmvi_amd", "csrc"), "-j8"], check=True)
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from gmmvi_amd import _lib
+    header = open(os.path.join(ROOT, "include", "gmmvi_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(gmmvi_[a-z0-9_]+)\s*\(", header))
+    declared -= {"gmmvi_ctx"}
+    assert len(declared) > 40
+    missing_binding = declared - set(_lib.EXPORTED_SYMBOLS)
+    assert not missing_binding, f"declared in the header but not bound in _lib.py: {sorted(missing_binding)}"
+    for name in declared:
+        assert hasattr(built_lib, name), f"{name} is declared but not exported by libgmmvi_hip.so"
+    extra = set(_lib.EXPORTED_SYMBOLS) - declared
+    assert not extra, f"bound but not declared in the header: {sorted(extra)}"
+    # argument-free query works without a GPU
+    assert built_lib.gmmvi_packed_stride(20) == ((2 * 20 + 20 * 19 + 1 + 3) // 4) * 4
+    assert built_lib.gmmvi_packed_stride(65) == 0
+    assert built_lib.gmmvi_device_count() >= 0
+
+
+def test_context_creation_fails_loudly_without_gpu(built_lib):
+    from gmmvi_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from gmmvi_amd.device import Context
+    with pytest.raises(_lib.GmmviError):
+        Context(0)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under gmmvi_amd/ or gmmvi/ may import it."""
+    for pkg in ("gmmvi_amd", "gmmvi"):
+        for path in glob.glob(os.path.join(ROOT, pkg, "**", "*.py"), recursive=True):
+            src = open(path).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
+
+
+# ---------------------------------------------------------------------------------------------- host logic
+def test_config_merge_semantics():
+    from gmmvi_amd.configs import get_default_algorithm_config, get_default_experiment_config, update_config, \
+        get_default_config
+    c = get_default_algorithm_config("SAMTRON")
+    assert c["ng_estimator_type"] == "Stein" and c["num_component_adapter_type"] == "adaptive"
+    assert c["sample_selector_type"] == "component-based" and c["ng_based_updater_type"] == "trust-region"
+    assert c["component_stepsize_adapter_type"] == "improvement-based"          # hyphen
+    assert c["weight_stepsize_adapter_type"] == "improvement_based"             # underscore
+    assert c["weight_updater_type"] == "trust-region"
+    assert c["sample_selector_config"] == {"desired_samples_per_component": 100, "ratio_reused_samples_to_desired": 2.}
+    assert c["num_component_adapter_config"]["thresholds_for_add_heuristic"] == [5000., 1000., 500., 200., 100., 50.]
+    e = get_default_experiment_config("stm20")
+    assert e["model_initialization"]["num_initial_components"] == 20 and e["environment_config"]["num_dimensions"] == 20
+    u = update_config(e, {"model_initialization": {"num_initial_components": 45}, "start_seed": 3})
+    assert u["model_initialization"] == dict(e["model_initialization"], num_initial_components=45) and u["start_seed"] == 3
+    assert e["model_initialization"]["num_initial_components"] == 20                # inputs untouched
+    u2 = update_config(c, {"num_component_adapter_config": {"thresholds_for_add_heuristic": [1.0]}})
+    assert u2["num_component_adapter_config"]["thresholds_for_add_heuristic"] == [1.0]     # lists are REPLACED
+    full = get_default_config("SEPYFUX", "planar_robot_4")
+    assert full["ng_based_updater_type"] == "iBLR" and full["environment_name"] == "PlanarRobot4"
+    assert len(full["model_initialization"]["prior_scale"]) == 10
+    with pytest.raises(KeyError):
+        get_default_algorithm_config("SAMTRO?")
+
+
+def test_alias_package_maps_reference_module_paths():
+    import gmmvi  # noqa: F401
+    import gmmvi.gmmvi_runner as a
+    import gmmvi_amd.gmmvi_runner as b
+    assert a is b
+    from gmmvi.optimization.gmmvi_modules.ng_based_component_updater import NgBasedComponentUpdater
+    from gmmvi.optimization.gmmvi_modules.weight_updater import WeightUpdater
+    from gmmvi.optimization.gmmvi_modules.ng_estimator import NgEstimator
+    from gmmvi.optimization.gmmvi_modules.sample_selector import SampleSelector
+    from gmmvi.optimization.gmmvi_modules.component_adaptation import ComponentAdaptation
+    from gmmvi.optimization.gmmvi_modules.component_stepsize_adaptation import ComponentStepsizeAdaptation
+    from gmmvi.optimization.gmmvi_modules.weight_stepsize_adaptation import WeightStepsizeAdaptation
+    from gmmvi.experiments.target_distributions.lnpdf import LNPDF
+    for cls, key in ((NgBasedComponentUpdater, "ng_based_updater_type"), (WeightUpdater, "weight_updater_type"),
+                     (NgEstimator, "ng_estimator_type"), (SampleSelector, "sample_selector_type")):
+        with pytest.raises(ValueError):
+            args = ({key: "bogus", "temperature": 1.0}, None) if cls is not NgEstimator else \
+                ({key: "bogus"}, 1.0, None)
+            if cls is SampleSelector:
+                args = ({key: "bogus"}, None, None, None)
+            cls.build_from_config(*args)
+    assert LNPDF(use_log_density_and_grad=True, safe_for_tf_graph=False).use_log_density_and_grad

@@ -129,3 +129,44 @@ def test_runner_and_example_surface(tmp_path):
     assert metrics["num_samples"] == sum(50 * k for k in [5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7])
     import glob
     assert len(glob.glob(str(tmp_path) + "/*/gmm_dump_*.npz")) == 11
+
+
+# ---- committed golden fixtures (tests/golden/*.npz: inputs + oracle outputs; generated by make_golden.py) -----------
+import glob as _glob
+import os as _os
+
+_GOLDEN = sorted(_glob.glob(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "samtron_*.npz")))
+
+
+@pytest.mark.parametrize("path", _GOLDEN, ids=[_os.path.basename(p) for p in _GOLDEN])
+def test_device_reproduces_golden_trajectory(path):
+    from gmmvi_amd.models.full_cov_gmm import FullCovGMM
+    from gmmvi_amd.models.gmm_wrapper import GmmWrapper
+    from gmmvi_amd.optimization.gmmvi import GMMVI
+    from gmmvi_amd.experiments.target_distributions.gmm import GMM_LNPDF
+    from gmmvi_amd.experiments.target_distributions.student_t_mixture import StudentTMixture_LNPDF
+    from gmmvi_amd.experiments.target_distributions.planar_robot import PlanarRobot
+    g = np.load(path)
+    kind, d, s, seed, iters = str(g["kind"]), int(g["d"]), int(g["s"]), int(g["seed"]), int(g["iters"])
+    if kind == "stm":
+        tgt = StudentTMixture_LNPDF(g["target_weights"], g["target_means"], g["target_covs"], alpha=2)
+    elif kind == "gmm":
+        tgt = GMM_LNPDF(g["target_weights"], g["target_means"], g["target_covs"])
+    else:
+        tgt = PlanarRobot(d, 4)
+    model = FullCovGMM(g["init_weights"], g["init_means"].astype(np.float32), g["init_covs"].astype(np.float32))
+    model.seed = seed
+    cfg = samtron_config(s)
+    algo = GMMVI.build_from_config(cfg, tgt, GmmWrapper(model, 0.1, 1e-12, 400))
+    algo.ng_based_updater.want_info = True
+    for it in range(iters):
+        algo.train_iter()
+        tol = 2e-3 * (1 + it)
+        m = algo.model
+        assert np.abs(m.means.numpy() - g["means"][it]).max() <= tol * max(1.0, np.abs(g["means"][it]).max())
+        assert np.abs(m.chol_cov.numpy() - g["chols"][it]).max() <= tol * np.abs(g["chols"][it]).max()
+        assert np.abs(np.exp(m.log_weights.numpy()) - np.exp(g["log_weights"][it])).max() <= tol
+        np.testing.assert_array_equal(algo.ng_based_updater.last_success.numpy().astype(bool), g["success"][it])
+        np.testing.assert_allclose(m.stepsizes.numpy(), g["stepsizes"][it], rtol=1e-5)
+        if it < 5:
+            np.testing.assert_array_equal(algo.ng_based_updater.last_info[1].numpy(), g["n_probes"][it])

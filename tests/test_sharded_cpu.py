@@ -165,13 +165,22 @@ def _worker(rank, world, init_file, out_dir):
     else:
         ex.allgather(algo.stepsizes); ex.allgather(algo.last_eta)
     ex.barrier()
+    ex.dist.destroy_process_group()
 
 
 def test_sharded_orchestration_matches_unsharded_oracle():
-    import torch.multiprocessing as mp
+    # plain multiprocessing (spawn): torch is imported only inside the two workers, never in the pytest process,
+    # which may already hold libgmmvi_hip.so (two HIP runtimes in one process abort at exit)
+    import multiprocessing as mp
+    mpc = mp.get_context("spawn")
     with tempfile.TemporaryDirectory() as tmp:
         init_file = os.path.join(tmp, "rdzv")
-        mp.spawn(_worker, args=(2, init_file, tmp), nprocs=2, join=True)
+        procs = [mpc.Process(target=_worker, args=(r, 2, init_file, tmp)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
         got = np.load(os.path.join(tmp, "sharded.npz"))
         cfg = samtron_config(S)
         ref = make_oracle(KIND, D, K, S, SEED, cfg)
