@@ -343,7 +343,7 @@ size_t update_lds_bytes(int D) { return ((size_t)5 * D * (D + 1) + 6 * D) * size
 
 extern "C" {
 
-int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_dev,
+int gmmvi_update_components_kl_reference(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_dev,
                                const float* H_neg_dev, const float* g_neg_dev, const float* stepsizes_dev,
                                float temperature, float l2_init, float* last_eta_dev, float* l2_dev,
                                float* num_received_updates_dev, int32_t* success_out_dev, float* kl_out_dev,
@@ -355,7 +355,7 @@ int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* means_dev, f
     if (shmem > 64 * 1024)
         GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)update_kl_kernel,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    GMMVI_PROF(ctx, "update_kl");
+    GMMVI_PROF(ctx, "update_kl_reference");
     hipLaunchKernelGGL(update_kl_kernel, dim3(K), dim3(64), shmem, ctx->stream, D, means_dev, chols_dev, H_neg_dev,
                        g_neg_dev, stepsizes_dev, temperature, l2_init, last_eta_dev, l2_dev, num_received_updates_dev,
                        success_out_dev, kl_out_dev, n_probes_out_dev);

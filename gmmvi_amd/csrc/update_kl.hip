@@ -1,0 +1,328 @@
+// KL-constrained natural-gradient component update, production kernel
+// (gmmvi_modules/ng_based_component_updater.py:431-524; bracketing_search :335-429; kl :244-333).
+//
+// Same decisions as the reference, different arithmetic route.  In the coordinates whitened by the old Cholesky factor
+// L (Sigma = L L^T) the updated precision is Q' = L^-T (I + M/eta) L^-1 with M = L^T R L (R = expected_hessian_neg), and
+//     KL(eta) = 1/2 [ logdet B - D + tr B^-1 + |B^-1 w|^2 / eta^2 ],   B = I + M/eta,  w = L^T (g_neg + (R_sym - R) mu)
+// (derivation in DESIGN.md section 4).  M is reduced ONCE to tridiagonal form T = H^T M H (Householder), after which
+// logdet, tr(B^-1) (two-sided pivot recurrences) and |B^-1 w| (Thomas solve) cost O(D) per eta.  The bisection of the
+// reference is then evaluated speculatively: the 63 nodes of the next six levels of the bisection tree are probed in
+// parallel, one lane per node, and the tree is walked with the reference's stop rules -- the visited etas, the
+// comparisons and therefore the accepted eta are those of the sequential search.  The new factor follows from the
+// UL factorisation B = U U^T:  L' = L U^-T is lower triangular with positive diagonal, i.e. chol(Sigma') itself.
+// "Cholesky failed" (non-positive pivot / NaN) maps to KL = float32.max and to the reject branch (:320-324, :493).
+// One wavefront per component, matrices in LDS (row stride D+1), lane = row (D <= 64).
+#include "common.h"
+#include <cfloat>
+
+namespace {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+struct Ws {
+    int D, ld;
+    float *L, *M, *Mc;                 // D x D (stride ld): old factor; M (tridiagonalised in place); copy of M / outputs
+    float *mu, *w, *wt, *td, *te, *v, *q, *y, *z;   // D each
+    float* pr;                          // per-lane probe scratch [2 D][64]
+};
+
+__device__ void carve(Ws& s, float* sm, int D) {
+    s.D = D; s.ld = D + 1;
+    const int m = D * (D + 1);
+    s.L = sm; s.M = sm + m; s.Mc = sm + 2 * m;
+    float* v = sm + 3 * m;
+    s.mu = v; s.w = v + D; s.wt = v + 2 * D; s.td = v + 3 * D; s.te = v + 4 * D; s.v = v + 5 * D; s.q = v + 6 * D;
+    s.y = v + 7 * D; s.z = v + 8 * D;
+    s.pr = v + 9 * D;
+}
+
+size_t lds_bytes(int D) { return ((size_t)3 * D * (D + 1) + 9 * D + (size_t)2 * D * 64) * sizeof(float); }
+
+// KL(eta) from the tridiagonal form; every lane may evaluate a different eta (scratch column = lane).
+__device__ float kl_tridiag(const Ws& s, float eta) {
+    const int D = s.D, lane = threadIdx.x;
+    const float inv = 1.f / eta;
+    float* dcol = s.pr + lane;                 // d_i at [i][lane], c_i at [D + i][lane]
+    float dprev = 1.f, cprev = 0.f, logdet = 0.f;
+    bool ok = true;
+    for (int i = 0; i < D; ++i) {
+        const float a = fmaf(s.td[i], inv, 1.f);
+        float d = a, c = s.wt[i];
+        if (i > 0) {
+            const float b = s.te[i - 1] * inv;
+            const float r = b / dprev;
+            d = fmaf(-b, r, a);
+            c = fmaf(-r, cprev, c);
+        }
+        ok = ok && (d > 0.f);
+        logdet += __logf(d);
+        dcol[i * 64] = d;
+        dcol[(D + i) * 64] = c;
+        dprev = d; cprev = c;
+    }
+    float dnext = 1.f, ynext = 0.f, tr = 0.f, yy = 0.f;
+    for (int i = D - 1; i >= 0; --i) {
+        const float a = fmaf(s.td[i], inv, 1.f);
+        const float d = dcol[i * 64], c = dcol[(D + i) * 64];
+        float delta = a, y = c / d;
+        if (i < D - 1) {
+            const float b = s.te[i] * inv;
+            delta = fmaf(-b, b / dnext, a);
+            y = (c - b * ynext) / d;
+        }
+        tr += 1.f / (d + delta - a);
+        yy = fmaf(y, y, yy);
+        dnext = delta; ynext = y;
+    }
+    float kl = 0.5f * (logdet - (float)D + tr + yy * inv * inv);
+    if (!ok || !(kl == kl)) kl = FLT_MAX;
+    return kl;
+}
+
+__global__ __launch_bounds__(64) void update_kl_fast_kernel(int D, float* __restrict__ means, float* __restrict__ chols,
+                                                            const float* __restrict__ H_neg, const float* __restrict__ g_neg,
+                                                            const float* __restrict__ stepsizes, float temperature,
+                                                            float l2_init, float* __restrict__ last_eta, float* __restrict__ l2,
+                                                            float* __restrict__ num_updates, int32_t* __restrict__ success_out,
+                                                            float* __restrict__ kl_out, int32_t* __restrict__ nprobes_out) {
+    extern __shared__ float sm[];
+    Ws s;
+    carve(s, sm, D);
+    const int k = blockIdx.x, t = threadIdx.x, ld = s.ld;
+    float* Lg = chols + (size_t)k * D * D;
+    float* mug = means + (size_t)k * D;
+    const float* Rg = H_neg + (size_t)k * D * D;
+
+    // ---- load: L, R_sym (lower triangle mirrored, as tf.linalg.cholesky reads only the lower part) into M -----------
+    for (int e = t; e < D * D; e += 64) {
+        const int i = e / D, j = e % D;
+        s.L[i * ld + j] = (j <= i) ? Lg[e] : 0.f;
+        s.M[i * ld + j] = (j <= i) ? Rg[e] : Rg[j * D + i];
+    }
+    if (t < D) {
+        s.mu[t] = mug[t];
+        // g~ = g_neg + (R_sym - R) mu   (zero correction for a symmetric R)
+        float gt = g_neg[(size_t)k * D + t];
+        for (int j = t + 1; j < D; ++j) gt = fmaf(Rg[j * D + t] - Rg[t * D + j], mug[j], gt);
+        s.y[t] = gt;
+    }
+    __syncthreads();
+    // ---- T1 = R_sym L (into Mc), M = L^T T1, w = L^T g~ ------------------------------------------------------------------
+    if (t < D) {
+        for (int j = 0; j < D; ++j) {
+            float a = 0.f;
+            for (int c = j; c < D; ++c) a = fmaf(s.M[t * ld + c], s.L[c * ld + j], a);
+            s.Mc[t * ld + j] = a;
+        }
+    }
+    __syncthreads();
+    if (t < D) {
+        for (int j = 0; j < D; ++j) {
+            float a = 0.f;
+            for (int c = t; c < D; ++c) a = fmaf(s.L[c * ld + t], s.Mc[c * ld + j], a);
+            s.M[t * ld + j] = a;
+        }
+        float a = 0.f;
+        for (int c = t; c < D; ++c) a = fmaf(s.L[c * ld + t], s.y[c], a);
+        s.w[t] = a;
+        s.wt[t] = a;
+    }
+    __syncthreads();
+    if (t < D) {                                   // exact symmetry for the reflectors; keep a copy for the final step
+        for (int j = 0; j < t; ++j) {
+            const float m = 0.5f * (s.M[t * ld + j] + s.M[j * ld + t]);
+            s.M[t * ld + j] = m; s.M[j * ld + t] = m;
+        }
+    }
+    __syncthreads();
+    if (t < D)
+        for (int j = 0; j < D; ++j) s.Mc[t * ld + j] = s.M[t * ld + j];
+    __syncthreads();
+
+    // ---- Householder tridiagonalisation of M (in place), reflectors applied to wt -----------------------------------------
+    for (int c = 0; c + 2 < D; ++c) {
+        const bool act = (t > c) && (t < D);
+        const float x = act ? s.M[t * ld + c] : 0.f;
+        const float x1 = __shfl(x, c + 1);
+        const float tail = wsum((t > c + 1) ? x * x : 0.f);
+        if (!(tail > 0.f)) {                        // column already tridiagonal (also covers NaN: handled later)
+            if (t == 0) s.te[c] = x1;
+            continue;
+        }
+        const float nrm = sqrtf(tail + x1 * x1);
+        const float alpha = (x1 > 0.f) ? -nrm : nrm;
+        const float vv = act ? (t == c + 1 ? x - alpha : x) : 0.f;
+        const float beta = 1.f / (nrm * nrm - alpha * x1);          // 2 / |v|^2, |v|^2 = 2 (alpha^2 - alpha x1)
+        if (t < D) s.v[t] = vv;
+        __syncthreads();
+        float p = 0.f;
+        if (act) {
+            for (int j = c + 1; j < D; ++j) p = fmaf(s.M[t * ld + j], s.v[j], p);
+            p *= beta;
+        }
+        const float kk = 0.5f * beta * wsum(vv * p);
+        const float qq = p - kk * vv;
+        if (t < D) s.q[t] = qq;
+        const float wdot = beta * wsum(act ? vv * s.wt[t] : 0.f);
+        __syncthreads();
+        if (act) {
+            for (int j = c + 1; j < D; ++j) s.M[t * ld + j] -= vv * s.q[j] + qq * s.v[j];
+            s.wt[t] -= wdot * vv;
+        }
+        if (t == 0) s.te[c] = alpha;
+        __syncthreads();
+    }
+    if (t < D) s.td[t] = s.M[t * ld + t];
+    if (t == 0 && D >= 2) s.te[D - 2] = s.M[(D - 1) * ld + (D - 2)];
+    __syncthreads();
+
+    // ---- speculative bisection: 63 tree nodes (6 levels) per round, one lane per node ------------------------------------
+    const float eps = stepsizes[k];
+    const float last = last_eta[k];
+    float lb, ub;
+    if (last < 0.f) { lb = -20.f; ub = 80.f; }                                            // :462-466
+    else { lb = fmaxf(0.f, __logf(last) - 3.f); ub = __logf(last) + 3.f; }                 // :467-471
+    bool ub_ok = false, done = false;
+    int probes = 0, iters = 0;
+    while (!done && iters < 1000) {                                                        // :399
+        // node of this lane: heap index t (1 = root); follow its bits from the root
+        float nlb = lb, nub = ub;
+        if (t >= 2) {
+            const int depth = 31 - __clz(t);                   // number of steps from the root
+            for (int b = depth - 1; b >= 0; --b) {
+                const float mid = 0.5f * (nub + nlb);
+                if ((t >> b) & 1) nlb = mid; else nub = mid;   // bit 1: "KL too large" branch (lb = eta)
+            }
+        }
+        const float neta = 0.5f * (nub + nlb);
+        const float e_eta = expf(neta);
+        const float ndiff = fminf(expf(nub) - e_eta, e_eta - expf(nlb));                  // :401
+        const float nkl = (t >= 1) ? kl_tridiag(s, e_eta) : 0.f;                           // :407
+        int n = 1;
+        for (int level = 0; level < 6 && !done && iters < 1000; ++level, ++iters) {
+            const float diff = __shfl(ndiff, n), klv = __shfl(nkl, n), eta = __shfl(neta, n);
+            if (diff < 1e-1f) { done = true; break; }                                      // :404-405
+            ++probes;
+            if (fabsf(eps - klv) < 1e-1f * eps) { lb = ub = eta; done = true; break; }     // :410-413
+            if (eps > klv) { ub = eta; ub_ok = true; n = 2 * n; }                          // :415-417
+            else { lb = eta; n = 2 * n + 1; }                                              // :418-419
+        }
+    }
+    if (ub_ok) lb = ub;                                                                    // :423-424
+    const float lo = expf(lb), hi = expf(ub);                                              // :426-427
+    const float eta_star = fmaxf(lo, temperature);                                         // :476
+    bool success = (lo == hi);                                                             // :478
+    float kl_val = -1.f;
+    const float inv = 1.f / eta_star;
+    if (success) {
+        kl_val = __shfl(kl_tridiag(s, eta_star), 0);                                       // :480-482
+        success = kl_val < FLT_MAX;                                                        // :488
+    }
+    if (success) {
+        // ---- B = I + Mc/eta*  ->  UL factor U (upper, B = U U^T) built in M -------------------------------------------------
+        if (t < D)
+            for (int j = t; j < D; ++j) s.M[t * ld + j] = (j == t ? 1.f : 0.f) + s.Mc[t * ld + j] * inv;
+        __syncthreads();
+        for (int j = D - 1; j >= 0 && success; --j) {
+            float a = 0.f;
+            if (t <= j) {
+                a = s.M[t * ld + j];
+                for (int c = j + 1; c < D; ++c) a = fmaf(-s.M[t * ld + c], s.M[j * ld + c], a);
+            }
+            const float p = __shfl(a, j);
+            if (!(p > 0.f) || !(p < FLT_MAX)) { success = false; break; }
+            const float d = sqrtf(p);
+            __syncthreads();
+            if (t == j) s.M[t * ld + j] = d;
+            else if (t < j) s.M[t * ld + j] = a / d;
+            __syncthreads();
+        }
+    }
+    if (success) {
+        // ---- Uinv (upper) into Mc: lane c solves U x = e_c from the bottom ---------------------------------------------------
+        if (t < D) {
+            for (int i = D - 1; i >= 0; --i) {
+                float a = (i == t) ? 1.f : 0.f;
+                for (int j = i + 1; j <= t; ++j) a = fmaf(-s.M[i * ld + j], s.Mc[j * ld + t], a);
+                s.Mc[i * ld + t] = (i <= t) ? a / s.M[i * ld + i] : 0.f;
+            }
+        }
+        __syncthreads();
+        // z = Uinv w ; y = Uinv^T z = B^-1 w
+        if (t < D) {
+            float a = 0.f;
+            for (int c = t; c < D; ++c) a = fmaf(s.Mc[t * ld + c], s.w[c], a);
+            s.z[t] = a;
+        }
+        __syncthreads();
+        if (t < D) {
+            float a = 0.f;
+            for (int c = 0; c <= t; ++c) a = fmaf(s.Mc[c * ld + t], s.z[c], a);
+            s.y[t] = a;
+        }
+        __syncthreads();
+        // new mean mu' = mu - L y / eta* ; new factor L' = L Uinv^T (row t), written to M (U no longer needed)
+        float new_mu = 0.f;
+        bool bad = false;
+        if (t < D) {
+            float a = 0.f;
+            for (int c = 0; c <= t; ++c) a = fmaf(s.L[t * ld + c], s.y[c], a);
+            new_mu = s.mu[t] - a * inv;
+            bad = !(new_mu == new_mu);
+        }
+        __syncthreads();
+        if (t < D) {
+            for (int j = 0; j <= t; ++j) {
+                float a = 0.f;
+                for (int c = j; c <= t; ++c) a = fmaf(s.L[t * ld + c], s.Mc[j * ld + c], a);
+                s.M[t * ld + j] = a;
+                bad |= !(a == a);
+            }
+            bad |= !(s.M[t * ld + t] > 0.f);
+        }
+        success = (__any(bad) == 0);                                                       // :493 is_nan(new_chol)
+        __syncthreads();
+        if (success) {
+            for (int e = t; e < D * D; e += 64) {
+                const int i = e / D, j = e % D;
+                Lg[e] = (j <= i) ? s.M[i * ld + j] : 0.f;
+            }
+            if (t < D) mug[t] = new_mu;
+        }
+    }
+    if (t == 0) {
+        last_eta[k] = success ? eta_star : -1.f;                                           // :504,:511,:524
+        if (kl_out) kl_out[k] = success ? kl_val : -1.f;
+        if (nprobes_out) nprobes_out[k] = probes;
+        const float old = l2[k];
+        l2[k] = success ? fmaxf(0.5f * old, l2_init) : fminf(1e-6f, 10.f * old);           // :520-523 (min on failure)
+        num_updates[k] += 1.f;                                                             // :519
+        if (success_out) success_out[k] = success ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+extern "C" int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_dev,
+                                          const float* H_neg_dev, const float* g_neg_dev, const float* stepsizes_dev,
+                                          float temperature, float l2_init, float* last_eta_dev, float* l2_dev,
+                                          float* num_received_updates_dev, int32_t* success_out_dev, float* kl_out_dev,
+                                          int32_t* n_probes_out_dev) {
+    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM);
+    GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && H_neg_dev && g_neg_dev && stepsizes_dev && last_eta_dev && l2_dev &&
+                             num_received_updates_dev);
+    size_t shmem = lds_bytes(D);
+    if (shmem > 64 * 1024)
+        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)update_kl_fast_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    GMMVI_PROF(ctx, "update_kl");
+    hipLaunchKernelGGL(update_kl_fast_kernel, dim3(K), dim3(64), shmem, ctx->stream, D, means_dev, chols_dev, H_neg_dev,
+                       g_neg_dev, stepsizes_dev, temperature, l2_init, last_eta_dev, l2_dev, num_received_updates_dev,
+                       success_out_dev, kl_out_dev, n_probes_out_dev);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}

@@ -148,6 +148,13 @@ int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* means_dev, f
                                float temperature, float l2_init, float* last_eta_dev, float* l2_dev,
                                float* num_received_updates_dev, int32_t* success_out_dev, float* kl_out_dev,
                                int32_t* n_probes_out_dev);
+/* Same contract, computed with the reference's own formulation (Q' = (eta Q + R)/eta, Cholesky + triangular inverse
+ * per probe, sequential bisection).  Slow; kept as an on-device cross-check of the production kernel. */
+int gmmvi_update_components_kl_reference(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_dev,
+                                         const float* H_neg_dev, const float* g_neg_dev, const float* stepsizes_dev,
+                                         float temperature, float l2_init, float* last_eta_dev, float* l2_dev,
+                                         float* num_received_updates_dev, int32_t* success_out_dev, float* kl_out_dev,
+                                         int32_t* n_probes_out_dev);
 /* DirectNgBasedComponentUpdater (:97-141) and NgBasedComponentUpdaterIblr (:160-223). */
 int gmmvi_update_components_direct(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_dev,
                                    const float* H_neg_dev, const float* g_neg_dev, const float* stepsizes_dev,

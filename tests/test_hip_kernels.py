@@ -319,3 +319,31 @@ def test_combine_partials(ctx, rng):
     ref_lp = logsumexp(lp, axis=0)
     np.testing.assert_allclose(out_lp.numpy(), ref_lp, rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(out_g.numpy(), np.einsum('rn,rnd->nd', np.exp(lp - ref_lp[None]), g), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("k,d", [(6, 4), (16, 20), (5, 33), (3, 64), (7, 1), (4, 2)])
+def test_update_kl_fast_kernel_matches_reference_formulation(ctx, rng, k, d):
+    """Production kernel (whitened + tridiagonal + speculative bisection) vs the kernel that follows the reference's
+    own arithmetic, over cold and warm starts and a non-symmetric reward Hessian (plain-IW Stein branch)."""
+    m, hs, gs = _update_inputs(rng, k, d)
+    if k > 1:
+        hs[1] = hs[1] + 0.05 * rng.normal(size=(d, d))                 # not symmetric: only the lower part counts
+    state = {}
+    for name in ("fast", "ref"):
+        logw, means, chols = upload_model(ctx, m)
+        state[name] = dict(means=means, chols=chols, last_eta=ctx.full((k,), -1.0), l2=ctx.full((k,), 1e-12),
+                           nupd=ctx.zeros((k,)))
+    steps = ctx.asarray(np.linspace(0.02, 0.6, k))
+    for round_ in range(3):
+        out = {}
+        for name in ("fast", "ref"):
+            st = state[name]
+            out[name] = ops().update_components_kl(ctx, st["means"], st["chols"], ctx.asarray(hs), ctx.asarray(gs), steps,
+                                                   1.0, 1e-12, st["last_eta"], st["l2"], st["nupd"], want_info=True,
+                                                   reference=(name == "ref"))
+        np.testing.assert_array_equal(out["fast"][0].numpy(), out["ref"][0].numpy())
+        np.testing.assert_array_equal(out["fast"][2].numpy(), out["ref"][2].numpy())           # identical probe counts
+        np.testing.assert_allclose(out["fast"][1].numpy(), out["ref"][1].numpy(), rtol=5e-3, atol=1e-5)
+        np.testing.assert_allclose(state["fast"]["last_eta"].numpy(), state["ref"]["last_eta"].numpy(), rtol=1e-5)
+        np.testing.assert_allclose(state["fast"]["means"].numpy(), state["ref"]["means"].numpy(), rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(state["fast"]["chols"].numpy(), state["ref"]["chols"].numpy(), rtol=2e-3, atol=2e-4)
