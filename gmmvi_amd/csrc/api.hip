@@ -144,6 +144,45 @@ int gmmvi_gather_rows(gmmvi_ctx* ctx, const void* src_dev, const int32_t* idx_de
     return GMMVI_OK;
 }
 
+struct CopyBatch { uint32_t* dst[8]; const uint32_t* src[8]; unsigned long long words[8]; int n; };
+
+__global__ void copy_batch_kernel(CopyBatch b) {
+    const int a = blockIdx.y;
+    if (a >= b.n) return;
+    const unsigned long long n = b.words[a];
+    uint32_t* __restrict__ d = b.dst[a];
+    const uint32_t* __restrict__ s = b.src[a];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * blockDim.x)
+        d[i] = s[i];
+}
+
+int gmmvi_copy_batch(gmmvi_ctx* ctx, int n, void* const* dst_dev, const void* const* src_dev, const size_t* nbytes) {
+    GMMVI_ARG_CHECK(ctx, n >= 0 && n <= 8);
+    if (n == 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, dst_dev && src_dev && nbytes);
+    CopyBatch b;
+    b.n = n;
+    unsigned long long mx = 0;
+    for (int i = 0; i < 8; ++i) {
+        b.dst[i] = i < n ? (uint32_t*)dst_dev[i] : nullptr;
+        b.src[i] = i < n ? (const uint32_t*)src_dev[i] : nullptr;
+        b.words[i] = i < n ? nbytes[i] / 4 : 0;
+        if (i < n) {
+            GMMVI_ARG_CHECK(ctx, nbytes[i] % 4 == 0 && (nbytes[i] == 0 || (dst_dev[i] && src_dev[i])));
+            if (b.words[i] > mx) mx = b.words[i];
+        }
+    }
+    if (mx == 0) return GMMVI_OK;
+    int bx = (int)((mx + 1023) / 1024);
+    if (bx > 512) bx = 512;
+    if (bx < 1) bx = 1;
+    GMMVI_PROF(ctx, "copy_batch");
+    hipLaunchKernelGGL(copy_batch_kernel, dim3(bx, n), dim3(256), 0, ctx->stream, b);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
 __global__ void add_scalar_i32_kernel(int32_t* dst, const int32_t* src, int32_t v, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;

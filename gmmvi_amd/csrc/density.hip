@@ -7,7 +7,9 @@
 // solve is fully unrolled for the padded dimension DP; partial (max, sum, gradient) of the W waves are merged
 // through LDS.
 #include "common.h"
+#include "subst.h"
 #include <cmath>
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------------------
 // pack: (means, chols) -> kernel-side blocks; optional explicit inverse (sample_db.py:121)
@@ -100,49 +102,46 @@ __global__ __launch_bounds__(64) void cholesky_kernel(int D, const float* __rest
 // ---------------------------------------------------------------------------------------------------------------
 // mixture_eval
 // ---------------------------------------------------------------------------------------------------------------
-template <int DP>
-__device__ __forceinline__ void forward_subst(const float* __restrict__ P, const float (&x)[DP], float (&z)[DP], float& q) {
-    using PK = Pack<DP>;
-    q = 0.f;
-#pragma unroll
-    for (int i = 0; i < DP; ++i) {
-        float t = x[i] - P[PK::MU + i];
-#pragma unroll
-        for (int j = 0; j < i; ++j) t = fmaf(-P[PK::LROW + PK::rowofs(i) + j], z[j], t);
-        z[i] = t * P[PK::RD + i];
-        q = fmaf(z[i], z[i], q);
-    }
-}
-
-// y = L^-T z  (Sigma^-1 (x - mu) when z = L^-1 (x - mu))
-template <int DP>
-__device__ __forceinline__ void backward_subst(const float* __restrict__ P, const float (&z)[DP], float (&y)[DP]) {
-    using PK = Pack<DP>;
-#pragma unroll
-    for (int i = DP - 1; i >= 0; --i) {
-        float t = z[i];
-#pragma unroll
-        for (int j = i + 1; j < DP; ++j) t = fmaf(-P[PK::LCOL + PK::colofs(i) + (j - i - 1)], y[j], t);
-        y[i] = t * P[PK::RD + i];
-    }
-}
-
-template <int DP, int FAMILY, bool GRAD>
-__global__ __launch_bounds__(1024) void mixture_eval_kernel(float nu, int K, int D, const float* __restrict__ packed,
+// LDSFEED: component blocks through a wave-private LDS copy (else scalar loads from global memory).
+// gridDim.y > 1: the components are split over blockIdx.y; lp_out / grad_out then receive per-chunk partials
+// ([chunk][N], [chunk][N][D]) that combine_partials merges.
+#ifndef GMMVI_ME_THREADS
+#define GMMVI_ME_THREADS 1024
+#define GMMVI_ME_MINW 1
+#endif
+template <int DP, int FAMILY, bool GRAD, bool LDSFEED>
+__global__ __launch_bounds__(GMMVI_ME_THREADS, GMMVI_ME_MINW) void mixture_eval_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
                                                             const float* __restrict__ logw, const float* __restrict__ X,
                                                             int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
                                                             float* __restrict__ grad_out) {
     using PK = Pack<DP>;
-    extern __shared__ float sm[];
+    extern __shared__ __align__(16) float sm[];
+    const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
+    const int k_lo = blockIdx.y * kchunk;
+    const int K = min(K_total, k_lo + kchunk);
+    if (gridDim.y > 1) {
+        if (lp_out) lp_out += (size_t)blockIdx.y * N;
+        if (GRAD && grad_out) grad_out += (size_t)blockIdx.y * N * D;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
-    const int n = blockIdx.x * 64 + lane;
-    const bool valid = n < N;
+    const int n0 = blockIdx.x * 64;
+    const int n_here = min(64, N - n0);
+    const int n = n0 + lane;
+    const bool valid = lane < n_here;
+    // LDS: [nwaves][STRIDE] wave-private component blocks, then the merge / staging area
+    float* Pw = sm + (size_t)wave * PK::STRIDE;
+    float* sm_merge = sm + (LDSFEED ? (size_t)nwaves * PK::STRIDE : 0);
 
+    // ---- x tile: coalesced load staged through LDS (rows of a row-major [N, D] array are 4D bytes apart) -----------
+    const int ldx = D | 1;
+    for (int e = threadIdx.x; e < n_here * D; e += blockDim.x) sm_merge[(e / D) * ldx + (e % D)] = X[(size_t)n0 * D + e];
+    __syncthreads();
     float x[DP];
 #pragma unroll
-    for (int i = 0; i < DP; ++i) x[i] = (valid && i < D) ? X[(size_t)n * D + i] : 0.f;
+    for (int i = 0; i < DP; ++i) x[i] = (valid && i < D) ? sm_merge[lane * ldx + i] : 0.f;
+    __syncthreads();
 
     float m = -3.0e38f, s = 0.f;
     float acc[GRAD ? DP : 1];
@@ -152,8 +151,22 @@ __global__ __launch_bounds__(1024) void mixture_eval_kernel(float nu, int K, int
     }
     const float nud = nu + (float)D;
 
-    for (int k = wave; k < K; k += nwaves) {
-        const float* __restrict__ P = packed + (size_t)k * PK::STRIDE;
+    // component blocks: coalesced global loads one component ahead (registers), then a wave-private LDS copy that the
+    // unrolled substitution reads with broadcast ds_read_b128
+    PackStager<DP> stager;
+    if (LDSFEED && k_lo + wave < K) stager.prefetch(packed, k_lo + wave, lane);
+    for (int k = k_lo + wave; k < K; k += nwaves) {
+        PackRef P;
+        if (LDSFEED) {
+            stager.commit(Pw, lane);
+            if (k + nwaves < K) stager.prefetch(packed, k + nwaves, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            P.p = reinterpret_cast<const float4*>(Pw);
+        } else {
+            P.p = reinterpret_cast<const float4*>(packed + (size_t)k * PK::STRIDE);
+        }
+        const float lw = logw[k];
         float z[DP], q;
         forward_subst<DP>(P, x, z, q);
         float ld, coef;
@@ -165,7 +178,7 @@ __global__ __launch_bounds__(1024) void mixture_eval_kernel(float nu, int K, int
             coef = -nud / (nu + q);
         }
         if (ld_out != nullptr && valid) ld_out[(size_t)k * N + n] = ld;
-        const float a = ld + logw[k];
+        const float a = ld + lw;
         const float mn = fmaxf(m, a);
         const float sc = __expf(m - mn);
         const float e = __expf(a - mn);
@@ -178,13 +191,17 @@ __global__ __launch_bounds__(1024) void mixture_eval_kernel(float nu, int K, int
 #pragma unroll
             for (int i = 0; i < DP; ++i) acc[i] = fmaf(acc[i], sc, ec * y[i]);
         }
+        if (LDSFEED) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     if (lp_out == nullptr && !GRAD) return;
 
     // merge the W waves' partials: sm_m[w][lane], sm_s[w][lane], sm_acc[w][i][lane]
-    float* sm_m = sm;
-    float* sm_s = sm + nwaves * 64;
-    float* sm_acc = sm + 2 * nwaves * 64;
+    float* sm_m = sm_merge;
+    float* sm_s = sm_merge + nwaves * 64;
+    float* sm_acc = sm_merge + 2 * nwaves * 64;
     sm_m[wave * 64 + lane] = m;
     sm_s[wave * 64 + lane] = s;
     if (GRAD) {
@@ -199,40 +216,85 @@ __global__ __launch_bounds__(1024) void mixture_eval_kernel(float nu, int K, int
     if (wave == 0 && valid && lp_out != nullptr) lp_out[n] = M + __logf(S);
     if (GRAD && grad_out != nullptr) {
         const float inv = 1.f / S;
+        // wave w reduces dimensions w, w + W, ...; results go to a [64][ldx] tile and leave coalesced
+        float* outt = sm_acc + (size_t)nwaves * DP * 64;
         for (int i = wave; i < D; i += nwaves) {
             float g = 0.f;
             for (int w = 0; w < nwaves; ++w) g += sm_acc[(w * DP + i) * 64 + lane] * __expf(sm_m[w * 64 + lane] - M);
-            if (valid) grad_out[(size_t)n * D + i] = g * inv;
+            outt[lane * ldx + i] = g * inv;
         }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n_here * D; e += blockDim.x)
+            grad_out[(size_t)n0 * D + e] = outt[(e / D) * ldx + (e % D)];
     }
 }
 
 template <int DP>
 static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
                                const float* logw, const float* X, int N, float* ld, float* lp, float* grad) {
+    using PK = Pack<DP>;
     const bool want_grad = grad != nullptr;
-    // waves per workgroup: enough to spread K, bounded by the LDS needed for the merge (<= 64 KiB) and 1024 threads
-    int per_wave_floats = 64 * ((want_grad ? DP : 0) + 2);
-    int max_w = (64 * 1024) / (per_wave_floats * 4);
-    int nw = K < 16 ? K : 16;
-    if (nw > max_w) nw = max_w;
-    if (nw < 1) nw = 1;
-    // plenty of sample tiles: fewer waves per tile keeps more tiles resident per CU
-    int tiles = (N + 63) / 64;
-    while (nw > 4 && (long)tiles * nw > 8L * 4 * ctx->num_cus) nw >>= 1;
-    size_t shmem = (size_t)nw * per_wave_floats * 4;
-    dim3 grid(tiles), block(nw * 64);
-    GMMVI_PROF(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval");
-#define GMMVI_LAUNCH_ME(FAM, G)                                                                              \
-    hipLaunchKernelGGL((mixture_eval_kernel<DP, FAM, G>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
-                       logw, X, N, ld, lp, grad)
-    if (family == GMMVI_GAUSS) {
-        if (want_grad) GMMVI_LAUNCH_ME(GMMVI_GAUSS, true); else GMMVI_LAUNCH_ME(GMMVI_GAUSS, false);
-    } else {
-        if (want_grad) GMMVI_LAUNCH_ME(GMMVI_STUDENT_T, true); else GMMVI_LAUNCH_ME(GMMVI_STUDENT_T, false);
+    const bool want_merge = want_grad || lp != nullptr;
+    static const int env_feed = getenv("GMMVI_ME_FEED") ? atoi(getenv("GMMVI_ME_FEED")) : 0;
+    static const int env_nw = getenv("GMMVI_ME_NW") ? atoi(getenv("GMMVI_ME_NW")) : 0;
+    static const int env_ky = getenv("GMMVI_ME_KY") ? atoi(getenv("GMMVI_ME_KY")) : 0;
+    const bool lds_feed = env_feed != 0;
+    auto lds_floats = [&](int nw) {
+        size_t merge = (size_t)nw * 64 * ((want_grad ? DP : 0) + 2) + (want_grad ? 64 * (size_t)(D | 1) : 0);
+        size_t stage = 64 * (size_t)(D | 1);
+        return (lds_feed ? (size_t)nw * PK::STRIDE : 0) + (merge > stage ? merge : stage);
+    };
+    const int tiles = (N + 63) / 64;
+    // geometry: ky chunks of components over blockIdx.y, nw waves per workgroup; aim at >= ~6 waves per SIMD overall
+    // Measured on MI355X at the north-star shape (tools/tune_mixture_eval.py, profiles/r01_tune_mixture_eval.log):
+    // scalar-load feed, 16 waves per tile and no K split is the fastest geometry (19.9 / 35.0 us without / with the
+    // gradient); splitting K over blockIdx.y only pays for very few sample tiles.
+    int ky = 1, nw = K < 16 ? K : 16;
+    if (env_ky > 0) ky = env_ky < K ? env_ky : K;
+    else {
+        while (ky < 8 && (long)tiles * nw * ky < ctx->num_cus && K / (ky + 1) >= 16) ++ky;
     }
+    const int kchunk = (K + ky - 1) / ky;
+    ky = (K + kchunk - 1) / kchunk;
+    if (nw > kchunk) nw = kchunk;
+    if (env_nw > 0) nw = env_nw < kchunk ? env_nw : kchunk;
+    while (nw > 1 && lds_floats(nw) * 4 > 96 * 1024) --nw;
+    size_t shmem = lds_floats(nw) * 4;
+    float* lp_k = lp;
+    float* grad_k = grad;
+    if (ky > 1 && want_merge) {
+        size_t need = ((size_t)ky * N + (want_grad ? (size_t)ky * N * D : 0)) * sizeof(float);
+        int rc = gmmvi_ws_reserve(ctx, need);
+        if (rc != GMMVI_OK) return rc;
+        lp_k = (float*)ctx->ws;
+        grad_k = want_grad ? lp_k + (size_t)ky * N : nullptr;
+    }
+    dim3 grid(tiles, ky), block(nw * 64);
+    {
+        GMMVI_PROF(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval");
+#define GMMVI_LAUNCH_ME(FAM, G, F)                                                                                  \
+    do {                                                                                                            \
+        if (shmem > 64 * 1024)                                                                                      \
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_kernel<DP, FAM, G, F>,               \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
+        hipLaunchKernelGGL((mixture_eval_kernel<DP, FAM, G, F>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
+                           logw, X, N, ld, lp_k, grad_k);                                                           \
+    } while (0)
+#define GMMVI_LAUNCH_ME2(FAM, G) do { if (lds_feed) GMMVI_LAUNCH_ME(FAM, G, true); else GMMVI_LAUNCH_ME(FAM, G, false); } while (0)
+        if (family == GMMVI_GAUSS) {
+            if (want_grad) GMMVI_LAUNCH_ME2(GMMVI_GAUSS, true); else GMMVI_LAUNCH_ME2(GMMVI_GAUSS, false);
+        } else {
+            if (want_grad) GMMVI_LAUNCH_ME2(GMMVI_STUDENT_T, true); else GMMVI_LAUNCH_ME2(GMMVI_STUDENT_T, false);
+        }
+#undef GMMVI_LAUNCH_ME2
 #undef GMMVI_LAUNCH_ME
+    }
     GMMVI_LAUNCH_CHECK(ctx);
+    if (ky > 1 && want_merge) {
+        GMMVI_PROF(ctx, "mixture_combine");
+        int rc = gmmvi_combine_partials(ctx, ky, N, D, lp_k, grad_k, lp, grad);
+        if (rc != GMMVI_OK) return rc;
+    }
     return GMMVI_OK;
 }
 

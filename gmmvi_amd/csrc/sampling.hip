@@ -5,39 +5,63 @@
 #include "common.h"
 #include "philox.h"
 
-__global__ void sample_components_kernel(int K, int D, const float* __restrict__ means, const float* __restrict__ chols,
-                                         const int32_t* __restrict__ offsets, int N, uint64_t seed,
-                                         uint64_t first_index, uint32_t stream_id, const float* __restrict__ eps_in,
-                                         float* __restrict__ X, int32_t* __restrict__ mapping) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    // component of sample n: largest k with offsets[k] <= n (binary search over the K+1 prefix sums)
-    int lo = 0, hi = K;
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (offsets[mid] <= n) lo = mid; else hi = mid;
-    }
-    const int k = lo;
-    if (mapping) mapping[n] = k;
-    float eps[GMMVI_MAX_DIM];
+// grid = (component, 256-sample chunk of that component); (mu_k, L_k) staged in LDS and read as broadcasts, eps and x in
+// registers (DP = padded dimension, loops unrolled), the output tile leaves through LDS with coalesced stores.
+template <int DP>
+__global__ __launch_bounds__(256) void sample_components_kernel(int K, int D, const float* __restrict__ means,
+                                                                const float* __restrict__ chols,
+                                                                const int32_t* __restrict__ offsets, int N, uint64_t seed,
+                                                                uint64_t first_index, uint32_t stream_id,
+                                                                const float* __restrict__ eps_in, float* __restrict__ X,
+                                                                int32_t* __restrict__ mapping) {
+    extern __shared__ float sm[];
+    const int k = blockIdx.x;
+    const int begin = offsets[k], end = offsets[k + 1];
+    const int base = begin + blockIdx.y * 256;
+    if (base >= end) return;
+    const int n_here = min(256, end - base);
+    float* Ls = sm;                      // [D][D]
+    float* mus = sm + D * D;             // [D]
+    float* tile = mus + D;               // [256][ldx]
+    const int ldx = D | 1;
+    const int t = threadIdx.x;
+    for (int e = t; e < D * D; e += 256) Ls[e] = chols[(size_t)k * D * D + e];
+    for (int e = t; e < D; e += 256) mus[e] = means[(size_t)k * D + e];
     if (eps_in) {
-        for (int i = 0; i < D; ++i) eps[i] = eps_in[(size_t)n * D + i];
+        for (int e = t; e < n_here * D; e += 256) tile[(e / D) * ldx + (e % D)] = eps_in[(size_t)base * D + e];
+    }
+    __syncthreads();
+    const bool valid = t < n_here;
+    float eps[DP];
+    if (eps_in) {
+#pragma unroll
+        for (int i = 0; i < DP; ++i) eps[i] = (valid && i < D) ? tile[t * ldx + i] : 0.f;
     } else {
-        const uint64_t idx = first_index + (uint64_t)n;
-        for (int b = 0; b * 4 < D; ++b) {
+        const uint64_t idx = first_index + (uint64_t)(base + t);
+#pragma unroll
+        for (int b = 0; b < (DP + 3) / 4; ++b) {
             float nn[4];
             philox_normal4(seed, idx, (uint32_t)b, stream_id, nn);
+#pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (4 * b + j < D) eps[4 * b + j] = nn[j];
+                if (4 * b + j < DP) eps[4 * b + j] = nn[j];
         }
     }
-    const float* L = chols + (size_t)k * D * D;
-    const float* mu = means + (size_t)k * D;
-    for (int i = 0; i < D; ++i) {
-        float v = mu[i];
-        for (int j = 0; j <= i; ++j) v = fmaf(L[i * D + j], eps[j], v);
-        X[(size_t)n * D + i] = v;
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+            if (i < D) {
+                float v = mus[i];
+#pragma unroll
+                for (int j = 0; j <= i; ++j) v = fmaf(Ls[i * D + j], eps[j], v);
+                tile[t * ldx + i] = v;
+            }
+        }
+        if (mapping) mapping[base + t] = k;
     }
+    __syncthreads();
+    for (int e = t; e < n_here * D; e += 256) X[(size_t)base * D + e] = tile[(e / D) * ldx + (e % D)];
 }
 
 __global__ void philox_normals_kernel(uint64_t seed, uint64_t first_index, uint32_t stream_id, int N, int D,
@@ -71,9 +95,14 @@ int gmmvi_sample_components(gmmvi_ctx* ctx, int K, int D, const float* means_dev
     if (N == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && offsets_dev && X_out_dev);
     GMMVI_PROF(ctx, "sample_components");
-    hipLaunchKernelGGL(sample_components_kernel, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, K, D, means_dev,
-                       chols_dev, offsets_dev, N, seed, first_index, (uint32_t)stream_id, eps_dev, X_out_dev,
-                       mapping_out_dev);
+    // the per-component counts live on the device: cover the worst case (all N samples in one component); empty
+    // chunks exit immediately
+    const int chunks = (N + 255) / 256;
+    const size_t shmem = ((size_t)D * D + D + 256 * (size_t)(D | 1)) * sizeof(float);
+    const int dp = gmmvi_padded_dim(D);
+    GMMVI_DISPATCH_DP(dp, hipLaunchKernelGGL((sample_components_kernel<DP>), dim3(K, chunks), dim3(256), shmem,
+                                             ctx->stream, K, D, means_dev, chols_dev, offsets_dev, N, seed, first_index,
+                                             (uint32_t)stream_id, eps_dev, X_out_dev, mapping_out_dev));
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }

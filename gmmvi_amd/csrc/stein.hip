@@ -1,16 +1,21 @@
 // Importance-weighted Stein estimate of the per-component expected gradient / Hessian
 // (gmmvi_modules/ng_estimator.py:204-263, :171-188 self-normalised, :154-169 plain importance weights).
 //
-// For component k:  A_k = sum_n e_kn [g_n; 1] [y_kn; 1]^T,  e_kn = exp(ld[k,n] - bg[n] - m),  g_n = grad log p~ - grad log q,
+// For component k:  A_k = sum_n [g_n; 1] (e_kn [y_kn; 1])^T,  e_kn = exp(ld[k,n] - bg[n] - m),  g_n = grad log p~ - grad log q,
 // y_kn = Sigma_k^-1 (x_n - mu_k).  The (D+1)x(D+1) matrix A_k carries sum e g y^T, sum e g (last column) and sum e
 // (corner), so one contraction over the samples yields the Hessian, the gradient and the normaliser.
 //
-// Mapping (DESIGN.md "stein"): grid = (sample ranges, components), 4 waves per workgroup.  Each wave takes 64
-// samples per step: one lane per sample computes y by the register-resident forward/backward substitution
-// (component block through scalar loads), writes e*[g;1] and [y;1] rows to its private LDS tile (row stride
-// 32*NB+1: conflict-free), then contracts the 64 samples with v_mfma_f32_32x32x2_f32 (A = G^T, B = Y read straight
-// from the tile).  A running wave-uniform maximum keeps e <= 1 (online rescaling of the accumulators).  Waves are
-// merged through LDS, ranges through a slab summed in fixed order by stein_finalize (bitwise reproducible).
+// Mapping (DESIGN.md "stein"): grid = (256-sample tiles, component chunks); 4 waves per workgroup, 64 samples each.
+//   * the x and g tiles of the workgroup are fetched ONCE with fully coalesced loads and staged through LDS (the
+//     per-lane rows of a row-major [N, D] array are 4*D bytes apart: loading them lane-by-lane costs one cache line per
+//     lane per element and was the dominant stall of the first version of this kernel);
+//   * each lane keeps its sample x in VGPRs and each wave keeps the [g;1] MFMA A-fragments of its 64 samples in VGPRs;
+//     both are reused for every component of the chunk;
+//   * per component: y by the register-resident forward/backward substitution (component block through scalar
+//     loads), e*[y;1] rows written to the wave's LDS tile (row stride 32*NB+1: conflict-free), contraction of the 64
+//     samples with v_mfma_f32_32x32x2_f32, then the four waves are merged through LDS (own maximum per wave, fixed
+//     summation order) and the (component, tile) partial goes to a slab.
+// stein_finalize sums the slab in fixed order (bitwise reproducible), normalises, symmetrises and negates.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -45,105 +50,110 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+__global__ void sub_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) out[i] = a[i] - b[i];
+}
+
 template <int DP, int NB>
-__global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, const float* __restrict__ packed,
-                                                            const float* __restrict__ X, int N, int range_size,
-                                                            const float* __restrict__ ld, const float* __restrict__ qgrad,
-                                                            const float* __restrict__ bg, const float* __restrict__ tgrad,
+__global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, int chunk, const float* __restrict__ packed,
+                                                            const float* __restrict__ X, const float* __restrict__ G, int N,
+                                                            const float* __restrict__ ld, const float* __restrict__ bg,
                                                             const int32_t* __restrict__ mapping, int map_offset, int flags,
                                                             float* __restrict__ part, float* __restrict__ part_m) {
     using PK = Pack<DP>;
     constexpr int W = 32 * NB;         // padded width of [g;1] and [y;1]
-    constexpr int LDW = W + 1;         // LDS row stride
+    constexpr int LDW = W + 1;         // LDS row stride of the MFMA operand tiles
     extern __shared__ float sm[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int k = blockIdx.y;
-    const int r = blockIdx.x;
+    __shared__ float sm_m[4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int n_tiles = gridDim.x;
     const int D1 = D + 1;
-    float* Gt = sm + (size_t)wave * (2 * 64 * LDW);
-    float* Yt = Gt + 64 * LDW;
-    const float* __restrict__ P = packed + (size_t)k * PK::STRIDE;
+    const int n0 = tile * 256;
+    const int n_here = min(256, N - n0);
+    float* Gs = sm;                                   // [256][LDW]  rows [g;1;0...]
+    float* Ys = sm + 256 * LDW;                       // 4 x [64][LDW] rows e*[y;1;0...]; also staging / merge scratch
+    float* Yw = Ys + wave * 64 * LDW;
     const bool own_only = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
 
-    // zero the padded columns once (columns 0..D are rewritten every step)
-    for (int c = D1; c < W; ++c) { Gt[lane * LDW + c] = 0.f; Yt[lane * LDW + c] = 0.f; }
-
-    f32x16 acc[NB][NB];
+    // ---- stage the x tile (coalesced) through Ys, keep this lane's row in registers -------------------------------
+    const int ldx = D | 1;                            // odd stride: conflict-free row reads
+    for (int e = tid; e < n_here * D; e += 256) Ys[(e / D) * ldx + (e % D)] = X[(size_t)n0 * D + e];
+    __syncthreads();
+    const int row = wave * 64 + lane;
+    const bool valid = row < n_here;
+    const int n = n0 + row;
+    float x[DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) x[i] = (valid && i < D) ? Ys[row * ldx + i] : 0.f;
+    __syncthreads();
+    // ---- stage the g tile (coalesced) as [g;1] rows, zero padding; pre-zero the padded columns of the Y tiles ----------
+    for (int e = tid; e < 256 * W; e += 256) {
+        const int r = e / W, c = e % W;
+        float v = 0.f;
+        if (r < n_here) v = (c < D) ? G[(size_t)(n0 + r) * D + c] : (c == D ? 1.f : 0.f);
+        Gs[r * LDW + c] = v;
+    }
+    for (int c = D1; c < W; ++c) Yw[lane * LDW + c] = 0.f;
+    __syncthreads();
+    // A fragments of this wave's 64 samples: lane (col = l & 31, half = l >> 5), step s -> Gs[2s + half][col]
+    const int col = lane & 31, half = lane >> 5;
+    float af[NB][32];
 #pragma unroll
     for (int a = 0; a < NB; ++a)
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int t = 0; t < 16; ++t) acc[a][b][t] = 0.f;
-    float m_run = -3.0e38f;
+        for (int s = 0; s < 32; ++s) af[a][s] = Gs[(wave * 64 + 2 * s + half) * LDW + 32 * a + col];
 
-    const int n_begin = r * range_size;
-    const int n_end = min(N, n_begin + range_size);
-    for (int base = n_begin + wave * 64; base < n_end; base += 256) {
-        const int n = base + lane;
-        const bool valid = n < n_end;
+    const int k_begin = blockIdx.y * chunk;
+    const int k_end = min(K, k_begin + chunk);
+    for (int k = k_begin; k < k_end; ++k) {
+        const float* __restrict__ P = packed + (size_t)k * PK::STRIDE;
         float a_log = -3.0e38f;
         if (valid) {
             if (own_only) a_log = (mapping[n] + map_offset == k) ? 0.f : -3.0e38f;
             else a_log = ld[(size_t)k * N + n] - bg[n];
         }
-        const float m_new = fmaxf(m_run, wave_max(a_log));
-        const float rescale = __expf(m_run - m_new);
-        m_run = m_new;
-        const float e = (valid && a_log > -1.0e38f) ? __expf(a_log - m_new) : 0.f;
-#pragma unroll
-        for (int a = 0; a < NB; ++a)
-#pragma unroll
-            for (int b = 0; b < NB; ++b) acc[a][b] *= rescale;
+        const float m_w = wave_max(a_log);
+        const float e = (valid && a_log > -1.0e38f) ? __expf(a_log - m_w) : 0.f;
 
-        float x[DP], z[DP], y[DP];
-#pragma unroll
-        for (int i = 0; i < DP; ++i) x[i] = (valid && i < D) ? X[(size_t)n * D + i] : 0.f;
+        float z[DP], y[DP];
         forward_subst_s<DP>(P, x, z);
         backward_subst_s<DP>(P, z, y);
 #pragma unroll
-        for (int i = 0; i < DP; ++i) {
-            if (i < D) {
-                const float g = valid ? (tgrad[(size_t)n * D + i] - qgrad[(size_t)n * D + i]) : 0.f;
-                Gt[lane * LDW + i] = e * g;
-                Yt[lane * LDW + i] = valid ? y[i] : 0.f;
-            }
-        }
-        Gt[lane * LDW + D] = e;
-        Yt[lane * LDW + D] = 1.f;
+        for (int i = 0; i < DP; ++i)
+            if (i < D) Yw[lane * LDW + i] = e * y[i];
+        Yw[lane * LDW + D] = e;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
 
-        const int col = lane & 31, half = lane >> 5;
-#pragma unroll 8
-        for (int s = 0; s < 32; ++s) {
-            const int row = 2 * s + half;
-            float af[NB], bf[NB];
+        f32x16 acc[NB][NB];
 #pragma unroll
-            for (int a = 0; a < NB; ++a) {
-                af[a] = Gt[row * LDW + 32 * a + col];
-                bf[a] = Yt[row * LDW + 32 * a + col];
-            }
+        for (int a = 0; a < NB; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc[a][b][t] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            float bf[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bf[b] = Yw[(2 * s + half) * LDW + 32 * b + col];
 #pragma unroll
             for (int a = 0; a < NB; ++a)
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[b], acc[a][b], 0, 0, 0);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-    }
 
-    // ---- merge the 4 waves (each wave's scratch lives inside its own tile region) ----
-    __shared__ float sm_m[4];
-    if (lane == 0) sm_m[wave] = m_run;
-    __syncthreads();
-    const float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
-    const float f = __expf(m_run - M);
-    float* red = Gt;                                   // [W][W] floats, W*W <= 2*64*LDW
-    {
-        const int col = lane & 31, half = lane >> 5;
+        // ---- merge the four waves: common maximum, fixed order ------------------------------------------------------
+        if (lane == 0) sm_m[wave] = m_w;
+        __syncthreads();                                  // also: every wave is done reading its Y tile
+        const float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+        const float f = __expf(m_w - M);
 #pragma unroll
         for (int a = 0; a < NB; ++a)
 #pragma unroll
@@ -152,37 +162,40 @@ __global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, const 
                 for (int t = 0; t < 16; ++t) {
                     const int i = 32 * a + (t & 3) + 8 * (t >> 2) + 4 * half;
                     const int j = 32 * b + col;
-                    red[i * W + j] = acc[a][b][t] * f;
+                    Yw[i * W + j] = acc[a][b][t] * f;      // W*W <= 64*LDW floats
                 }
+        __syncthreads();
+        float* out = part + ((size_t)k * n_tiles + tile) * (size_t)(D1 * D1);
+        for (int el = tid; el < D1 * D1; el += 256) {
+            const int i = el / D1, j = el % D1;
+            out[el] = (Ys[i * W + j] + Ys[64 * LDW + i * W + j]) + (Ys[2 * 64 * LDW + i * W + j] + Ys[3 * 64 * LDW + i * W + j]);
+        }
+        if (tid == 0) part_m[(size_t)k * n_tiles + tile] = M;
+        __syncthreads();
+        // the merge overwrote the padded columns of the Y tiles: restore the zeros for the next component
+        for (int c = D1; c < W; ++c) Yw[lane * LDW + c] = 0.f;
     }
-    __syncthreads();
-    float* out = part + ((size_t)k * gridDim.x + r) * (size_t)(D1 * D1);
-    for (int e = threadIdx.x; e < D1 * D1; e += 256) {
-        const int i = e / D1, j = e % D1;
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) v += sm[(size_t)w * (2 * 64 * LDW) + i * W + j];
-        out[e] = v;
-    }
-    if (threadIdx.x == 0) part_m[(size_t)k * gridDim.x + r] = M;
 }
 
 __global__ __launch_bounds__(256) void stein_finalize_kernel(int D, int R, int N, int flags, const float* __restrict__ part,
                                                              const float* __restrict__ part_m, float* __restrict__ H_neg,
                                                              float* __restrict__ g_neg) {
-    extern __shared__ float A[];       // (D+1)^2
+    extern __shared__ float A[];       // (D+1)^2, then R scale factors
     const int k = blockIdx.x;
     const int D1 = D + 1;
+    float* scale_r = A + D1 * D1;
     float M = -3.0e38f;
     for (int r = 0; r < R; ++r) M = fmaxf(M, part_m[(size_t)k * R + r]);
+    for (int r = threadIdx.x; r < R; r += 256) scale_r[r] = __expf(part_m[(size_t)k * R + r] - M);
+    __syncthreads();
     for (int e = threadIdx.x; e < D1 * D1; e += 256) {
         float v = 0.f;
-        for (int r = 0; r < R; ++r)
-            v = fmaf(part[((size_t)k * R + r) * (size_t)(D1 * D1) + e], __expf(part_m[(size_t)k * R + r] - M), v);
+        for (int r = 0; r < R; ++r) v = fmaf(part[((size_t)k * R + r) * (size_t)(D1 * D1) + e], scale_r[r], v);
         A[e] = v;
     }
     __syncthreads();
     const bool snis = (flags & GMMVI_SELF_NORMALIZED) != 0;
+    // A[i][j] = sum e g_i y_j, A[i][D] = sum e g_i, A[D][D] = sum e.
     // plain importance weights: 1/N * sum exp(ld - bg) v   (ng_estimator.py:146-152), Hessian not symmetrised
     const float scale = snis ? 1.f / A[D * D1 + D] : __expf(M) / (float)N;
     for (int e = threadIdx.x; e < D * D; e += 256) {
@@ -199,21 +212,28 @@ static int launch_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
                         int flags, float* H_neg, float* g_neg) {
     constexpr int LDW = 32 * NB + 1;
     const int D1 = D + 1;
-    // sample ranges: aim at ~8 workgroups per CU, at least 256 samples (one step of 4 waves) per range
-    long target = (8L * ctx->num_cus + K - 1) / K;
-    if (target < 1) target = 1;
-    long steps_total = ((long)N + 255) / 256;
-    long steps_per_range = (steps_total + target - 1) / target;
-    if (steps_per_range < 1) steps_per_range = 1;
-    const int range_size = (int)(steps_per_range * 256);
-    const int R = (int)(((long)N + range_size - 1) / range_size);
-    size_t part_floats = (size_t)K * R * D1 * D1;
-    size_t need = (part_floats + (size_t)K * R) * sizeof(float);
+    const int n_tiles = (N + 255) / 256;
+    // components per workgroup: amortise the tile staging, keep >= ~4 workgroups per CU in flight
+    int chunk = (int)(((long)n_tiles * K + 4L * ctx->num_cus - 1) / (4L * ctx->num_cus));
+    if (chunk < 1) chunk = 1;
+    if (chunk > 16) chunk = 16;
+    const int n_chunks = (K + chunk - 1) / chunk;
+    const size_t part_floats = (size_t)K * n_tiles * D1 * D1;
+    const size_t g_floats = (size_t)N * D;
+    const size_t need = (part_floats + (size_t)K * n_tiles + g_floats) * sizeof(float);
     int rc = gmmvi_ws_reserve(ctx, need);
     if (rc != GMMVI_OK) return rc;
     float* part = (float*)ctx->ws;
     float* part_m = part + part_floats;
-    size_t shmem = (size_t)4 * 2 * 64 * LDW * sizeof(float);
+    float* g = part_m + (size_t)K * n_tiles;
+    {
+        GMMVI_PROF(ctx, "stein_gdiff");
+        int blocks = (int)((g_floats + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(sub_kernel, dim3(blocks), dim3(256), 0, ctx->stream, tgrad, qgrad, g, g_floats);
+    }
+    GMMVI_LAUNCH_CHECK(ctx);
+    const size_t shmem = (size_t)(256 + 4 * 64) * LDW * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && shmem > 64 * 1024) {
         GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_partial_kernel<DP, NB>,
@@ -221,14 +241,14 @@ static int launch_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
         attr_set = true;
     }
     {
-    GMMVI_PROF(ctx, "stein_partial");
-    hipLaunchKernelGGL((stein_partial_kernel<DP, NB>), dim3(R, K), dim3(256), shmem, ctx->stream, K, D, packed, X, N,
-                       range_size, ld, qgrad, bg, tgrad, mapping, map_offset, flags, part, part_m);
+        GMMVI_PROF(ctx, "stein_partial");
+        hipLaunchKernelGGL((stein_partial_kernel<DP, NB>), dim3(n_tiles, n_chunks), dim3(256), shmem, ctx->stream, K, D,
+                           chunk, packed, X, g, N, ld, bg, mapping, map_offset, flags, part, part_m);
     }
     GMMVI_LAUNCH_CHECK(ctx);
     GMMVI_PROF(ctx, "stein_finalize");
-    hipLaunchKernelGGL(stein_finalize_kernel, dim3(K), dim3(256), (size_t)D1 * D1 * sizeof(float), ctx->stream, D, R,
-                       N, flags, part, part_m, H_neg, g_neg);
+    hipLaunchKernelGGL(stein_finalize_kernel, dim3(K), dim3(256), ((size_t)D1 * D1 + n_tiles) * sizeof(float), ctx->stream,
+                       D, n_tiles, N, flags, part, part_m, H_neg, g_neg);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }

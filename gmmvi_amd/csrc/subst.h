@@ -1,0 +1,65 @@
+// Register-resident triangular substitutions against one packed component block (layout: common.h Pack<DP>).
+// The block is addressed through a float4-typed pointer so that, once the loops are unrolled, every parameter fetch is
+// a 16-byte access (ds_read_b128 broadcast from a wave-private LDS copy, or s_load_dwordx4+ from global memory); the
+// compiler merges the repeated fetches of one float4.
+#pragma once
+#include "common.h"
+
+struct PackRef {
+    const float4* p;
+    __device__ __forceinline__ float operator[](int idx) const {
+        const float4 v = p[idx >> 2];
+        const int c = idx & 3;
+        return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
+    }
+};
+
+// z = L^-1 (x - mu), q = |z|^2
+template <int DP>
+__device__ __forceinline__ void forward_subst(const PackRef P, const float (&x)[DP], float (&z)[DP], float& q) {
+    using PK = Pack<DP>;
+    q = 0.f;
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+        float t = x[i] - P[PK::MU + i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) t = fmaf(-P[PK::LROW + PK::rowofs(i) + j], z[j], t);
+        z[i] = t * P[PK::RD + i];
+        q = fmaf(z[i], z[i], q);
+    }
+}
+
+// y = L^-T z  (Sigma^-1 (x - mu) when z = L^-1 (x - mu))
+template <int DP>
+__device__ __forceinline__ void backward_subst(const PackRef P, const float (&z)[DP], float (&y)[DP]) {
+    using PK = Pack<DP>;
+#pragma unroll
+    for (int i = DP - 1; i >= 0; --i) {
+        float t = z[i];
+#pragma unroll
+        for (int j = i + 1; j < DP; ++j) t = fmaf(-P[PK::LCOL + PK::colofs(i) + (j - i - 1)], y[j], t);
+        y[i] = t * P[PK::RD + i];
+    }
+}
+
+// Coalesced copy of one component block into a wave-private LDS slot, one component ahead of its use.
+template <int DP>
+struct PackStager {
+    using PK = Pack<DP>;
+    static constexpr int NPF = (PK::STRIDE + 63) / 64;
+    float pf[NPF];
+    __device__ __forceinline__ void prefetch(const float* __restrict__ packed, int k, int lane) {
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int idx = lane + 64 * j;
+            pf[j] = (idx < PK::STRIDE) ? packed[(size_t)k * PK::STRIDE + idx] : 0.f;
+        }
+    }
+    __device__ __forceinline__ void commit(float* slot, int lane) const {
+#pragma unroll
+        for (int j = 0; j < NPF; ++j) {
+            const int idx = lane + 64 * j;
+            if (idx < PK::STRIDE) slot[idx] = pf[j];
+        }
+    }
+};

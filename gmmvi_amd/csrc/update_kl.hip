@@ -43,12 +43,14 @@ __device__ void carve(Ws& s, float* sm, int D) {
 size_t lds_bytes(int D) { return ((size_t)3 * D * (D + 1) + 9 * D + (size_t)2 * D * 64) * sizeof(float); }
 
 // KL(eta) from the tridiagonal form; every lane may evaluate a different eta (scratch column = lane).
-__device__ float kl_tridiag(const Ws& s, float eta) {
-    const int D = s.D, lane = threadIdx.x;
+template <int DC>
+__device__ __forceinline__ float kl_tridiag(const Ws& s, float eta) {
+    const int D = DC > 0 ? DC : s.D, lane = threadIdx.x;
     const float inv = 1.f / eta;
     float* dcol = s.pr + lane;                 // d_i at [i][lane], c_i at [D + i][lane]
     float dprev = 1.f, cprev = 0.f, logdet = 0.f;
     bool ok = true;
+#pragma unroll
     for (int i = 0; i < D; ++i) {
         const float a = fmaf(s.td[i], inv, 1.f);
         float d = a, c = s.wt[i];
@@ -65,6 +67,7 @@ __device__ float kl_tridiag(const Ws& s, float eta) {
         dprev = d; cprev = c;
     }
     float dnext = 1.f, ynext = 0.f, tr = 0.f, yy = 0.f;
+#pragma unroll
     for (int i = D - 1; i >= 0; --i) {
         const float a = fmaf(s.td[i], inv, 1.f);
         const float d = dcol[i * 64], c = dcol[(D + i) * 64];
@@ -83,16 +86,19 @@ __device__ float kl_tridiag(const Ws& s, float eta) {
     return kl;
 }
 
-__global__ __launch_bounds__(64) void update_kl_fast_kernel(int D, float* __restrict__ means, float* __restrict__ chols,
+// DC > 0: dimension known at compile time (inner loops unrolled, LDS reads issued in batches); DC == 0: generic.
+template <int DC>
+__global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __restrict__ means, float* __restrict__ chols,
                                                             const float* __restrict__ H_neg, const float* __restrict__ g_neg,
                                                             const float* __restrict__ stepsizes, float temperature,
                                                             float l2_init, float* __restrict__ last_eta, float* __restrict__ l2,
                                                             float* __restrict__ num_updates, int32_t* __restrict__ success_out,
                                                             float* __restrict__ kl_out, int32_t* __restrict__ nprobes_out) {
     extern __shared__ float sm[];
+    const int D = DC > 0 ? DC : Drt;
     Ws s;
     carve(s, sm, D);
-    const int k = blockIdx.x, t = threadIdx.x, ld = s.ld;
+    const int k = blockIdx.x, t = threadIdx.x, ld = D + 1;
     float* Lg = chols + (size_t)k * D * D;
     float* mug = means + (size_t)k * D;
     const float* Rg = H_neg + (size_t)k * D * D;
@@ -115,7 +121,8 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int D, float* __rest
     if (t < D) {
         for (int j = 0; j < D; ++j) {
             float a = 0.f;
-            for (int c = j; c < D; ++c) a = fmaf(s.M[t * ld + c], s.L[c * ld + j], a);
+#pragma unroll
+            for (int c = 0; c < D; ++c) a = fmaf(s.M[t * ld + c], s.L[c * ld + j], a);     // L[c][j] = 0 for c < j
             s.Mc[t * ld + j] = a;
         }
     }
@@ -123,11 +130,13 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int D, float* __rest
     if (t < D) {
         for (int j = 0; j < D; ++j) {
             float a = 0.f;
-            for (int c = t; c < D; ++c) a = fmaf(s.L[c * ld + t], s.Mc[c * ld + j], a);
+#pragma unroll
+            for (int c = 0; c < D; ++c) a = fmaf(s.L[c * ld + t], s.Mc[c * ld + j], a);    // L[c][t] = 0 for c < t
             s.M[t * ld + j] = a;
         }
         float a = 0.f;
-        for (int c = t; c < D; ++c) a = fmaf(s.L[c * ld + t], s.y[c], a);
+#pragma unroll
+        for (int c = 0; c < D; ++c) a = fmaf(s.L[c * ld + t], s.y[c], a);
         s.w[t] = a;
         s.wt[t] = a;
     }
@@ -161,7 +170,8 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int D, float* __rest
         __syncthreads();
         float p = 0.f;
         if (act) {
-            for (int j = c + 1; j < D; ++j) p = fmaf(s.M[t * ld + j], s.v[j], p);
+#pragma unroll
+            for (int j = 0; j < D; ++j) p = fmaf(s.M[t * ld + j], s.v[j], p);              // v[j] = 0 for j <= c
             p *= beta;
         }
         const float kk = 0.5f * beta * wsum(vv * p);
@@ -170,7 +180,8 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int D, float* __rest
         const float wdot = beta * wsum(act ? vv * s.wt[t] : 0.f);
         __syncthreads();
         if (act) {
-            for (int j = c + 1; j < D; ++j) s.M[t * ld + j] -= vv * s.q[j] + qq * s.v[j];
+#pragma unroll
+            for (int j = 0; j < D; ++j) s.M[t * ld + j] -= vv * s.q[j] + qq * s.v[j];      // q[j] = v[j] = 0 for j <= c
             s.wt[t] -= wdot * vv;
         }
         if (t == 0) s.te[c] = alpha;
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int D, float* __rest
         const float neta = 0.5f * (nub + nlb);
         const float e_eta = expf(neta);
         const float ndiff = fminf(expf(nub) - e_eta, e_eta - expf(nlb));                  // :401
-        const float nkl = (t >= 1) ? kl_tridiag(s, e_eta) : 0.f;                           // :407
+        const float nkl = (t >= 1) ? kl_tridiag<DC>(s, e_eta) : 0.f;                           // :407
         int n = 1;
         for (int level = 0; level < 6 && !done && iters < 1000; ++level, ++iters) {
             const float diff = __shfl(ndiff, n), klv = __shfl(nkl, n), eta = __shfl(neta, n);
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int D, float* __rest
     float kl_val = -1.f;
     const float inv = 1.f / eta_star;
     if (success) {
-        kl_val = __shfl(kl_tridiag(s, eta_star), 0);                                       // :480-482
+        kl_val = __shfl(kl_tridiag<DC>(s, eta_star), 0);                                       // :480-482
         success = kl_val < FLT_MAX;                                                        // :488
     }
     if (success) {
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int D, float* __rest
         if (t < D) {
             for (int i = D - 1; i >= 0; --i) {
                 float a = (i == t) ? 1.f : 0.f;
-                for (int j = i + 1; j <= t; ++j) a = fmaf(-s.M[i * ld + j], s.Mc[j * ld + t], a);
+                for (int j = i + 1; j < D; ++j) a = fmaf(-s.M[i * ld + j], s.Mc[j * ld + t], a);   // Mc[j][t] = 0, j > t
                 s.Mc[i * ld + t] = (i <= t) ? a / s.M[i * ld + i] : 0.f;
             }
         }
@@ -255,13 +266,15 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int D, float* __rest
         // z = Uinv w ; y = Uinv^T z = B^-1 w
         if (t < D) {
             float a = 0.f;
-            for (int c = t; c < D; ++c) a = fmaf(s.Mc[t * ld + c], s.w[c], a);
+#pragma unroll
+            for (int c = 0; c < D; ++c) a = fmaf(s.Mc[t * ld + c], s.w[c], a);            // Uinv[t][c] = 0 for c < t
             s.z[t] = a;
         }
         __syncthreads();
         if (t < D) {
             float a = 0.f;
-            for (int c = 0; c <= t; ++c) a = fmaf(s.Mc[c * ld + t], s.z[c], a);
+#pragma unroll
+            for (int c = 0; c < D; ++c) a = fmaf(s.Mc[c * ld + t], s.z[c], a);            // Uinv[c][t] = 0 for c > t
             s.y[t] = a;
         }
         __syncthreads();
@@ -270,7 +283,8 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int D, float* __rest
         bool bad = false;
         if (t < D) {
             float a = 0.f;
-            for (int c = 0; c <= t; ++c) a = fmaf(s.L[t * ld + c], s.y[c], a);
+#pragma unroll
+            for (int c = 0; c < D; ++c) a = fmaf(s.L[t * ld + c], s.y[c], a);             // L[t][c] = 0 for c > t
             new_mu = s.mu[t] - a * inv;
             bad = !(new_mu == new_mu);
         }
@@ -278,7 +292,8 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int D, float* __rest
         if (t < D) {
             for (int j = 0; j <= t; ++j) {
                 float a = 0.f;
-                for (int c = j; c <= t; ++c) a = fmaf(s.L[t * ld + c], s.Mc[j * ld + c], a);
+#pragma unroll
+                for (int c = 0; c < D; ++c) a = fmaf(s.L[t * ld + c], s.Mc[j * ld + c], a);
                 s.M[t * ld + j] = a;
                 bad |= !(a == a);
             }
@@ -316,13 +331,24 @@ extern "C" int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* m
     GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && H_neg_dev && g_neg_dev && stepsizes_dev && last_eta_dev && l2_dev &&
                              num_received_updates_dev);
     size_t shmem = lds_bytes(D);
-    if (shmem > 64 * 1024)
-        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)update_kl_fast_kernel,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
     GMMVI_PROF(ctx, "update_kl");
-    hipLaunchKernelGGL(update_kl_fast_kernel, dim3(K), dim3(64), shmem, ctx->stream, D, means_dev, chols_dev, H_neg_dev,
-                       g_neg_dev, stepsizes_dev, temperature, l2_init, last_eta_dev, l2_dev, num_received_updates_dev,
-                       success_out_dev, kl_out_dev, n_probes_out_dev);
+#define GMMVI_UKL(DCV)                                                                                             \
+    do {                                                                                                           \
+        if (shmem > 64 * 1024)                                                                                     \
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)update_kl_fast_kernel<DCV>,                      \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));     \
+        hipLaunchKernelGGL((update_kl_fast_kernel<DCV>), dim3(K), dim3(64), shmem, ctx->stream, D, means_dev,      \
+                           chols_dev, H_neg_dev, g_neg_dev, stepsizes_dev, temperature, l2_init, last_eta_dev,     \
+                           l2_dev, num_received_updates_dev, success_out_dev, kl_out_dev, n_probes_out_dev);       \
+    } while (0)
+    switch (D) {                       // dimensions of the BASELINE configurations get unrolled instances
+        case 4: GMMVI_UKL(4); break;
+        case 10: GMMVI_UKL(10); break;
+        case 20: GMMVI_UKL(20); break;
+        case 32: GMMVI_UKL(32); break;
+        default: GMMVI_UKL(0); break;
+    }
+#undef GMMVI_UKL
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }

@@ -33,34 +33,47 @@ __device__ float block_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// One workgroup per component: E_k = sum_n softmax_n(ld[k,n] - bg[n]) * (tlp[n] - beta logq[n]).
-__global__ __launch_bounds__(256) void elr_kernel(int N, const float* __restrict__ ld, const float* __restrict__ bg,
-                                                  const float* __restrict__ tlp, const float* __restrict__ logq, float beta,
-                                                  const float* __restrict__ logw, int self_normalized,
-                                                  float* __restrict__ E_out, float* __restrict__ reward_out,
-                                                  float* __restrict__ ess_out) {
-    __shared__ float red[4];
+// One 1024-thread workgroup per component: E_k = sum_n softmax_n(ld[k,n] - bg[n]) * (tlp[n] - beta logq[n]) in a single
+// pass (per-thread running maximum with rescaling), then a fixed-order tree over the 16 waves.
+__global__ __launch_bounds__(1024) void elr_kernel(int N, const float* __restrict__ ld, const float* __restrict__ bg,
+                                                   const float* __restrict__ tlp, const float* __restrict__ logq, float beta,
+                                                   const float* __restrict__ logw, int self_normalized,
+                                                   float* __restrict__ E_out, float* __restrict__ reward_out,
+                                                   float* __restrict__ ess_out) {
+    __shared__ float red[4][16];
     const int k = blockIdx.x;
     const float* row = ld + (size_t)k * N;
-    float m = -3.0e38f;
-    for (int n = threadIdx.x; n < N; n += 256) m = fmaxf(m, row[n] - bg[n]);
-    m = block_max(m, red);
-    float s = 0.f, se = 0.f, s2 = 0.f;
-    for (int n = threadIdx.x; n < N; n += 256) {
-        const float e = __expf(row[n] - bg[n] - m);
-        s += e;
-        s2 = fmaf(e, e, s2);
-        se = fmaf(e, tlp[n] - beta * logq[n], se);
+    float m = -3.0e38f, s = 0.f, se = 0.f, s2 = 0.f;
+    for (int n = threadIdx.x; n < N; n += 1024) {
+        const float a = row[n] - bg[n];
+        const float rho = tlp[n] - beta * logq[n];
+        const float mn = fmaxf(m, a);
+        const float sc = __expf(m - mn), e = __expf(a - mn);
+        s = fmaf(s, sc, e);
+        se = fmaf(se, sc, e * rho);
+        s2 = fmaf(s2, sc * sc, e * e);
+        m = mn;
     }
-    s = block_sum(s, red);
-    se = block_sum(se, red);
-    s2 = block_sum(s2, red);
+    // wave level
+    const float mw = wmax(m);
+    const float f = __expf(m - mw);
+    s = wsum(s * f); se = wsum(se * f); s2 = wsum(s2 * f * f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = mw; red[1][wave] = s; red[2][wave] = se; red[3][wave] = s2; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        float M = -3.0e38f;
+        for (int w = 0; w < 16; ++w) M = fmaxf(M, red[0][w]);
+        float S = 0.f, SE = 0.f, S2 = 0.f;
+        for (int w = 0; w < 16; ++w) {
+            const float g = __expf(red[0][w] - M);
+            S = fmaf(red[1][w], g, S); SE = fmaf(red[2][w], g, SE); S2 = fmaf(red[3][w], g * g, S2);
+        }
         // plain importance weights (:66-71): 1/N sum_n exp(ld - bg) rho_n
-        const float E = self_normalized ? se / s : se * __expf(m) / (float)N;
+        const float E = self_normalized ? SE / S : SE * __expf(M) / (float)N;
         if (E_out) E_out[k] = E;
         if (reward_out) reward_out[k] = beta * logw[k] + E;                              // :73
-        if (ess_out) ess_out[k] = (s * s) / s2;                                          // sample_selector.py:154-158
+        if (ess_out) ess_out[k] = (S * S) / S2;                                          // sample_selector.py:154-158
     }
 }
 
@@ -188,7 +201,7 @@ int gmmvi_expected_log_ratios(gmmvi_ctx* ctx, int K, int N, const float* ld_dev,
     GMMVI_ARG_CHECK(ctx, K >= 1 && N >= 1);
     GMMVI_ARG_CHECK(ctx, ld_dev && bg_dev && tlp_dev && logq_dev && logw_dev);
     GMMVI_PROF(ctx, "expected_log_ratios");
-    hipLaunchKernelGGL(elr_kernel, dim3(K), dim3(256), 0, ctx->stream, N, ld_dev, bg_dev, tlp_dev, logq_dev, beta,
+    hipLaunchKernelGGL(elr_kernel, dim3(K), dim3(1024), 0, ctx->stream, N, ld_dev, bg_dev, tlp_dev, logq_dev, beta,
                        logw_dev, self_normalized, E_out_dev, reward_out_dev, ess_out_dev);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;

@@ -226,3 +226,19 @@ def exp_into(ctx, dst, src):
         raise ValueError("exp_into: shape/dtype mismatch")
     ctx.check(ctx.lib.gmmvi_exp_f32(ctx.handle, dst.ptr, src.ptr, src.size))
     return dst
+
+
+def copy_batch(ctx, pairs):
+    """pairs: list of (dst DeviceArray view, src DeviceArray) of equal size; one launch per group of 8."""
+    import ctypes as C
+    pairs = [(d, s) for d, s in pairs if s.size > 0]
+    for i in range(0, len(pairs), 8):
+        grp = pairs[i:i + 8]
+        for d, s in grp:
+            if d.size != s.size or d.dtype != s.dtype:
+                raise ValueError("copy_batch: size/dtype mismatch")
+        n = len(grp)
+        dst = (C.c_void_p * n)(*[d.ptr for d, _ in grp])
+        src = (C.c_void_p * n)(*[s.ptr for _, s in grp])
+        nb = (C.c_size_t * n)(*[s.nbytes for _, s in grp])
+        ctx.check(ctx.lib.gmmvi_copy_batch(ctx.handle, n, dst, src, nb))

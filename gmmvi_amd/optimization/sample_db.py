@@ -41,6 +41,14 @@ class _Growable:
             self.buf.rows(self.n, self.n + m).copy_from(arr)
         self.n += m
 
+    def append_deferred(self, arr, pairs):
+        """Reserve room and queue the copy in ``pairs`` (executed by one hip_ops.copy_batch launch)."""
+        m = arr.shape[0]
+        self.reserve(m)
+        if m:
+            pairs.append((self.buf.rows(self.n, self.n + m), arr))
+        self.n += m
+
     def assign(self, arr):
         self.buf = arr
         self.n = arr.shape[0]
@@ -198,8 +206,11 @@ class SampleDB:
                 dst = self._mapping_dev.buf.rows(self._mapping_dev.n, self._mapping_dev.n + n_new)
                 ctx.check(ctx.lib.gmmvi_add_scalar_i32(ctx.handle, dst.ptr, mapping.ptr, int(offset), n_new))
             self._mapping_dev.n += n_new
-            self._means.append(means); self._chols.append(chols); self._packed.append(packed)
-            self._samples.append(samples); self._target_lnpdfs.append(tl); self._target_grads.append(tg)
+            pairs = []
+            for grow, arr in ((self._means, means), (self._chols, chols), (self._packed, packed),
+                              (self._samples, samples), (self._target_lnpdfs, tl), (self._target_grads, tg)):
+                grow.append_deferred(arr, pairs)
+            hip_ops.copy_batch(ctx, pairs)
         else:                                                                                  # :125-135
             self._segments = [(0, 0, np.asarray(counts, np.int64))] if counts is not None else []
             self._mapping_host.assign(mapping_host)

@@ -68,6 +68,9 @@ int gmmvi_fill_f32(gmmvi_ctx* ctx, float* dst_dev, float value, size_t count);
  * get_random_sample / background-component gather (optimization/sample_db.py:63-79,137-152,222-224 tf.gather). */
 int gmmvi_gather_rows(gmmvi_ctx* ctx, const void* src_dev, const int32_t* idx_dev, int n_rows, int row_words,
                       void* dst_dev);
+/* Up to 8 device-to-device copies in ONE launch (the per-iteration SampleDB append of samples, target values,
+ * gradients and component snapshots, optimization/sample_db.py:115-124; sizes in bytes, multiples of 4). */
+int gmmvi_copy_batch(gmmvi_ctx* ctx, int n, void* const* dst_dev, const void* const* src_dev, const size_t* nbytes);
 /* dst[i] = src[i] + value: the mapping offset of SampleDB.add_samples (optimization/sample_db.py:115). */
 int gmmvi_add_scalar_i32(gmmvi_ctx* ctx, int32_t* dst_dev, const int32_t* src_dev, int32_t value, size_t count);
 /* dst[i] = exp(src[i])  (GMM.weights, models/gmm.py:171; weight history, models/gmm_wrapper.py:182). */
