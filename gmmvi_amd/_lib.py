@@ -56,7 +56,7 @@ _PROTOS = {
     "gmmvi_philox_normals": (_i, [_p, _u64, _u64, _i, _i, _i, _p]),
     "gmmvi_philox_uniforms": (_i, [_p, _u64, _u64, _i, _i, _p]),
     "gmmvi_stein": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
-    "gmmvi_update_components_kl": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "gmmvi_update_components_kl": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "gmmvi_update_components_kl_reference": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
     "gmmvi_update_components_direct": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p]),
     "gmmvi_update_components_iblr": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p]),

@@ -50,15 +50,10 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__global__ void sub_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) out[i] = a[i] - b[i];
-}
-
 template <int DP, int NB>
 __global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, int chunk, const float* __restrict__ packed,
-                                                            const float* __restrict__ X, const float* __restrict__ G, int N,
+                                                            const float* __restrict__ X, const float* __restrict__ TG,
+                                                            const float* __restrict__ QG, int N,
                                                             const float* __restrict__ ld, const float* __restrict__ bg,
                                                             const int32_t* __restrict__ mapping, int map_offset, int flags,
                                                             float* __restrict__ part, float* __restrict__ part_m) {
@@ -95,7 +90,10 @@ __global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, int ch
     for (int e = tid; e < 256 * W; e += 256) {
         const int r = e / W, c = e % W;
         float v = 0.f;
-        if (r < n_here) v = (c < D) ? G[(size_t)(n0 + r) * D + c] : (c == D ? 1.f : 0.f);
+        if (r < n_here) {
+            const size_t gi = (size_t)(n0 + r) * D + c;
+            v = (c < D) ? TG[gi] - QG[gi] : (c == D ? 1.f : 0.f);       // g = grad log p~ - grad log q (:248)
+        }
         Gs[r * LDW + c] = v;
     }
     for (int c = D1; c < W; ++c) Yw[lane * LDW + c] = 0.f;
@@ -185,13 +183,22 @@ __global__ __launch_bounds__(256) void stein_finalize_kernel(int D, int R, int N
     const int D1 = D + 1;
     float* scale_r = A + D1 * D1;
     float M = -3.0e38f;
-    for (int r = 0; r < R; ++r) M = fmaxf(M, part_m[(size_t)k * R + r]);
+    for (int r = threadIdx.x & 63; r < R; r += 64) M = fmaxf(M, part_m[(size_t)k * R + r]);
+    M = wave_max(M);
     for (int r = threadIdx.x; r < R; r += 256) scale_r[r] = __expf(part_m[(size_t)k * R + r] - M);
     __syncthreads();
+    const float* pk = part + (size_t)k * R * (size_t)(D1 * D1);
     for (int e = threadIdx.x; e < D1 * D1; e += 256) {
-        float v = 0.f;
-        for (int r = 0; r < R; ++r) v = fmaf(part[((size_t)k * R + r) * (size_t)(D1 * D1) + e], scale_r[r], v);
-        A[e] = v;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;                    // four chains in flight, fixed final order
+        int r = 0;
+        for (; r + 3 < R; r += 4) {
+            v0 = fmaf(pk[(size_t)(r + 0) * (D1 * D1) + e], scale_r[r + 0], v0);
+            v1 = fmaf(pk[(size_t)(r + 1) * (D1 * D1) + e], scale_r[r + 1], v1);
+            v2 = fmaf(pk[(size_t)(r + 2) * (D1 * D1) + e], scale_r[r + 2], v2);
+            v3 = fmaf(pk[(size_t)(r + 3) * (D1 * D1) + e], scale_r[r + 3], v3);
+        }
+        for (; r < R; ++r) v0 = fmaf(pk[(size_t)r * (D1 * D1) + e], scale_r[r], v0);
+        A[e] = (v0 + v1) + (v2 + v3);
     }
     __syncthreads();
     const bool snis = (flags & GMMVI_SELF_NORMALIZED) != 0;
@@ -219,20 +226,11 @@ static int launch_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
     if (chunk > 16) chunk = 16;
     const int n_chunks = (K + chunk - 1) / chunk;
     const size_t part_floats = (size_t)K * n_tiles * D1 * D1;
-    const size_t g_floats = (size_t)N * D;
-    const size_t need = (part_floats + (size_t)K * n_tiles + g_floats) * sizeof(float);
+    const size_t need = (part_floats + (size_t)K * n_tiles) * sizeof(float);
     int rc = gmmvi_ws_reserve(ctx, need);
     if (rc != GMMVI_OK) return rc;
     float* part = (float*)ctx->ws;
     float* part_m = part + part_floats;
-    float* g = part_m + (size_t)K * n_tiles;
-    {
-        GMMVI_PROF(ctx, "stein_gdiff");
-        int blocks = (int)((g_floats + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(sub_kernel, dim3(blocks), dim3(256), 0, ctx->stream, tgrad, qgrad, g, g_floats);
-    }
-    GMMVI_LAUNCH_CHECK(ctx);
     const size_t shmem = (size_t)(256 + 4 * 64) * LDW * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && shmem > 64 * 1024) {
@@ -243,7 +241,7 @@ static int launch_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
     {
         GMMVI_PROF(ctx, "stein_partial");
         hipLaunchKernelGGL((stein_partial_kernel<DP, NB>), dim3(n_tiles, n_chunks), dim3(256), shmem, ctx->stream, K, D,
-                           chunk, packed, X, g, N, ld, bg, mapping, map_offset, flags, part, part_m);
+                           chunk, packed, X, tgrad, qgrad, N, ld, bg, mapping, map_offset, flags, part, part_m);
     }
     GMMVI_LAUNCH_CHECK(ctx);
     GMMVI_PROF(ctx, "stein_finalize");

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
                                                             const float* __restrict__ stepsizes, float temperature,
                                                             float l2_init, float* __restrict__ last_eta, float* __restrict__ l2,
                                                             float* __restrict__ num_updates, int32_t* __restrict__ success_out,
-                                                            float* __restrict__ kl_out, int32_t* __restrict__ nprobes_out) {
+                                                            float* __restrict__ kl_out, int32_t* __restrict__ nprobes_out,
+                                                            float* __restrict__ packed_out, int DPk) {
     extern __shared__ float sm[];
     const int D = DC > 0 ? DC : Drt;
     Ws s;
@@ -309,6 +310,32 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             if (t < D) mug[t] = new_mu;
         }
     }
+    if (packed_out != nullptr) {
+        // packed parameter block of the (new or kept) component for the density kernels: layout of common.h Pack<DP>
+        __syncthreads();
+        const float* Lf = success ? s.M : s.L;                      // final factor (lower triangle), stride ld
+        const float mu_f = (t < D) ? (success ? mug[t] : s.mu[t]) : 0.f;
+        const int T = DPk * (DPk - 1) / 2;
+        const int stride = ((2 * DPk + 2 * T + 1 + 3) / 4) * 4;
+        float* out = packed_out + (size_t)k * stride;
+        for (int i = t; i < DPk; i += 64) {
+            out[i] = (i < D) ? mu_f : 0.f;
+            out[DPk + i] = (i < D) ? 1.f / Lf[i * ld + i] : 1.f;
+        }
+        for (int e = t; e < DPk * DPk; e += 64) {
+            const int i = e / DPk, j = e % DPk;
+            if (j < i) {
+                const float v = (i < D) ? Lf[i * ld + j] : 0.f;
+                out[2 * DPk + i * (i - 1) / 2 + j] = v;
+                out[2 * DPk + T + j * (DPk - 1) - j * (j - 1) / 2 + (i - j - 1)] = v;
+            }
+        }
+        const float lsum = wsum((t < D) ? __logf(Lf[t * ld + t]) : 0.f);
+        if (t == 0) {
+            out[2 * DPk + 2 * T] = -lsum - 0.5f * D * 1.8378770664093453f;
+            for (int i = 2 * DPk + 2 * T + 1; i < stride; ++i) out[i] = 0.f;
+        }
+    }
     if (t == 0) {
         last_eta[k] = success ? eta_star : -1.f;                                           // :504,:511,:524
         if (kl_out) kl_out[k] = success ? kl_val : -1.f;
@@ -326,7 +353,7 @@ extern "C" int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* m
                                           const float* H_neg_dev, const float* g_neg_dev, const float* stepsizes_dev,
                                           float temperature, float l2_init, float* last_eta_dev, float* l2_dev,
                                           float* num_received_updates_dev, int32_t* success_out_dev, float* kl_out_dev,
-                                          int32_t* n_probes_out_dev) {
+                                          int32_t* n_probes_out_dev, float* packed_out_dev) {
     GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM);
     GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && H_neg_dev && g_neg_dev && stepsizes_dev && last_eta_dev && l2_dev &&
                              num_received_updates_dev);
@@ -339,7 +366,8 @@ extern "C" int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* m
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));     \
         hipLaunchKernelGGL((update_kl_fast_kernel<DCV>), dim3(K), dim3(64), shmem, ctx->stream, D, means_dev,      \
                            chols_dev, H_neg_dev, g_neg_dev, stepsizes_dev, temperature, l2_init, last_eta_dev,     \
-                           l2_dev, num_received_updates_dev, success_out_dev, kl_out_dev, n_probes_out_dev);       \
+                           l2_dev, num_received_updates_dev, success_out_dev, kl_out_dev, n_probes_out_dev,        \
+                           packed_out_dev, gmmvi_padded_dim(D));                                                   \
     } while (0)
     switch (D) {                       // dimensions of the BASELINE configurations get unrolled instances
         case 4: GMMVI_UKL(4); break;

@@ -126,7 +126,8 @@ def stein(ctx, packed, x, ld, qgrad, bg, tgrad, d, mapping=None, map_offset=0, s
 
 
 def update_components_kl(ctx, means, chols, h_neg, g_neg, stepsizes, temperature, l2_init, last_eta, l2, num_updates,
-                         want_info=False, reference=False):
+                         want_info=False, reference=False, want_packed=False):
+    """-> (success, kl | None, probes | None[, packed])."""
     k, d = means.shape
     _req(means, (k, d), name="means"); _req(chols, (k, d, d), name="chols")
     _req(h_neg, (k, d, d), name="h_neg"); _req(g_neg, (k, d), name="g_neg"); _req(stepsizes, (k,), name="stepsizes")
@@ -134,11 +135,15 @@ def update_components_kl(ctx, means, chols, h_neg, g_neg, stepsizes, temperature
     success = ctx.empty((k,), np.int32)
     kl = ctx.empty((k,)) if want_info else None
     probes = ctx.empty((k,), np.int32) if want_info else None
-    fn = ctx.lib.gmmvi_update_components_kl_reference if reference else ctx.lib.gmmvi_update_components_kl
-    ctx.check(fn(ctx.handle, k, d, means.ptr, chols.ptr, h_neg.ptr, g_neg.ptr,
-                 stepsizes.ptr, float(temperature), float(l2_init), last_eta.ptr, l2.ptr, num_updates.ptr, success.ptr,
-                 None if kl is None else kl.ptr, None if probes is None else probes.ptr))
-    return success, kl, probes
+    args = [ctx.handle, k, d, means.ptr, chols.ptr, h_neg.ptr, g_neg.ptr, stepsizes.ptr, float(temperature),
+            float(l2_init), last_eta.ptr, l2.ptr, num_updates.ptr, success.ptr, None if kl is None else kl.ptr,
+            None if probes is None else probes.ptr]
+    if reference:
+        ctx.check(ctx.lib.gmmvi_update_components_kl_reference(*args))
+        return success, kl, probes
+    packed = ctx.empty((k, packed_stride(d))) if want_packed else None
+    ctx.check(ctx.lib.gmmvi_update_components_kl(*args, None if packed is None else packed.ptr))
+    return (success, kl, probes, packed) if want_packed else (success, kl, probes)
 
 
 def update_components_plain(ctx, mode, means, chols, h_neg, g_neg, stepsizes, l2_init, l2, num_updates):

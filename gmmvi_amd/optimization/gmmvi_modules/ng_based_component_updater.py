@@ -60,10 +60,10 @@ class KLConstrainedNgBasedComponentUpdater(NgBasedComponentUpdater):
     def apply_NG_update(self, expected_hessians_neg, expected_gradients_neg, stepsizes):
         m = self.model
         ctx = m.ctx
-        succ, kl, probes = hip_ops.update_components_kl(
+        succ, kl, probes, packed = hip_ops.update_components_kl(
             ctx, m.means, m.chol_cov, ctx.asarray(expected_hessians_neg), ctx.asarray(expected_gradients_neg),
             ctx.asarray(stepsizes), self.temperature, m.initial_regularizer, m.last_log_etas, m.l2_regularizers,
-            m.num_received_updates, want_info=self.want_info)
+            m.num_received_updates, want_info=self.want_info, want_packed=True)
         self.last_success = succ
         self.last_info = (kl, probes)
-        m.model._invalidate()
+        m.model._packed = packed          # the kernel emitted the parameter blocks of the updated components

@@ -145,12 +145,13 @@ int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const flo
 /* KLConstrainedNgBasedComponentUpdater.apply_NG_update (gmmvi_modules/ng_based_component_updater.py:431-524,
  * bracketing_search :335-429, kl :244-333) with the exact stop rules of SURVEY.md Appendix A.1.
  * In/out: means[K,D], chols[K,D,D], last_eta[K] (stores eta, not log eta; -1 = none), l2[K].
- * Out (may be NULL): success[K] (int32 0/1), kl[K], n_probes[K]. */
+ * Out (may be NULL): success[K] (int32 0/1), kl[K], n_probes[K], packed[K, gmmvi_packed_stride(D)] = the Gaussian
+ * parameter blocks of the updated model (saves the separate gmmvi_pack_components launch). */
 int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_dev,
                                const float* H_neg_dev, const float* g_neg_dev, const float* stepsizes_dev,
                                float temperature, float l2_init, float* last_eta_dev, float* l2_dev,
                                float* num_received_updates_dev, int32_t* success_out_dev, float* kl_out_dev,
-                               int32_t* n_probes_out_dev);
+                               int32_t* n_probes_out_dev, float* packed_out_dev);
 /* Same contract, computed with the reference's own formulation (Q' = (eta Q + R)/eta, Cholesky + triangular inverse
  * per probe, sequential bisection).  Slow; kept as an on-device cross-check of the production kernel. */
 int gmmvi_update_components_kl_reference(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_dev,

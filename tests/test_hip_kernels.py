@@ -347,3 +347,17 @@ def test_update_kl_fast_kernel_matches_reference_formulation(ctx, rng, k, d):
         np.testing.assert_allclose(state["fast"]["last_eta"].numpy(), state["ref"]["last_eta"].numpy(), rtol=1e-5)
         np.testing.assert_allclose(state["fast"]["means"].numpy(), state["ref"]["means"].numpy(), rtol=1e-3, atol=1e-3)
         np.testing.assert_allclose(state["fast"]["chols"].numpy(), state["ref"]["chols"].numpy(), rtol=2e-3, atol=2e-4)
+
+
+def test_update_kl_emits_packed_blocks(ctx, rng):
+    """The parameter blocks written by the update kernel equal gmmvi_pack_components on the updated model."""
+    for k, d in [(5, 4), (6, 20), (3, 33)]:
+        m, hs, gs = _update_inputs(rng, k, d)
+        hs[0] = np.nan                                  # one rejected component keeps (and packs) its old parameters
+        logw, means, chols = upload_model(ctx, m)
+        succ, _, _, packed = ops().update_components_kl(
+            ctx, means, chols, ctx.asarray(hs), ctx.asarray(gs), ctx.full((k,), 0.1), 1.0, 1e-12, ctx.full((k,), -1.0),
+            ctx.full((k,), 1e-12), ctx.zeros((k,)), want_packed=True)
+        assert succ.numpy()[0] == 0 and succ.numpy()[1:].all()
+        ref, _ = ops().pack_components(ctx, means, chols)
+        np.testing.assert_allclose(packed.numpy(), ref.numpy(), rtol=2e-6, atol=1e-6)
