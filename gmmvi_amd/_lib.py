@@ -51,6 +51,7 @@ _PROTOS = {
     "gmmvi_pack_components": (_i, [_p, _i, _f, _i, _i, _p, _p, _p, _p]),
     "gmmvi_cholesky": (_i, [_p, _i, _i, _p, _p, _p]),
     "gmmvi_mixture_eval": (_i, [_p, _i, _f, _i, _i, _p, _p, _p, _i, _p, _p, _p]),
+    "gmmvi_mixture_eval_dual": (_i, [_p, _i, _f, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
     "gmmvi_target_planar": (_i, [_p, _i, _p, _i, _p, _f, _p, _i, _p, _p]),
     "gmmvi_sample_components": (_i, [_p, _i, _i, _p, _p, _p, _i, _u64, _u64, _i, _p, _p, _p]),
     "gmmvi_philox_normals": (_i, [_p, _u64, _u64, _i, _i, _i, _p]),

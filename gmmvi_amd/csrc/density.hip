@@ -113,7 +113,8 @@ template <int DP, int FAMILY, bool GRAD, bool LDSFEED>
 __global__ __launch_bounds__(GMMVI_ME_THREADS, GMMVI_ME_MINW) void mixture_eval_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
                                                             const float* __restrict__ logw, const float* __restrict__ X,
                                                             int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
-                                                            float* __restrict__ grad_out) {
+                                                            float* __restrict__ grad_out, const float* __restrict__ logw2,
+                                                            float* __restrict__ lp2_out) {
     using PK = Pack<DP>;
     extern __shared__ __align__(16) float sm[];
     const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
@@ -144,6 +145,8 @@ __global__ __launch_bounds__(GMMVI_ME_THREADS, GMMVI_ME_MINW) void mixture_eval_
     __syncthreads();
 
     float m = -3.0e38f, s = 0.f;
+    float m2 = -3.0e38f, s2 = 0.f;                      // second mixture over the same components (logw2), optional
+    const bool dual = logw2 != nullptr;
     float acc[GRAD ? DP : 1];
     if (GRAD) {
 #pragma unroll
@@ -184,6 +187,12 @@ __global__ __launch_bounds__(GMMVI_ME_THREADS, GMMVI_ME_MINW) void mixture_eval_
         const float e = __expf(a - mn);
         s = fmaf(s, sc, e);
         m = mn;
+        if (dual) {
+            const float a2 = ld + logw2[k];
+            const float mn2 = fmaxf(m2, a2);
+            s2 = fmaf(s2, __expf(m2 - mn2), __expf(a2 - mn2));
+            m2 = mn2;
+        }
         if (GRAD) {
             float y[DP];
             backward_subst<DP>(P, z, y);
@@ -214,6 +223,20 @@ __global__ __launch_bounds__(GMMVI_ME_THREADS, GMMVI_ME_MINW) void mixture_eval_
     float S = 0.f;
     for (int w = 0; w < nwaves; ++w) S += sm_s[w * 64 + lane] * __expf(sm_m[w * 64 + lane] - M);
     if (wave == 0 && valid && lp_out != nullptr) lp_out[n] = M + __logf(S);
+    if (dual) {
+        float* sm_m2 = sm_merge + (size_t)nwaves * 64 * ((GRAD ? DP : 0) + 2) + (GRAD ? 64 * ldx : 0);
+        float* sm_s2 = sm_m2 + nwaves * 64;
+        sm_m2[wave * 64 + lane] = m2;
+        sm_s2[wave * 64 + lane] = s2;
+        __syncthreads();
+        if (wave == 0 && valid && lp2_out != nullptr) {
+            float M2 = -3.0e38f;
+            for (int w = 0; w < nwaves; ++w) M2 = fmaxf(M2, sm_m2[w * 64 + lane]);
+            float S2 = 0.f;
+            for (int w = 0; w < nwaves; ++w) S2 += sm_s2[w * 64 + lane] * __expf(sm_m2[w * 64 + lane] - M2);
+            lp2_out[n] = M2 + __logf(S2);
+        }
+    }
     if (GRAD && grad_out != nullptr) {
         const float inv = 1.f / S;
         // wave w reduces dimensions w, w + W, ...; results go to a [64][ldx] tile and leave coalesced
@@ -231,7 +254,8 @@ __global__ __launch_bounds__(GMMVI_ME_THREADS, GMMVI_ME_MINW) void mixture_eval_
 
 template <int DP>
 static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
-                               const float* logw, const float* X, int N, float* ld, float* lp, float* grad) {
+                               const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
+                               const float* logw2 = nullptr, float* lp2 = nullptr) {
     using PK = Pack<DP>;
     const bool want_grad = grad != nullptr;
     const bool want_merge = want_grad || lp != nullptr;
@@ -240,7 +264,8 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     static const int env_ky = getenv("GMMVI_ME_KY") ? atoi(getenv("GMMVI_ME_KY")) : 0;
     const bool lds_feed = env_feed != 0;
     auto lds_floats = [&](int nw) {
-        size_t merge = (size_t)nw * 64 * ((want_grad ? DP : 0) + 2) + (want_grad ? 64 * (size_t)(D | 1) : 0);
+        size_t merge = (size_t)nw * 64 * ((want_grad ? DP : 0) + 2) + (want_grad ? 64 * (size_t)(D | 1) : 0) +
+                       (logw2 ? (size_t)nw * 128 : 0);
         size_t stage = 64 * (size_t)(D | 1);
         return (lds_feed ? (size_t)nw * PK::STRIDE : 0) + (merge > stage ? merge : stage);
     };
@@ -250,7 +275,8 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     // scalar-load feed, 16 waves per tile and no K split is the fastest geometry (19.9 / 35.0 us without / with the
     // gradient); splitting K over blockIdx.y only pays for very few sample tiles.
     int ky = 1, nw = K < 16 ? K : 16;
-    if (env_ky > 0) ky = env_ky < K ? env_ky : K;
+    if (logw2 != nullptr) ky = 1;                      // the dual mixture is merged inside the workgroup only
+    else if (env_ky > 0) ky = env_ky < K ? env_ky : K;
     else {
         while (ky < 8 && (long)tiles * nw * ky < ctx->num_cus && K / (ky + 1) >= 16) ++ky;
     }
@@ -278,7 +304,7 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
             GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_kernel<DP, FAM, G, F>,               \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
         hipLaunchKernelGGL((mixture_eval_kernel<DP, FAM, G, F>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
-                           logw, X, N, ld, lp_k, grad_k);                                                           \
+                           logw, X, N, ld, lp_k, grad_k, logw2, lp2);                                               \
     } while (0)
 #define GMMVI_LAUNCH_ME2(FAM, G) do { if (lds_feed) GMMVI_LAUNCH_ME(FAM, G, true); else GMMVI_LAUNCH_ME(FAM, G, false); } while (0)
         if (family == GMMVI_GAUSS) {
@@ -335,6 +361,19 @@ int gmmvi_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const
     int dp = gmmvi_padded_dim(D);
     GMMVI_DISPATCH_DP(dp, return launch_mixture_eval<DP>(ctx, family, nu, K, D, packed_dev, logw_dev, X_dev, N,
                                                          ld_out_dev, lp_out_dev, grad_out_dev));
+    return GMMVI_OK;
+}
+
+int gmmvi_mixture_eval_dual(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed_dev,
+                            const float* logw_dev, const float* logw2_dev, const float* X_dev, int N, float* ld_out_dev,
+                            float* lp_out_dev, float* grad_out_dev, float* lp2_out_dev) {
+    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM && N >= 0);
+    GMMVI_ARG_CHECK(ctx, family == GMMVI_GAUSS || family == GMMVI_STUDENT_T);
+    if (N == 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, packed_dev && logw_dev && logw2_dev && X_dev && lp_out_dev && lp2_out_dev);
+    int dp = gmmvi_padded_dim(D);
+    GMMVI_DISPATCH_DP(dp, return launch_mixture_eval<DP>(ctx, family, nu, K, D, packed_dev, logw_dev, X_dev, N,
+                                                         ld_out_dev, lp_out_dev, grad_out_dev, logw2_dev, lp2_out_dev));
     return GMMVI_OK;
 }
 

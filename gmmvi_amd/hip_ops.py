@@ -62,6 +62,22 @@ def mixture_eval(ctx, packed, logw, x, d, family=_lib.GAUSS, nu=0.0, want_ld=Fal
     return ld, lp, grad
 
 
+def mixture_eval_dual(ctx, packed, logw, logw2, x, d, want_ld=True, want_grad=True):
+    """One sweep, two mixtures over the same components -> (ld | None, lp, grad | None, lp2)."""
+    k = packed.shape[0]
+    n = x.shape[0]
+    _req(packed, (k, packed_stride(d)), name="packed"); _req(logw, (k,), name="logw"); _req(logw2, (k,), name="logw2")
+    _req(x, (n, d), name="x")
+    ld = ctx.empty((k, n)) if want_ld else None
+    lp, lp2 = ctx.empty((n,)), ctx.empty((n,))
+    grad = ctx.empty((n, d)) if want_grad else None
+    if n > 0:
+        ctx.check(ctx.lib.gmmvi_mixture_eval_dual(ctx.handle, _lib.GAUSS, 0.0, k, d, packed.ptr, logw.ptr, logw2.ptr,
+                                                  x.ptr, n, None if ld is None else ld.ptr, lp.ptr,
+                                                  None if grad is None else grad.ptr, lp2.ptr))
+    return ld, lp, grad, lp2
+
+
 def target_planar(ctx, prior_std, goals, likelihood_std, x, want_grad=True):
     n, d = x.shape
     g = goals.shape[0]

@@ -24,6 +24,7 @@ class GMM:
         self._const_log_det = 0.5 * self.num_dimensions * np.log(2 * np.pi)
         self.log_weights = self.ctx.asarray(log_weights)
         self._packed = None
+        self._eval_cache = None       # (samples ptr, shape, packed) -> (lp, grad, ld) of a fused evaluation
         self.seed = 0                 # Philox key for sample(); the runner sets it from the config seed
         self._sample_counter = 0      # index into the mixture-sampling Philox streams
         self.replace_weights(self.log_weights)                                   # gmm.py:34
@@ -31,6 +32,7 @@ class GMM:
     # ---- packed parameter blocks for the kernels (rebuilt lazily after every component change) -----------
     def _invalidate(self):
         self._packed = None
+        self._eval_cache = None
 
     @property
     def packed(self):
@@ -72,8 +74,25 @@ class GMM:
     def density(self, samples):
         return np.exp(self.log_density(samples).numpy())
 
+    def eval_with_background(self, samples, log_background_weights):
+        """Background density log sum_k c_k N(x; mu_k, Sigma_k) (sample_db.py:221-227) AND the model's
+        log_density_and_grad of the same samples in one sweep over the (sample, component) pairs.  The model part is
+        cached and handed out by the next log_density_and_grad(samples) call (gmmvi_modules/ng_estimator.py:246)."""
+        x = self._x(samples)
+        packed = self.packed
+        ld, lp, grad, bg = hip_ops.mixture_eval_dual(self.ctx, packed, self.log_weights, log_background_weights, x,
+                                                     self.num_dimensions)
+        self._eval_cache = (x.ptr, x.shape, packed, self.log_weights.ptr, (lp, grad, ld))
+        return bg
+
     def log_density_and_grad(self, samples):
         """-> (log q [N], grad_x log q [N,D], component log densities [K,N])."""
+        c = self._eval_cache
+        if c is not None:
+            x = self._x(samples)
+            if c[0] == x.ptr and c[1] == x.shape and c[2] is self._packed and c[3] == self.log_weights.ptr:
+                self._eval_cache = None
+                return c[4]
         ld, lp, grad = hip_ops.mixture_eval(self.ctx, self.packed, self.log_weights, self._x(samples),
                                             self.num_dimensions, want_ld=True, want_lp=True, want_grad=True)
         return lp, grad, ld

@@ -46,6 +46,7 @@ class VipsSampleSelector(SampleSelector):
         self.reused_samples_per_component = int(np.floor(ratio_reused_samples_to_desired
                                                          * desired_samples_per_component))
         self.eps_override = None       # callable(n, d) -> host normals, for bit-reproducible parity runs
+        self.fuse_background = True    # fused background + model density pass when nothing is reused
 
     def get_effective_samples(self, model_densities, oldsamples_pdf):
         """sample_selector.py:140-158: ESS_k = 1 / sum_n softmax_n(ld[k,n] - bg[n])^2 (device reduction)."""
@@ -91,8 +92,11 @@ class VipsSampleSelector(SampleSelector):
                                    mapping_host=self._last_mapping_host, packed=self.model.packed,
                                    counts=self._last_counts)
         num_new = new_samples.shape[0]
+        # nothing reused: the active samples come from the current components, so the background mixture shares its
+        # components with the model and both are evaluated in one sweep
+        fuse = self.model.model if (num_reused == 0 and self.fuse_background) else None
         oldsamples_pdf, samples, mapping, target_lnpdfs, target_grads = \
-            self.sample_db.get_newest_samples(num_reused + num_new)
+            self.sample_db.get_newest_samples(num_reused + num_new, fuse_with_model=fuse)
         return samples, mapping, oldsamples_pdf, target_lnpdfs, target_grads
 
 

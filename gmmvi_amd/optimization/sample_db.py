@@ -254,8 +254,11 @@ class SampleDB:
         order = np.argsort(first)
         return uniq[order], counts[order]
 
-    def get_newest_samples(self, N):
-        """sample_db.py:194-228 -> (log_pdfs, samples, mapping, target_lnpdfs, target_grads)."""
+    def get_newest_samples(self, N, fuse_with_model=None):
+        """sample_db.py:194-228 -> (log_pdfs, samples, mapping, target_lnpdfs, target_grads).
+        ``fuse_with_model``: a model whose CURRENT components are exactly the snapshot components of the requested
+        window (the caller guarantees it: newest append, reuse ratio 0); the background density is then computed
+        together with the model's density/gradient in one sweep (GMM.eval_with_background)."""
         ctx, d = self.ctx, self._dim
         N = int(N)
         if self._samples.n == 0 or N == 0:                                                     # :213-214
@@ -274,7 +277,11 @@ class SampleDB:
             w = counts.astype(np.float64) / counts.sum()                                       # :225-226
             return ctx.asarray(np.log(w).astype(np.float32))
         logw = ctx.cached_const(("bg_logw", counts.tobytes()), build)
-        _, bg, _ = hip_ops.mixture_eval(ctx, packed, logw, xs, d, want_lp=True)                # :227
+        if (fuse_with_model is not None and self._segments and self._segments[-1][0] == start
+                and len(active) == fuse_with_model.num_components):
+            bg = fuse_with_model.eval_with_background(xs, logw)
+        else:
+            _, bg, _ = hip_ops.mixture_eval(ctx, packed, logw, xs, d, want_lp=True)            # :227
         return (bg, xs, self._mapping_dev.view(start), self._target_lnpdfs.view(start),
                 self._target_grads.view(start))
 

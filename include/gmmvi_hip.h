@@ -112,6 +112,14 @@ int gmmvi_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const
                        const float* logw_dev, const float* X_dev, int N, float* ld_out_dev, float* lp_out_dev,
                        float* grad_out_dev);
 
+/* Same pass with a SECOND set of mixture weights over the same components: lp2[n] = logsumexp_k(logw2[k] + ld[k,n]).
+ * Fuses SampleDB.get_newest_samples' background density (weights = sample counts, sample_db.py:221-227) with
+ * GMM.log_density_and_grad (models/gmm.py:274-300) when the active samples were drawn from the current components
+ * (reuse ratio 0): one sweep over the (sample, component) pairs instead of two. */
+int gmmvi_mixture_eval_dual(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed_dev,
+                            const float* logw_dev, const float* logw2_dev, const float* X_dev, int N, float* ld_out_dev,
+                            float* lp_out_dev, float* grad_out_dev, float* lp2_out_dev);
+
 /* Planar n-link robot target (target_distributions/planar_robot.py:29-66) and its gradient. goals_dev[G,2]. */
 int gmmvi_target_planar(gmmvi_ctx* ctx, int D, const float* prior_std_dev, int G, const float* goals_dev,
                         float likelihood_std, const float* X_dev, int N, float* lp_out_dev, float* grad_out_dev);

@@ -361,3 +361,24 @@ def test_update_kl_emits_packed_blocks(ctx, rng):
         assert succ.numpy()[0] == 0 and succ.numpy()[1:].all()
         ref, _ = ops().pack_components(ctx, means, chols)
         np.testing.assert_allclose(packed.numpy(), ref.numpy(), rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("k,d,n", [(3, 4, 64), (8, 20, 512), (40, 20, 1000), (5, 50, 130)])
+def test_mixture_eval_dual(ctx, rng, k, d, n):
+    """Fused background + model sweep equals the two separate sweeps."""
+    m = random_gmm(rng, k, d)
+    x = m.means[rng.integers(0, k, n)] + rng.normal(size=(n, d)) * 1.5
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    counts = rng.integers(1, 50, k).astype(np.float64)
+    logc = ctx.asarray(np.log(counts / counts.sum()))
+    xd = ctx.asarray(x)
+    ld, lp, grad, bg = ops().mixture_eval_dual(ctx, packed, logw, logc, xd, d)
+    ld1, lp1, grad1 = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_grad=True)
+    _, bg1, _ = ops().mixture_eval(ctx, packed, logc, xd, d)
+    np.testing.assert_allclose(ld.numpy(), ld1.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(lp.numpy(), lp1.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(grad.numpy(), grad1.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(bg.numpy(), bg1.numpy(), rtol=1e-6, atol=1e-6)
+    ref = logsumexp(m.component_log_densities(x.astype(np.float32).astype(np.float64)) + np.log(counts / counts.sum())[:, None], axis=0)
+    np.testing.assert_allclose(bg.numpy(), ref, rtol=1e-4, atol=2e-4)
