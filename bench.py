@@ -33,6 +33,7 @@ WORKLOADS = {
     "c2": ("stm", 20, 50, 100),        # BASELINE configs[1]: K=50, N=5000
     "c3": ("gmm", 50, 100, 100),       # BASELINE configs[2]: GMM target D=50, K=100, N=10k
     "c4": ("planar", 10, 200, 100),    # BASELINE configs[3] on one GPU: planar-4, K=200, N=20k
+    "tiny": ("stm", 4, 4, 16),         # host-overhead probe (kernels are empty; time = launch path)
 }
 
 
@@ -173,6 +174,12 @@ def main():
     f_alg_iter = float(n_tot) * k_tot * (8 * d * d + 12 * d)                   # SURVEY.md 8d (probes reported apart)
     b_alg_iter = 4.0 * (3 * n_tot * d + 3 * n_tot + 2 * k_tot * (d * d + d + 1))
 
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            traffic = json.load(f).get(args.workload, {}).get(roof_name, {}).get("hbm_bytes")
+    except (OSError, ValueError):
+        pass
     result = {
         "metric": "samples_components_per_sec", "value": n_tot * k_tot / (elapsed / args.steps),
         "unit": "samples*components/s", "train_iter_per_sec": args.steps / elapsed,
@@ -183,7 +190,7 @@ def main():
                                f"(Stein, fixed K, reuse ratio 0, KL trust regions, improvement-based stepsizes)",
                    "K": k_tot, "D": d, "N": n_tot, "parallelism": f"component-shard x{n_gpus}"},
         "roofline": {"kernel": roof_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
                      "avg_us": kernels[roof_name]["avg_us"], "flops_per_launch": fl,
                      "note": "fp32 FMA path (vector substitution + f32 MFMA contraction); peak = fp32 vector == f32 "
                              "MFMA rate. Algorithmic HBM bytes per iteration are tiny (see iter_roofline): the "

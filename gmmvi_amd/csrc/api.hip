@@ -55,6 +55,7 @@ void gmmvi_ctx_destroy(gmmvi_ctx* ctx) {
         (void)hipStreamDestroy(ctx->stream);
     }
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->arena) (void)hipFree(ctx->arena);
     delete ctx;
 }
 

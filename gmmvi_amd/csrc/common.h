@@ -15,6 +15,8 @@ struct gmmvi_ctx {
     // scratch reused by multi-kernel entry points (grown on demand, never shrunk)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    void* arena = nullptr;       // persistent scratch of the single-call iteration (fused.hip)
+    size_t arena_bytes = 0;
     void* comm = nullptr;        // ncclComm_t
     int n_ranks = 1, rank = 0;
     int num_cus = 256;

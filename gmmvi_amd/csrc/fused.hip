@@ -1,0 +1,100 @@
+// gmmvi_train_iter_samtron: the whole SAMTRON iteration (GMMVI.train_iter, optimization/gmmvi.py:146-174, with a
+// component-based sample selector at reuse ratio 0) issued from ONE host call.  It is exactly the composition of the
+// public entry points of this library in the order the Python modules call them -- no extra arithmetic lives here --
+// so that the fast path and the modular plug-in path produce identical results (tests/test_hip_fused.py).  Purpose:
+// the modular path costs ~20 Python->C transitions per iteration (~340 us of host time, more than the kernels take).
+#include "common.h"
+
+namespace {
+struct Arena {
+    float *ld, *lq, *qgrad, *bg, *H, *g, *E;
+    int32_t *mapping, *success;
+};
+}  // namespace
+
+static int arena_reserve(gmmvi_ctx* ctx, size_t floats) {
+    if (floats * sizeof(float) <= ctx->arena_bytes) return GMMVI_OK;
+    GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->arena) GMMVI_HIP_CHECK(ctx, hipFree(ctx->arena));
+    ctx->arena = nullptr;
+    ctx->arena_bytes = 0;
+    size_t want = floats * sizeof(float) * 3 / 2;
+    GMMVI_HIP_CHECK(ctx, hipMalloc(&ctx->arena, want));
+    ctx->arena_bytes = want;
+    return GMMVI_OK;
+}
+
+#define GMMVI_TRY(call)                \
+    do {                               \
+        int rc__ = (call);             \
+        if (rc__ != GMMVI_OK) return rc__; \
+    } while (0)
+
+extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) {
+    GMMVI_ARG_CHECK(ctx, p != nullptr);
+    const int K = p->K, D = p->D, N = p->N;
+    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D < GMMVI_MAX_DIM && N >= 1);
+    GMMVI_ARG_CHECK(ctx, p->means && p->chols && p->logw && p->packed && p->packed_new && p->stepsizes && p->last_eta &&
+                             p->l2 && p->num_updates && p->offsets && p->bg_logw && p->db_samples && p->db_tlp &&
+                             p->db_tgrad && p->db_mapping && p->reward_next && p->wstate);
+    const size_t KN = (size_t)K * N, ND = (size_t)N * D;
+    const size_t floats = KN + 2 * (size_t)N + ND + (size_t)K * D * D + (size_t)K * D + 3 * (size_t)K + N + 64;
+    GMMVI_TRY(arena_reserve(ctx, floats));
+    Arena a;
+    float* base = (float*)ctx->arena;
+    a.ld = base; base += KN;
+    a.lq = base; base += N;
+    a.bg = base; base += N;
+    a.qgrad = base; base += ND;
+    a.H = base; base += (size_t)K * D * D;
+    a.g = base; base += (size_t)K * D;
+    a.E = base; base += K;
+    a.success = (int32_t*)base; base += K;
+    a.mapping = (int32_t*)base; base += N;
+
+    float* x = p->db_samples;          // the new samples ARE the active samples (reuse ratio 0): no copy
+    // ---- sample selection: draw, evaluate the target, append to the DB (sample_selector.py:160-219) --------------------
+    GMMVI_TRY(gmmvi_sample_components(ctx, K, D, p->means, p->chols, p->offsets, N, p->seed, p->first_index, 0, nullptr, x,
+                                      a.mapping));
+    GMMVI_TRY(gmmvi_add_scalar_i32(ctx, p->db_mapping, a.mapping, p->mapping_base, (size_t)N));
+    if (p->target_kind == 1) {
+        GMMVI_TRY(gmmvi_target_planar(ctx, D, p->planar_prior_std, p->planar_goals_count, p->planar_goals,
+                                      p->planar_likelihood_std, x, N, p->db_tlp, p->db_tgrad));
+    } else {
+        GMMVI_TRY(gmmvi_mixture_eval(ctx, p->target_family, p->target_nu, p->target_K, D, p->target_packed,
+                                     p->target_logw, x, N, nullptr, p->db_tlp, p->db_tgrad));
+    }
+    if (p->db_means && p->db_chols && p->db_packed) {
+        void* dst[3] = {p->db_means, p->db_chols, p->db_packed};
+        const void* src[3] = {p->means, p->chols, p->packed};
+        size_t nb[3] = {(size_t)K * D * 4, (size_t)K * D * D * 4, (size_t)K * gmmvi_packed_stride(D) * 4};
+        GMMVI_TRY(gmmvi_copy_batch(ctx, 3, dst, src, nb));
+    }
+    // ---- background + model density / gradient in one sweep (sample_db.py:194-228, gmm.py:274-300) ------------------------
+    GMMVI_TRY(gmmvi_mixture_eval_dual(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, p->logw, p->bg_logw, x, N, a.ld, a.lq, a.qgrad,
+                                      a.bg));
+    // ---- component update (gmmvi.py:165-169) -----------------------------------------------------------------------------
+    if (p->component_stepsize_mode == 1)
+        GMMVI_TRY(gmmvi_component_stepsize_improvement(ctx, K, p->stepsizes, p->reward_prev, p->reward_last, p->cs_min,
+                                                       p->cs_max, p->cs_inc, p->cs_dec));
+    GMMVI_TRY(gmmvi_stein(ctx, K, D, p->packed, x, N, a.ld, a.qgrad, a.bg, p->db_tgrad, nullptr, 0, p->stein_flags, a.H,
+                          a.g));
+    GMMVI_TRY(gmmvi_update_components_kl(ctx, K, D, p->means, p->chols, a.H, a.g, p->stepsizes, p->temperature, p->l2_init,
+                                         p->last_eta, p->l2, p->num_updates, p->success_out ? p->success_out : a.success,
+                                         nullptr, nullptr, p->packed_new));
+    // ---- weight update (gmmvi.py:172-173) ---------------------------------------------------------------------------------
+    if (p->weight_stepsize_mode == 1)
+        GMMVI_TRY(gmmvi_weight_stepsize_improvement(ctx, K, p->logw, p->reward_last, p->wstate, p->ws_min, p->ws_max,
+                                                    p->ws_inc, p->ws_dec));
+    GMMVI_TRY(gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed_new, p->logw, x, N, a.ld, a.lq, nullptr));
+    GMMVI_TRY(gmmvi_expected_log_ratios(ctx, K, N, a.ld, a.bg, p->db_tlp, a.lq, p->temperature, p->logw,
+                                        (p->stein_flags & GMMVI_SELF_NORMALIZED) ? 1 : 0, a.E, p->reward_next, nullptr));
+    if (K > 1) {
+        if (p->weight_update_mode == 0)
+            GMMVI_TRY(gmmvi_update_weights_kl(ctx, K, p->logw, a.E, p->wstate, p->temperature, nullptr));
+        else
+            GMMVI_TRY(gmmvi_update_weights_direct(ctx, K, p->logw, a.E, p->wstate, p->temperature));
+        if (p->weight_slot) GMMVI_TRY(gmmvi_exp_f32(ctx, p->weight_slot, p->logw, (size_t)K));
+    }
+    return GMMVI_OK;
+}

@@ -34,6 +34,11 @@ class GMM_LNPDF(LNPDF):
     def get_num_dimensions(self):
         return int(self.target_means.shape[1])
 
+    def _fast_path_target(self):
+        """Descriptor for the single-call iteration (optimization/fused.py)."""
+        return {"kind": 0, "family": self._family, "nu": float(self._nu), "K": int(self.target_means.shape[0]),
+                "packed": self._packed.ptr, "logw": self._logw.ptr}
+
     def log_density(self, x):
         _, lp, _ = hip_ops.mixture_eval(self.ctx, self._packed, self._logw, self.ctx.asarray(x),
                                         self.get_num_dimensions(), family=self._family, nu=self._nu)

@@ -29,6 +29,11 @@ class PlanarRobot(LNPDF):
     def get_num_dimensions(self):
         return self._num_dimensions
 
+    def _fast_path_target(self):
+        """Descriptor for the single-call iteration (optimization/fused.py)."""
+        return {"kind": 1, "prior_std": self._prior_dev.ptr, "goals": self._goals_dev.ptr,
+                "G": int(self.goals.shape[0]), "lik_std": self.likelihood_std}
+
     def forward_kinematics(self, theta):
         """planar_robot.py:58-64 (host; metrics only)."""
         theta = np.asarray(theta.numpy() if hasattr(theta, "numpy") else theta, np.float64)

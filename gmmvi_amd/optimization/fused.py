@@ -1,0 +1,182 @@
+"""Single-call fast path of GMMVI.train_iter() (reference: src/gmmvi/optimization/gmmvi.py:146-174).
+
+When every plug-in module is one of the built-in SAMTRON-style choices (component-based selector at reuse ratio 0,
+Stein estimator, KL-constrained component updater, improvement-based or fixed stepsizes, trust-region or direct weight
+updater, built-in target), the iteration is issued by ONE C call (``gmmvi_train_iter_samtron``) that composes the same
+entry points the modules call, on the same state arrays.  Python only does the bookkeeping the reference keeps in
+``tf.Variable``s (DB length, ring positions, counters).  Anything else -- reuse ratio > 0, MORE, direct/iBLR updaters,
+own-samples-only, user targets, want_info -- takes the modular path.  Disable with ``GMMVI_FAST_PATH=0``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .. import _lib, hip_ops
+from .gmmvi_modules.sample_selector import VipsSampleSelector
+from .gmmvi_modules.ng_estimator import SteinNgEstimator
+from .gmmvi_modules.ng_based_component_updater import KLConstrainedNgBasedComponentUpdater
+from .gmmvi_modules.component_stepsize_adaptation import (FixedComponentStepsizeAdaptation,
+                                                          ImprovementBasedComponentStepsizeAdaptation)
+from .gmmvi_modules.weight_stepsize_adaptation import (FixedWeightStepsizeAdaptation,
+                                                       ImprovementBasedWeightStepsizeAdaptation)
+from .gmmvi_modules.weight_updater import DirectWeightUpdater, TrustRegionBasedWeightUpdater
+
+_f, _i, _p = C.c_float, C.c_int32, C.c_void_p
+
+
+class SamtronPlan(C.Structure):
+    """struct gmmvi_samtron_plan (include/gmmvi_hip.h)."""
+    _fields_ = [
+        ("K", _i), ("D", _i), ("N", _i), ("target_kind", _i), ("target_family", _i), ("target_K", _i),
+        ("target_nu", _f), ("target_packed", _p), ("target_logw", _p), ("planar_prior_std", _p), ("planar_goals", _p),
+        ("planar_goals_count", _i), ("planar_likelihood_std", _f),
+        ("means", _p), ("chols", _p), ("logw", _p), ("packed", _p), ("packed_new", _p),
+        ("stepsizes", _p), ("last_eta", _p), ("l2", _p), ("num_updates", _p), ("success_out", _p),
+        ("offsets", _p), ("bg_logw", _p), ("seed", C.c_uint64), ("first_index", C.c_uint64),
+        ("db_samples", _p), ("db_tlp", _p), ("db_tgrad", _p), ("db_mapping", _p), ("mapping_base", _i),
+        ("db_means", _p), ("db_chols", _p), ("db_packed", _p),
+        ("reward_prev", _p), ("reward_last", _p), ("reward_next", _p), ("weight_slot", _p), ("wstate", _p),
+        ("temperature", _f), ("l2_init", _f),
+        ("component_stepsize_mode", _i), ("cs_min", _f), ("cs_max", _f), ("cs_inc", _f), ("cs_dec", _f),
+        ("weight_stepsize_mode", _i), ("ws_min", _f), ("ws_max", _f), ("ws_inc", _f), ("ws_dec", _f),
+        ("weight_update_mode", _i), ("stein_flags", _i),
+    ]
+
+
+class SamtronFastPath:
+    def __init__(self, gmmvi):
+        self.g = gmmvi
+        self.plan = SamtronPlan()
+        self.enabled = os.environ.get("GMMVI_FAST_PATH", "1") != "0"
+        self._static_ok = None
+        lib = _lib.load()
+        lib.gmmvi_train_iter_samtron.restype = C.c_int
+        lib.gmmvi_train_iter_samtron.argtypes = [C.c_void_p, C.POINTER(SamtronPlan)]
+        self._fn = lib.gmmvi_train_iter_samtron
+
+    # ---- eligibility -----------------------------------------------------------------------------------------------------
+    def _check_static(self):
+        g = self.g
+        sel, est, upd = g.sample_selector, g.ng_estimator, g.ng_based_updater
+        wu, cs, ws = g.weight_updater, g.component_stepsize_adapter, g.weight_stepsize_adapter
+        tgt = sel.target_distribution
+        ok = (type(sel) is VipsSampleSelector and type(est) is SteinNgEstimator
+              and type(upd) is KLConstrainedNgBasedComponentUpdater
+              and type(cs) in (FixedComponentStepsizeAdaptation, ImprovementBasedComponentStepsizeAdaptation)
+              and type(ws) in (FixedWeightStepsizeAdaptation, ImprovementBasedWeightStepsizeAdaptation)
+              and type(wu) in (DirectWeightUpdater, TrustRegionBasedWeightUpdater)
+              and hasattr(tgt, "_fast_path_target")
+              and not est._only_use_own_samples
+              and est._use_self_normalized_importance_weights == wu.use_self_normalized_importance_weights
+              and g.sample_db.keep_samples and g.model.num_dimensions < _lib.MAX_DIM)
+        return bool(ok)
+
+    def eligible(self):
+        if not self.enabled:
+            return False
+        if self._static_ok is None:
+            self._static_ok = self._check_static()
+        if not self._static_ok:
+            return False
+        g = self.g
+        sel, db = g.sample_selector, g.sample_db
+        if sel.reused_samples_per_component != 0 or sel.eps_override is not None or not sel.fuse_background:
+            return False
+        if g.ng_based_updater.want_info or g.weight_updater.want_info:
+            return False
+        n_new = sel.desired_samples_per_component * g.model.num_components
+        if db.max_samples is not None and n_new + db._samples.n > db.max_samples:
+            return False                                   # the modular path thins the DB out first (sample_db.py:111-112)
+        return sel.desired_samples_per_component >= 1
+
+    # ---- one iteration -----------------------------------------------------------------------------------------------------
+    def step(self):
+        g = self.g
+        m = g.model                      # GmmWrapper
+        model = m.model
+        ctx = model.ctx
+        sel, db = g.sample_selector, g.sample_db
+        k, d = model.num_components, model.num_dimensions
+        s = sel.desired_samples_per_component
+        n = k * s
+        p = self.plan
+
+        counts = np.full(k, s, np.int64)
+        key = counts.tobytes()
+        offsets = np.arange(k + 1, dtype=np.int32) * np.int32(s)
+        offsets_dev = ctx.cached_const(("offsets", offsets.tobytes()), lambda: ctx.asarray(offsets, np.int32))
+        bg_logw = ctx.cached_const(("bg_logw", key),
+                                   lambda: ctx.asarray(np.full(k, -np.log(k), np.float32)))
+        if getattr(sel, "_mapping_key", None) != key:
+            sel._mapping_key = key
+            sel._last_mapping_host = np.repeat(np.arange(k, dtype=np.int32), counts)
+
+        # SampleDB: reserve room, remember the append position (sample_db.py:113-124)
+        for grow, rows in ((db._samples, n), (db._target_lnpdfs, n), (db._target_grads, n), (db._mapping_dev, n),
+                           (db._means, k), (db._chols, k), (db._packed, k)):
+            grow.reserve(rows)
+        s0, c0 = db._samples.n, db._means.n
+        stride = db._packed.inner[0]
+        packed_cur = model.packed
+        packed_new = ctx.empty((k, stride))
+        success = ctx.empty((k,), np.int32)
+
+        tgt = sel.target_distribution._fast_path_target()
+        p.K, p.D, p.N = k, d, n
+        p.target_kind = tgt["kind"]
+        p.target_family, p.target_K, p.target_nu = tgt.get("family", 0), tgt.get("K", 0), tgt.get("nu", 0.0)
+        p.target_packed, p.target_logw = tgt.get("packed"), tgt.get("logw")
+        p.planar_prior_std, p.planar_goals = tgt.get("prior_std"), tgt.get("goals")
+        p.planar_goals_count, p.planar_likelihood_std = tgt.get("G", 0), tgt.get("lik_std", 0.0)
+        p.means, p.chols, p.logw = model.means.ptr, model.chol_cov.ptr, model.log_weights.ptr
+        p.packed, p.packed_new = packed_cur.ptr, packed_new.ptr
+        p.stepsizes, p.last_eta, p.l2 = m.stepsizes.ptr, m.last_log_etas.ptr, m.l2_regularizers.ptr
+        p.num_updates, p.success_out = m.num_received_updates.ptr, success.ptr
+        p.offsets, p.bg_logw = offsets_dev.ptr, bg_logw.ptr
+        p.seed, p.first_index = int(model.seed) & 0xFFFFFFFFFFFFFFFF, int(db._num_samples_written)
+        p.db_samples = db._samples.buf.ptr + s0 * d * 4
+        p.db_tlp = db._target_lnpdfs.buf.ptr + s0 * 4
+        p.db_tgrad = db._target_grads.buf.ptr + s0 * d * 4
+        p.db_mapping, p.mapping_base = db._mapping_dev.buf.ptr + s0 * 4, c0
+        p.db_means = db._means.buf.ptr + c0 * d * 4
+        p.db_chols = db._chols.buf.ptr + c0 * d * d * 4
+        p.db_packed = db._packed.buf.ptr + c0 * stride * 4
+        p.reward_prev, p.reward_last = m.reward_slot(1).ptr, m.reward_slot(0).ptr
+        p.reward_next = m.next_reward_slot().ptr
+        wslot = m._slot(m._t_weight)
+        p.weight_slot = m._weight_ring.ptr + wslot * k * 4
+        ws, cs, wu = g.weight_stepsize_adapter, g.component_stepsize_adapter, g.weight_updater
+        p.wstate = ws._state.ptr
+        p.temperature, p.l2_init = float(g.temperature), float(m.initial_regularizer)
+        if type(cs) is ImprovementBasedComponentStepsizeAdaptation:
+            p.component_stepsize_mode = 1
+            p.cs_min, p.cs_max = cs.min_stepsize, cs.max_stepsize
+            p.cs_inc, p.cs_dec = cs.stepsize_inc_factor, cs.stepsize_dec_factor
+        else:
+            p.component_stepsize_mode = 0
+        if type(ws) is ImprovementBasedWeightStepsizeAdaptation:
+            p.weight_stepsize_mode = 1
+            p.ws_min, p.ws_max = ws.min_stepsize, ws.max_stepsize
+            p.ws_inc, p.ws_dec = ws.stepsize_inc_factor, ws.stepsize_dec_factor
+        else:
+            p.weight_stepsize_mode = 0
+        p.weight_update_mode = 0 if type(wu) is TrustRegionBasedWeightUpdater else 1
+        p.stein_flags = _lib.SELF_NORMALIZED if g.ng_estimator._use_self_normalized_importance_weights else 0
+
+        ctx.check(self._fn(ctx.handle, C.byref(p)))
+
+        # bookkeeping the modules would have done
+        for grow, rows in ((db._samples, n), (db._target_lnpdfs, n), (db._target_grads, n), (db._mapping_dev, n),
+                           (db._means, k), (db._chols, k), (db._packed, k)):
+            grow.n += rows
+        db._num_samples_written += n
+        db._mapping_host.append(sel._last_mapping_host + np.int32(c0))
+        db._segments.append((s0, c0, counts))
+        m.commit_rewards()
+        if k > 1:
+            m._t_weight += 1
+        model._packed = packed_new
+        model._eval_cache = None
+        g.ng_based_updater.last_success = success
+        g.num_updates.assign_add(1)

@@ -55,6 +55,8 @@ class GMMVI:
         self.weight_stepsize_adapter = weight_stepsize_adapter
         self.weight_updater = weight_updater
         self.num_updates = _Counter()
+        from .fused import SamtronFastPath
+        self._fast_path = SamtronFastPath(self)
 
     @staticmethod
     def build_from_config(config: dict, target_distribution, model: GmmWrapper):
@@ -75,10 +77,14 @@ class GMMVI:
                      weight_updater)
 
     def train_iter(self):
-        """gmmvi.py:146-161."""
-        samples, mapping, sample_dist_densities, target_lnpdfs, target_lnpdf_grads = \
-            self.sample_selector.select_samples()
-        self._run_updates(samples, mapping, sample_dist_densities, target_lnpdfs, target_lnpdf_grads)
+        """gmmvi.py:146-161.  Built-in SAMTRON-style module sets take the single-call fast path (optimization/fused.py:
+        the same kernels in the same order, one host call); everything else runs module by module."""
+        if self._fast_path.eligible():
+            self._fast_path.step()
+        else:
+            samples, mapping, sample_dist_densities, target_lnpdfs, target_lnpdf_grads = \
+                self.sample_selector.select_samples()
+            self._run_updates(samples, mapping, sample_dist_densities, target_lnpdfs, target_lnpdf_grads)
         self.num_component_adapter.adapt_number_of_components(self.num_updates)
 
     def _run_updates(self, samples, mapping, sample_dist_densities, target_lnpdfs, target_lnpdf_grads):

@@ -203,6 +203,49 @@ int gmmvi_weight_stepsize_improvement(gmmvi_ctx* ctx, int K, const float* logw_d
                                       float* state_dev, float min_stepsize, float max_stepsize, float inc_factor,
                                       float dec_factor);
 
+/* ---- single-call iteration ------------------------------------------------------------------------------------- */
+/* GMMVI.train_iter() (optimization/gmmvi.py:146-174) for the SAMTRON design choices with a component-based sample
+ * selector at reuse ratio 0: Stein estimator, KL-constrained component update, trust-region or direct weight update,
+ * improvement-based or fixed stepsizes, built-in target.  The call is exactly the composition of the entry points above
+ * in the order the plug-in modules invoke them (one host call instead of ~20), operating on the caller's state arrays. */
+typedef struct gmmvi_samtron_plan {
+    int32_t K, D, N;                      /* components, dimension, samples of this iteration (sum of the counts) */
+    int32_t target_kind;                  /* 0: mixture family (gmmvi_mixture_eval), 1: planar robot */
+    int32_t target_family, target_K;      /* enum gmmvi_family, number of target components */
+    float target_nu;
+    const float* target_packed;           /* [target_K, stride] */
+    const float* target_logw;             /* [target_K] */
+    const float* planar_prior_std;        /* [D] */
+    const float* planar_goals;            /* [G, 2] */
+    int32_t planar_goals_count;
+    float planar_likelihood_std;
+    /* model state (in/out) */
+    float* means; float* chols; float* logw;          /* [K,D], [K,D,D], [K] */
+    const float* packed;                  /* parameter blocks of the CURRENT components [K, stride] */
+    float* packed_new;                    /* out: blocks of the updated components */
+    float* stepsizes; float* last_eta; float* l2; float* num_updates;      /* [K] each */
+    int32_t* success_out;                 /* [K] or NULL */
+    /* sampling */
+    const int32_t* offsets;               /* [K+1] prefix sums of the per-component sample counts */
+    const float* bg_logw;                 /* [K] log(count_k / N): background mixture weights (sample_db.py:225-226) */
+    uint64_t seed, first_index;           /* Philox key / global index of the first new sample */
+    /* SampleDB append targets, already offset to the first free row (sample_db.py:115-124); snapshots may be NULL */
+    float* db_samples; float* db_tlp; float* db_tgrad; int32_t* db_mapping; int32_t mapping_base;
+    float* db_means; float* db_chols; float* db_packed;
+    /* reward / weight history slots (models/gmm_wrapper.py:150-158,182) */
+    const float* reward_prev; const float* reward_last; float* reward_next; float* weight_slot;
+    float* wstate;                        /* [2]: weight stepsize, previous ELBO proxy */
+    /* hyper-parameters */
+    float temperature, l2_init;
+    int32_t component_stepsize_mode;      /* 0 fixed, 1 improvement-based */
+    float cs_min, cs_max, cs_inc, cs_dec;
+    int32_t weight_stepsize_mode;         /* 0 fixed, 1 improvement-based */
+    float ws_min, ws_max, ws_inc, ws_dec;
+    int32_t weight_update_mode;           /* 0 trust-region, 1 direct */
+    int32_t stein_flags;                  /* enum gmmvi_stein_flags (own-samples-only is not supported here) */
+} gmmvi_samtron_plan;
+int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan* plan);
+
 /* ---- multi-GPU exchange (component shards) ----------------------------------------------------- */
 /* RCCL communicator over the ranks of one node; unique_id is the 128-byte ncclUniqueId produced by rank 0. */
 int gmmvi_comm_unique_id(char* out_id_128);

@@ -1,0 +1,76 @@
+"""The single-call iteration (gmmvi_train_iter_samtron, optimization/fused.py) must equal the module-by-module path:
+same kernels, same order, same state arrays -> identical trajectories; and it must step aside whenever a module or
+setting outside its scope is configured."""
+import numpy as np
+import pytest
+
+from helpers import samtron_config, make_oracle, make_device
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(kind, d, k, s, seed, cfg):
+    o = make_oracle(kind, d, k, s, seed, cfg)
+    fast = make_device(kind, d, k, s, seed, cfg, o)
+    slow = make_device(kind, d, k, s, seed, cfg, o)
+    slow._fast_path.enabled = False
+    return o, fast, slow
+
+
+@pytest.mark.parametrize("kind,d,k,s,cfg", [
+    ("stm", 4, 3, 32, samtron_config(32)),
+    ("planar", 10, 4, 50, samtron_config(50)),
+    ("gmm", 20, 8, 64, samtron_config(64, weight_updater="direct", wstep=0.05)),
+    ("gmm", 3, 1, 40, samtron_config(40)),
+    ("stm", 6, 5, 30, samtron_config(30, snis=False, initial_stepsize=0.01)),
+])
+def test_fast_path_equals_modular_path(kind, d, k, s, cfg):
+    o, fast, slow = _pair(kind, d, k, s, 23, cfg)
+    assert fast._fast_path.eligible() and not slow._fast_path.eligible()
+    for it in range(8):
+        fast.train_iter()
+        slow.train_iter()
+        for name in ("means", "chol_cov", "log_weights", "stepsizes", "last_log_etas", "l2_regularizers",
+                     "num_received_updates"):
+            a, b = getattr(fast.model, name).numpy(), getattr(slow.model, name).numpy()
+            np.testing.assert_array_equal(a, b, err_msg=f"iteration {it}: {name}")
+        np.testing.assert_array_equal(fast.model.reward_slot(0).numpy(), slow.model.reward_slot(0).numpy())
+        np.testing.assert_array_equal(fast.weight_stepsize_adapter._state.numpy(),
+                                      slow.weight_stepsize_adapter._state.numpy())
+    np.testing.assert_array_equal(fast.sample_db.samples.numpy(), slow.sample_db.samples.numpy())
+    np.testing.assert_array_equal(fast.sample_db.mapping.numpy(), slow.sample_db.mapping.numpy())
+    np.testing.assert_array_equal(fast.sample_db.means.numpy(), slow.sample_db.means.numpy())
+    np.testing.assert_array_equal(fast.sample_db.target_grads.numpy(), slow.sample_db.target_grads.numpy())
+    assert int(fast.sample_db.num_samples_written) == int(slow.sample_db.num_samples_written)
+    assert int(fast.num_updates) == int(slow.num_updates) == 8
+    np.testing.assert_array_equal(fast.model.weight_history[:, -3:], slow.model.weight_history[:, -3:])
+    np.testing.assert_array_equal(fast.ng_based_updater.last_success.numpy(), slow.ng_based_updater.last_success.numpy())
+
+
+def test_fast_path_with_adaptive_components_and_oracle():
+    ad = {"del_iters": 6, "add_iters": 3, "max_components": 6, "thresholds_for_add_heuristic": [50., 20., 10.],
+          "min_weight_for_del_heuristic": 1e-6, "num_database_samples": 200, "num_prior_samples": 0}
+    cfg = samtron_config(40, adaptive=ad)
+    o, fast, slow = _pair("gmm", 3, 2, 40, 9, cfg)
+    for it in range(12):
+        o.train_iter(); fast.train_iter(); slow.train_iter()
+    assert fast.model.num_components == slow.model.num_components == o.model.num_components > 2
+    np.testing.assert_array_equal(fast.model.means.numpy(), slow.model.means.numpy())
+    np.testing.assert_allclose(fast.model.means.numpy(), o.model.means, rtol=0.05, atol=0.05)
+
+
+def test_fast_path_steps_aside():
+    cfg = samtron_config(30, reuse_ratio=2.0)
+    o, fast, _ = _pair("stm", 4, 3, 30, 5, cfg)
+    assert not fast._fast_path.eligible()                       # sample reuse needs the ESS on the host
+    cfg = samtron_config(30, updater="direct", initial_stepsize=0.01)
+    o, fast, _ = _pair("gmm", 4, 3, 30, 5, cfg)
+    assert not fast._fast_path.eligible()
+    cfg = samtron_config(30, own=True)
+    o, fast, _ = _pair("gmm", 4, 3, 30, 5, cfg)
+    assert not fast._fast_path.eligible()
+    cfg = samtron_config(30)
+    o, fast, _ = _pair("gmm", 4, 3, 30, 5, cfg)
+    fast.ng_based_updater.want_info = True
+    assert not fast._fast_path.eligible()
+    fast.train_iter()                                            # and the modular path still runs
