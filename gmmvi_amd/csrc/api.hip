@@ -184,6 +184,39 @@ int gmmvi_copy_batch(gmmvi_ctx* ctx, int n, void* const* dst_dev, const void* co
     return GMMVI_OK;
 }
 
+__global__ void fill_strided_kernel(float* dst, size_t stride, size_t count, float v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += step) dst[i * stride] = v;
+}
+
+int gmmvi_fill_strided_f32(gmmvi_ctx* ctx, float* dst_dev, size_t stride, size_t count, float value) {
+    if (count == 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, dst_dev != nullptr && stride >= 1);
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(fill_strided_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dst_dev, stride, count, value);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+// one thread per row: shift columns idx+1 .. K-1 one to the left (ascending, so the in-place move is safe)
+__global__ void remove_column_kernel(float* a, int rows, size_t stride, int K, int idx) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float* row = a + (size_t)r * stride;
+    for (int c = idx; c + 1 < K; ++c) row[c] = row[c + 1];
+}
+
+int gmmvi_remove_column_f32(gmmvi_ctx* ctx, float* a_dev, int rows, size_t stride, int K, int idx) {
+    GMMVI_ARG_CHECK(ctx, a_dev && rows >= 0 && K >= 1 && idx >= 0 && idx < K && stride >= (size_t)K);
+    if (rows == 0 || idx == K - 1) return GMMVI_OK;
+    hipLaunchKernelGGL(remove_column_kernel, dim3((rows + 127) / 128), dim3(128), 0, ctx->stream, a_dev, rows, stride, K,
+                       idx);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
 __global__ void add_scalar_i32_kernel(int32_t* dst, const int32_t* src, int32_t v, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;

@@ -1,9 +1,10 @@
 """GmmWrapper: per-component learner state beside the model (reference: src/gmmvi/models/gmm_wrapper.py:4-182).
 
 State the kernels read/write every iteration lives in HBM (stepsizes, l2_regularizers, last_log_etas,
-num_received_updates, and the reward / weight histories as *ring buffers* [H, K] instead of the reference's
-concat-shift of a [K, 10000] tensor twice per iteration, gmm_wrapper.py:158,:182).  ``reward_history`` and
-``weight_history`` materialise the reference's [K, H] layout (newest entry last) on demand.
+num_received_updates, and the reward / weight histories as *ring buffers* [H, Kcap] instead of the reference's
+concat-shift of a [K, 10000] tensor twice per iteration, gmm_wrapper.py:158,:182).  Kcap >= K is a capacity: adding a
+component fills one column, removing one shifts the columns on the device -- no host round trip of the history.
+``reward_history`` / ``weight_history`` materialise the reference's [K, H] layout (newest entry last) on demand.
 """
 import numpy as np
 
@@ -37,8 +38,9 @@ class GmmWrapper:
         self.num_received_updates = ctx.zeros((k,))                              # :70
         self.stepsizes = ctx.full((k,), self.initial_stepsize)                   # :71
         h = self.max_reward_history_length
-        self._reward_ring = ctx.full((h, k), FLOAT32_MIN)                        # :72
-        self._weight_ring = ctx.full((h, k), FLOAT32_MIN)                        # :74
+        self._kcap = max(64, 2 * k)
+        self._reward_ring = ctx.full((h, self._kcap), FLOAT32_MIN)               # :72
+        self._weight_ring = ctx.full((h, self._kcap), FLOAT32_MIN)               # :74
         self._t_reward = 0          # number of store_rewards() calls
         self._t_weight = 0          # number of replace_weights() calls
         self.unique_component_ids = np.arange(k, dtype=np.int32)                 # :76
@@ -53,28 +55,34 @@ class GmmWrapper:
     def _slot(self, t):
         return t % self.max_reward_history_length
 
+    def _row(self, ring, slot):
+        """Device view [K] of one time slot."""
+        return ring.rows(slot, slot + 1).reshape(-1).rows(0, self.model.num_components)
+
     def reward_slot(self, back):
         """Device view [K] of reward_history[:, -1-back] (back = 0: newest)."""
-        s = self._slot(self._t_reward - 1 - back)
-        return self._reward_ring.rows(s, s + 1).reshape(-1)
+        return self._row(self._reward_ring, self._slot(self._t_reward - 1 - back))
 
     def next_reward_slot(self):
         """Device view the next store_rewards() writes to; advance with commit_rewards()."""
-        s = self._slot(self._t_reward)
-        return self._reward_ring.rows(s, s + 1).reshape(-1)
+        return self._row(self._reward_ring, self._slot(self._t_reward))
+
+    def next_weight_slot(self):
+        return self._row(self._weight_ring, self._slot(self._t_weight))
 
     def commit_rewards(self):
         self._t_reward += 1
 
     def _materialise(self, ring, t, last_n=None):
         h = self.max_reward_history_length
+        k = self.model.num_components
         n = h if last_n is None else min(int(last_n), h)
         start = (t - n) % h                                  # oldest requested slot
         if start + n <= h:
             host = ring.rows(start, start + n).numpy()
         else:                                                # wraps around the ring: two contiguous pieces
             host = np.concatenate([ring.rows(start, h).numpy(), ring.rows(0, start + n - h).numpy()])
-        return np.ascontiguousarray(host.T)                  # [K, n], newest last
+        return np.ascontiguousarray(host[:, :k].T)           # [K, n], newest last
 
     @property
     def reward_history(self):
@@ -104,8 +112,7 @@ class GmmWrapper:
 
     def record_weights(self):
         """weight_history shift of :182 for weights already normalised on the device."""
-        s = self._slot(self._t_weight)
-        hip_ops.exp_into(self.model.ctx, self._weight_ring.rows(s, s + 1).reshape(-1), self.model.log_weights)
+        hip_ops.exp_into(self.model.ctx, self.next_weight_slot(), self.model.log_weights)
         self._t_weight += 1
 
     def replace_weights(self, new_log_weights):
@@ -113,16 +120,24 @@ class GmmWrapper:
         self.model.replace_weights(new_log_weights)
         self.record_weights()
 
-    def _rebuild_rings(self, rh, wh):
+    def _grow_rings(self, k_needed):
+        if k_needed <= self._kcap:
+            return
         ctx = self.model.ctx
-        self._reward_ring = ctx.asarray(np.ascontiguousarray(rh.T))
-        self._weight_ring = ctx.asarray(np.ascontiguousarray(wh.T))
-        self._t_reward = self._t_weight = 0                  # slot 0 = oldest again
+        new_cap = max(2 * self._kcap, k_needed)
+        h = self.max_reward_history_length
+        for name in ("_reward_ring", "_weight_ring"):
+            old = getattr(self, name).numpy()                 # rare (capacity doubling): through the host
+            new = np.full((h, new_cap), FLOAT32_MIN, np.float32)
+            new[:, :self._kcap] = old
+            setattr(self, name, ctx.asarray(new))
+        self._kcap = new_cap
 
     def add_component(self, initial_weight, initial_mean, initial_cov, adding_threshold, initial_entropy):
         """:90-127."""
         ctx = self.model.ctx
-        rh, wh = self.reward_history, self.weight_history
+        k_old = self.model.num_components
+        self._grow_rings(k_old + 1)
         self.model.add_component(initial_weight, initial_mean, initial_cov)
         self.max_component_id += 1
         self.unique_component_ids = np.append(self.unique_component_ids, np.int32(self.max_component_id))
@@ -132,9 +147,11 @@ class GmmWrapper:
         self.num_received_updates = app(self.num_received_updates, 0.0)
         self.stepsizes = app(self.stepsizes, self.initial_stepsize)
         h = self.max_reward_history_length
-        rh = np.concatenate([rh, np.full((1, h), FLOAT32_MIN, np.float32)], axis=0)
-        wh = np.concatenate([wh, np.full((1, h), np.float32(initial_weight), np.float32)], axis=0)
-        self._rebuild_rings(rh, wh)
+        # the new component's history column: rewards float32.min (:121-122), weights initial_weight (:123-124)
+        ctx.check(ctx.lib.gmmvi_fill_strided_f32(ctx.handle, self._reward_ring.ptr + 4 * k_old, self._kcap, h,
+                                                 FLOAT32_MIN))
+        ctx.check(ctx.lib.gmmvi_fill_strided_f32(ctx.handle, self._weight_ring.ptr + 4 * k_old, self._kcap, h,
+                                                 float(initial_weight)))
         self.adding_thresholds = np.append(self.adding_thresholds,
                                            np.asarray(adding_threshold, np.float32).reshape(-1))
         self.initial_entropies = np.append(self.initial_entropies,
@@ -144,7 +161,7 @@ class GmmWrapper:
         """:129-148."""
         ctx = self.model.ctx
         idx = int(idx)
-        rh, wh = self.reward_history, self.weight_history
+        k_old = self.model.num_components
         self.model.remove_component(idx)
         self.unique_component_ids = np.delete(self.unique_component_ids, idx)
         rm = lambda dev: ctx.asarray(np.delete(dev.numpy(), idx))
@@ -152,6 +169,8 @@ class GmmWrapper:
         self.last_log_etas = rm(self.last_log_etas)
         self.num_received_updates = rm(self.num_received_updates)
         self.stepsizes = rm(self.stepsizes)
-        self._rebuild_rings(np.delete(rh, idx, axis=0), np.delete(wh, idx, axis=0))
+        h = self.max_reward_history_length
+        for ring in (self._reward_ring, self._weight_ring):
+            ctx.check(ctx.lib.gmmvi_remove_column_f32(ctx.handle, ring.ptr, h, self._kcap, k_old, idx))
         self.adding_thresholds = np.delete(self.adding_thresholds, idx)
         self.initial_entropies = np.delete(self.initial_entropies, idx)

@@ -144,8 +144,7 @@ class SamtronFastPath:
         p.db_packed = db._packed.buf.ptr + c0 * stride * 4
         p.reward_prev, p.reward_last = m.reward_slot(1).ptr, m.reward_slot(0).ptr
         p.reward_next = m.next_reward_slot().ptr
-        wslot = m._slot(m._t_weight)
-        p.weight_slot = m._weight_ring.ptr + wslot * k * 4
+        p.weight_slot = m.next_weight_slot().ptr
         ws, cs, wu = g.weight_stepsize_adapter, g.component_stepsize_adapter, g.weight_updater
         p.wstate = ws._state.ptr
         p.temperature, p.l2_init = float(g.temperature), float(m.initial_regularizer)

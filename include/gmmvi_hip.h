@@ -71,6 +71,12 @@ int gmmvi_gather_rows(gmmvi_ctx* ctx, const void* src_dev, const int32_t* idx_de
 /* Up to 8 device-to-device copies in ONE launch (the per-iteration SampleDB append of samples, target values,
  * gradients and component snapshots, optimization/sample_db.py:115-124; sizes in bytes, multiples of 4). */
 int gmmvi_copy_batch(gmmvi_ctx* ctx, int n, void* const* dst_dev, const void* const* src_dev, const size_t* nbytes);
+/* dst[i * stride] = value, i < count: a new component's column of the [H, Kcap] reward / weight history rings
+ * (models/gmm_wrapper.py:121-124). */
+int gmmvi_fill_strided_f32(gmmvi_ctx* ctx, float* dst_dev, size_t stride, size_t count, float value);
+/* a[r, idx:K-1] = a[r, idx+1:K] for every row r of a [rows, stride] array: GmmWrapper.remove_component's history
+ * update (models/gmm_wrapper.py:145-146). */
+int gmmvi_remove_column_f32(gmmvi_ctx* ctx, float* a_dev, int rows, size_t stride, int K, int idx);
 /* dst[i] = src[i] + value: the mapping offset of SampleDB.add_samples (optimization/sample_db.py:115). */
 int gmmvi_add_scalar_i32(gmmvi_ctx* ctx, int32_t* dst_dev, const int32_t* src_dev, int32_t value, size_t count);
 /* dst[i] = exp(src[i])  (GMM.weights, models/gmm.py:171; weight history, models/gmm_wrapper.py:182). */

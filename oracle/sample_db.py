@@ -66,7 +66,8 @@ class SampleDB:
 
     def get_random_sample(self, n, rng):
         """sample_db.py:137-152 (tf.random.shuffle replaced by a NumPy Generator permutation)."""
-        idx = rng.permutation(self.samples.shape[0])[:n]
+        total = self.samples.shape[0]
+        idx = rng.choice(total, size=min(int(n), total), replace=False)     # == shuffle(range(total))[:n] in law
         return self.samples[idx], self.target_lnpdfs[idx]
 
     def gaussian_log_pdf(self, mean, chol, inv_chol, x):
