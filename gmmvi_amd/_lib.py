@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libgmmvi_hip.so")
 GAUSS, STUDENT_T = 0, 1
 SELF_NORMALIZED, OWN_SAMPLES_ONLY = 1, 2
 MAX_DIM = 64
+MORE_MAX_DIM = 21
 
 
 class GmmviError(RuntimeError):
@@ -59,6 +60,7 @@ _PROTOS = {
     "gmmvi_philox_normals": (_i, [_p, _u64, _u64, _i, _i, _i, _p]),
     "gmmvi_philox_uniforms": (_i, [_p, _u64, _u64, _i, _i, _p]),
     "gmmvi_stein": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
+    "gmmvi_more": (_i, [_p, _i, _i, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "gmmvi_update_components_kl": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
     "gmmvi_update_components_kl_reference": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
     "gmmvi_update_components_direct": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p]),

@@ -141,6 +141,29 @@ def stein(ctx, packed, x, ld, qgrad, bg, tgrad, d, mapping=None, map_offset=0, s
     return h_neg, g_neg
 
 
+def more(ctx, packed, chols, x, ld, logq, bg, tlp, l2, d, mapping=None, map_offset=0, self_normalized=True,
+         own_samples_only=False):
+    """MORE estimate (gmmvi_more) -> (h_neg [K,D,D], g_neg [K,D])."""
+    k = packed.shape[0]
+    n = x.shape[0]
+    if d > _lib.MORE_MAX_DIM:
+        raise ValueError(f"MORE estimator: D = {d} > {_lib.MORE_MAX_DIM} is not supported by the HIP kernel")
+    _req(packed, (k, packed_stride(d)), name="packed"); _req(chols, (k, d, d), name="chols"); _req(x, (n, d), name="x")
+    _req(logq, (n,), name="logq"); _req(tlp, (n,), name="tlp"); _req(l2, (k,), name="l2")
+    if own_samples_only:
+        _req(mapping, (n,), I32, "mapping")
+    else:
+        _req(ld, (k, n), name="ld"); _req(bg, (n,), name="bg")
+    flags = (_lib.SELF_NORMALIZED if self_normalized else 0) | (_lib.OWN_SAMPLES_ONLY if own_samples_only else 0)
+    h_neg = ctx.empty((k, d, d))
+    g_neg = ctx.empty((k, d))
+    ctx.check(ctx.lib.gmmvi_more(ctx.handle, k, d, packed.ptr, chols.ptr, x.ptr, n, None if ld is None else ld.ptr,
+                                 logq.ptr, None if bg is None else bg.ptr, tlp.ptr,
+                                 None if mapping is None else mapping.ptr, int(map_offset), flags, l2.ptr, h_neg.ptr,
+                                 g_neg.ptr))
+    return h_neg, g_neg
+
+
 def update_components_kl(ctx, means, chols, h_neg, g_neg, stepsizes, temperature, l2_init, last_eta, l2, num_updates,
                          want_info=False, reference=False, want_packed=False):
     """-> (success, kl | None, probes | None[, packed])."""

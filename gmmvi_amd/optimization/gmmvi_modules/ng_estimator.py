@@ -64,10 +64,39 @@ class SteinNgEstimator(NgEstimator):
 
 
 class MoreNgEstimator(NgEstimator):
-    """ng_estimator.py:266-376 (MORE, codename letter "Z").  Listed as "next" in SURVEY.md 8(f)-3: not part of the
-    first hot-path slice; constructing it fails loudly rather than falling back to a CPU path."""
+    """ng_estimator.py:266-376 (MORE, codename letter "Z"): importance-weighted quadratic ridge regression of the
+    rewards on the samples whitened by each component (least_squares.py:126-191), as one f32-MFMA Gram contraction
+    and one in-LDS Cholesky solve per component (csrc/more.hip).  D <= 21."""
 
     def __init__(self, temperature, model, only_use_own_samples: bool, initial_l2_regularizer: float,
                  use_self_normalized_importance_weights: bool):
-        raise NotImplementedError("MoreNgEstimator has no HIP kernel yet (SURVEY.md 8(f)-3); use ng_estimator_type "
-                                  "'Stein'")
+        super().__init__(temperature, model, True, only_use_own_samples,                   # :291 (True, as upstream)
+                         use_self_normalized_importance_weights)
+        l2 = model.l2_regularizers.numpy()
+        if not np.all(l2 == np.float32(initial_l2_regularizer)):                          # :293
+            raise ValueError("model.l2_regularizers must equal initial_l2_regularizer")
+        if model.num_dimensions > 21:
+            raise ValueError("MoreNgEstimator: the HIP kernel supports D <= 21 (DESIGN.md section 7)")
+        self.last_model_densities = None
+
+    def get_expected_hessian_and_grad(self, samples, mapping, background_densities, target_lnpdfs,
+                                      target_lnpdfs_grads=None):
+        """-> (expected_hessian_neg [K,D,D], expected_gradient_neg [K,D]); the gradients are not used (:296-299)."""
+        m = self._model
+        ctx = m.ctx
+        x = ctx.asarray(samples)
+        bg = ctx.asarray(background_densities)
+        tlp = ctx.asarray(target_lnpdfs)
+        k, d = m.num_components, m.num_dimensions
+        model_densities, ld = m.log_densities_also_individual(x)                          # :344
+        self.last_model_densities = model_densities
+        map_dev, map_offset = None, 0
+        if self._only_use_own_samples:
+            map_dev = ctx.asarray(mapping, np.int32)
+            host = getattr(m, "_mapping_max_hint", None)
+            mx = int(host) if host is not None else int(np.asarray(map_dev.numpy()).max())
+            map_offset = k - 1 - mx                                                        # :342
+        return hip_ops.more(ctx, m.packed, m.chol_cov, x, ld, model_densities, bg, tlp, m.l2_regularizers, d,
+                            mapping=map_dev, map_offset=map_offset,
+                            self_normalized=self._use_self_normalized_importance_weights,
+                            own_samples_only=self._only_use_own_samples)

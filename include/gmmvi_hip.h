@@ -50,6 +50,7 @@ enum gmmvi_stein_flags {
     GMMVI_OWN_SAMPLES_ONLY = 2 /* ng_estimator.py:110-118 */
 };
 
+#define GMMVI_MORE_MAX_DIM 21  /* gmmvi_more: the F x F ridge system (F = D(D+1)/2 + D + 1) is factorised in LDS */
 #define GMMVI_MAX_DIM 64       /* register-resident kernels: D <= 64 (D = 300 needs the blocked path) */
 
 /* ---- context, errors, memory ------------------------------------------------------------------------ */
@@ -154,6 +155,17 @@ int gmmvi_philox_uniforms(gmmvi_ctx* ctx, uint64_t seed, uint64_t first_index, i
 int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* X_dev, int N,
                 const float* ld_dev, const float* qgrad_dev, const float* bg_dev, const float* tgrad_dev,
                 const int32_t* mapping_dev, int map_offset, int flags, float* H_neg_out_dev, float* g_neg_out_dev);
+
+/* MoreNgEstimator.get_expected_hessian_and_grad (gmmvi_modules/ng_estimator.py:296-376) with QuadFunc.fit_quadratic
+ * (optimization/least_squares.py:126-191, RegressionFunc.fit :34-76): importance-weighted quadratic ridge regression of
+ * the rewards tlp[n] - logq[n] on the samples whitened by each component; flags = enum gmmvi_stein_flags.
+ * Inputs: packed blocks + chols[K,D,D] of the model, X[N,D], ld[K,N] and logq[N] (gmmvi_mixture_eval on the same X),
+ * bg[N], tlp[N], mapping[N] (GMMVI_OWN_SAMPLES_ONLY only), l2[K] ridge coefficients (GmmWrapper.l2_regularizers).
+ * Outputs: H_neg[K,D,D], g_neg[K,D]; NaN for a component whose ridge system is not positive definite.  D <= 21. */
+int gmmvi_more(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* chols_dev, const float* X_dev, int N,
+               const float* ld_dev, const float* logq_dev, const float* bg_dev, const float* tlp_dev,
+               const int32_t* mapping_dev, int map_offset, int flags, const float* l2_dev, float* H_neg_out_dev,
+               float* g_neg_out_dev);
 
 /* ---- component updates --------------------------------------------------------------------------------------- */
 /* KLConstrainedNgBasedComponentUpdater.apply_NG_update (gmmvi_modules/ng_based_component_updater.py:431-524,

@@ -5,13 +5,14 @@ from oracle import targets as otargets, train as otrain
 
 
 def samtron_config(desired_samples, reuse_ratio=0.0, initial_stepsize=0.1, adaptive=None, updater="trust-region",
-                   weight_updater="trust-region", snis=True, own=False, wstep=1.0):
+                   weight_updater="trust-region", snis=True, own=False, wstep=1.0, estimator="Stein"):
     """SAMTRON-style config dict with the keys of the reference's example_config.yml."""
     cfg = {
         "temperature": 1.0, "use_sample_database": True, "max_database_size": 10000000, "seed": 0,
         "model_initialization": {"use_diagonal_covs": False, "prior_mean": 0., "initial_cov": 1.0},
-        "ng_estimator_type": "Stein",
-        "ng_estimator_config": {"only_use_own_samples": own, "use_self_normalized_importance_weights": snis},
+        "ng_estimator_type": estimator,
+        "ng_estimator_config": dict({"only_use_own_samples": own, "use_self_normalized_importance_weights": snis},
+                                    **({"initial_l2_regularizer": 1e-12} if estimator == "MORE" else {})),
         "sample_selector_type": "component-based",
         "sample_selector_config": {"desired_samples_per_component": desired_samples,
                                    "ratio_reused_samples_to_desired": reuse_ratio},
@@ -68,6 +69,7 @@ def make_oracle(kind, d, k, s, seed, cfg, dtype=np.float64):
         tgt, model, temperature=cfg["temperature"], seed=seed,
         desired_samples_per_component=cfg["sample_selector_config"]["desired_samples_per_component"],
         ratio_reused_samples_to_desired=cfg["sample_selector_config"]["ratio_reused_samples_to_desired"],
+        ng_estimator=cfg["ng_estimator_type"],
         only_use_own_samples=cfg["ng_estimator_config"]["only_use_own_samples"],
         use_self_normalized_importance_weights=cfg["ng_estimator_config"]["use_self_normalized_importance_weights"],
         updater=cfg["ng_based_updater_type"] if cfg["ng_based_updater_type"] != "iBLR" else "iblr",

@@ -178,6 +178,68 @@ def test_stein_own_samples(ctx, rng):
     np.testing.assert_allclose(g.numpy(), rg, rtol=2e-3, atol=2e-3 * np.abs(rg).max())
 
 
+@pytest.mark.parametrize("k,d,n", [(3, 4, 400), (8, 20, 4000), (5, 10, 1500), (2, 2, 200), (4, 16, 2500), (3, 21, 3000),
+                                   (1, 7, 640), (20, 20, 6000)])
+@pytest.mark.parametrize("snis", [True, False])
+def test_more(ctx, rng, k, d, n, snis):
+    """gmmvi_more against the oracle's restatement of ng_estimator.py:296-376 / least_squares.py:126-191."""
+    from oracle import more as omore
+    m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    xd = ctx.asarray(x)
+    ld, lp, _ = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_lp=True)
+    l2 = np.full(k, 1e-6)
+    h, g = ops().more(ctx, packed, chols, xd, ld, lp, ctx.asarray(bg), ctx.asarray(tlp), ctx.asarray(l2), d,
+                      self_normalized=snis)
+    rh, rg = omore.get_expected_hessian_and_grad(m, l2, x, mapping, bg, tlp, False, snis)
+    h, g = h.numpy(), g.numpy()
+    assert np.all(np.isfinite(h)) and np.all(np.isfinite(g))
+    scale_h = np.abs(rh).max(axis=(1, 2), keepdims=True)
+    scale_g = np.abs(rg).max(axis=1, keepdims=True)
+    # fp32 normal equations of a quartic design: error ~ cond(A) * 2^-24 of the per-component magnitude
+    assert np.all(np.abs(h - rh) <= 2e-2 * scale_h + 1e-5), np.abs(h - rh).max() / scale_h.max()
+    assert np.all(np.abs(g - rg) <= 2e-2 * scale_g + 1e-5), np.abs(g - rg).max() / scale_g.max()
+
+
+def test_more_own_samples(ctx, rng):
+    from oracle import more as omore
+    k, d, n = 3, 5, 900
+    m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    xd = ctx.asarray(x)
+    ld, lp, _ = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_lp=True)
+    mp = mapping + 4
+    l2 = np.full(k, 1e-6)
+    h, g = ops().more(ctx, packed, chols, xd, ld, lp, ctx.asarray(bg), ctx.asarray(tlp), ctx.asarray(l2), d,
+                      mapping=ctx.asarray(mp, np.int32), map_offset=k - 1 - int(mp.max()), own_samples_only=True)
+    rh, rg = omore.get_expected_hessian_and_grad(m, l2, x, mp, bg, tlp, True, True)
+    np.testing.assert_allclose(h.numpy(), rh, rtol=2e-2, atol=2e-2 * np.abs(rh).max())
+    np.testing.assert_allclose(g.numpy(), rg, rtol=2e-2, atol=2e-2 * np.abs(rg).max())
+
+
+def test_more_quadratic_reward_is_exact(ctx, rng):
+    """A reward that IS quadratic is recovered whatever the weights: H = -2A' form, g from the linear term."""
+    from oracle import gmm as ogmm2
+    k, d, n = 2, 6, 1200
+    m, x, mapping, _, _, bg = _stein_inputs(rng, k, d, n)
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    xd = ctx.asarray(x)
+    ld, lp, _ = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_lp=True)
+    b = rng.normal(size=(d, d)); q = b @ b.T / d + np.eye(d)
+    lin = rng.normal(size=d)
+    x32 = xd.numpy().astype(np.float64)
+    rew = -0.5 * np.einsum("ni,ij,nj->n", x32, q, x32) + x32 @ lin + 0.3
+    tlp = rew + lp.numpy().astype(np.float64)              # reward = tlp - logq
+    l2 = np.full(k, 1e-10)
+    h, g = ops().more(ctx, packed, chols, xd, ld, lp, ctx.asarray(bg), ctx.asarray(tlp), ctx.asarray(l2), d)
+    for i in range(k):
+        np.testing.assert_allclose(h.numpy()[i], q, rtol=0, atol=3e-2 * np.abs(q).max())
+        np.testing.assert_allclose(g.numpy()[i], q @ m.means[i] - lin, rtol=0, atol=3e-2 * np.abs(q @ m.means[i] - lin).max())
+
+
 def _update_inputs(rng, k, d):
     m = random_gmm(rng, k, d)
     hs = np.stack([(lambda b: b @ b.T / d)(rng.normal(size=(d, d))) for _ in range(k)])
