@@ -33,6 +33,7 @@ WORKLOADS = {
     "c2": ("stm", 20, 50, 100),        # BASELINE configs[1]: K=50, N=5000
     "c3": ("gmm", 50, 100, 100),       # BASELINE configs[2]: GMM target D=50, K=100, N=10k
     "c4": ("planar", 10, 200, 100),    # BASELINE configs[3] on one GPU: planar-4, K=200, N=20k
+    "ns_more": ("stm", 20, 100, 100, "MORE"),   # north-star shape with the MORE estimator ("ZAMTRON") instead of Stein
     "tiny": ("stm", 4, 4, 16),         # host-overhead probe (kernels are empty; time = launch path)
 }
 
@@ -44,6 +45,8 @@ def kernel_flops(name, n, k, d):
         "mixture_eval": p * (d * d + 4 * d),              # forward substitution + square-sum + LSE
         "mixture_eval_grad": p * (2 * d * d + 8 * d),     # + backward substitution + responsibility-weighted gradient
         "stein_partial": p * (4 * d * d + 6 * d),         # recompute y (2D^2) + rank-1 accumulate (2D^2)
+        # MORE: lower triangle of the (F+1)x(F+1) Gram matrix of [phi; reward], F = D(D+1)/2 + D + 1 (2 flop per MAC)
+        "more_gram": p * ((d * (d + 1) // 2 + d + 2) * (d * (d + 1) // 2 + d + 3) + d * d),
     }.get(name)
 
 
@@ -56,7 +59,8 @@ def build(workload, n_gpus, rank, seed=0):
     from gmmvi_amd.experiments.target_distributions.gmm import GMM_LNPDF
     from gmmvi_amd.experiments.target_distributions.student_t_mixture import StudentTMixture_LNPDF
     from gmmvi_amd.experiments.target_distributions.planar_robot import PlanarRobot
-    kind, d, k_per_gpu, s1 = WORKLOADS[workload]
+    kind, d, k_per_gpu, s1 = WORKLOADS[workload][:4]
+    estimator = (WORKLOADS[workload] + ("Stein",))[4]
     k_total = k_per_gpu * n_gpus
     s = int(np.ceil(s1 / n_gpus))
     rng = np.random.default_rng(seed)
@@ -76,7 +80,7 @@ def build(workload, n_gpus, rank, seed=0):
     init_rng = np.random.default_rng(seed + 1)
     means = (np.asarray(prior_scale) * init_rng.standard_normal((k_total, d))).astype(np.float32)
     covs = np.broadcast_to((np.asarray(initial_cov) * np.eye(d)).astype(np.float32), (k_total, d, d))
-    cfg = samtron_config(s, initial_stepsize=0.1)
+    cfg = samtron_config(s, initial_stepsize=0.1, estimator=estimator)
     cfg["model_initialization"].update(prior_mean=0.0, initial_cov=initial_cov)
     return dict(kind=kind, d=d, k_total=k_total, s=s, n_total=k_total * s, cfg=cfg, target=tgt, oracle_target=ot,
                 means=means, covs=np.ascontiguousarray(covs), seed=seed + 2, FullCovGMM=FullCovGMM,
@@ -97,7 +101,7 @@ def make_oracle(w):
     from oracle import train as otrain, gmm as ogmm
     cfg = w["cfg"]
     model = ogmm.FullCovGMM(np.ones(w["k_total"]) / w["k_total"], w["means"], w["covs"])
-    return otrain.OracleGMMVI(w["oracle_target"], model, seed=w["seed"],
+    return otrain.OracleGMMVI(w["oracle_target"], model, seed=w["seed"], ng_estimator=cfg["ng_estimator_type"],
                               desired_samples_per_component=w["s"], ratio_reused_samples_to_desired=0.0,
                               component_stepsize_config=cfg["component_stepsize_adapter_config"],
                               weight_stepsize_config=cfg["weight_stepsize_adapter_config"])
@@ -187,7 +191,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {w['kind']} target D={d}, K={k_tot} components "
                                f"({k_local}/GPU), {w['s']} samples/component, N={n_tot} samples/iter, SAMTRON "
-                               f"(Stein, fixed K, reuse ratio 0, KL trust regions, improvement-based stepsizes)",
+                               f"({w['cfg']['ng_estimator_type']}, fixed K, reuse ratio 0, KL trust regions, improvement-based stepsizes)",
                    "K": k_tot, "D": d, "N": n_tot, "parallelism": f"component-shard x{n_gpus}"},
         "roofline": {"kernel": roof_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,

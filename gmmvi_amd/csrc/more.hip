@@ -7,24 +7,32 @@
 // i.e. it solves  (Phi^T W Phi + lambda I') beta = Phi^T W rew   (bias row of I' is zero), then un-whitens.
 //
 //   more_lse_kernel     per component: log sum_n exp(ld[o,n] - bg[n])  (self-normalised weights, :353-356)
-//   more_gram_kernel    the (F+1)x(F+1) Gram matrix of the rows  sqrt(w_n) [phi(z_n); rew_n]  -- one f32-MFMA SYRK per
+//   more_gram_kernel    the (F+1)x(F+1) Gram matrix of the rows  sqrt(w_n) [phi(z_n); rew_n]  -- one fp64-MFMA SYRK per
 //                       component: A = Phi^T W Phi, b = Phi^T W rew and sum w rew^2 in one contraction.  Workgroup =
-//                       (component, sample chunk); per 64-sample tile every wave substitutes z (SGPR-fed L), the four
-//                       waves write the weighted feature rows into one LDS image [F+1][64] and then contract it with
-//                       v_mfma_f32_32x32x2_f32, each wave owning up to PP lower-triangular 32x32 block pairs whose
-//                       accumulators stay in registers over the whole chunk.  Operands are read as ds_read_b128 (four
-//                       k-steps per read; row stride 68 words = conflict-free for the b128 lane groups).
-//   more_solve_kernel   per component: sums the chunk partials in fixed order into a packed lower triangle in LDS, adds the
-//                       ridge, Cholesky-factorises in place (1024 threads), solves, maps the coefficients back
-//                       (least_squares.py:177-189) and emits  H = L^-T Q_w L^-1  and  g = Q mu - lin = -L^-T lin_w.
+//                       (component, sample chunk), 8 waves; per 64-sample tile every wave substitutes z (SGPR-fed L), the
+//                       waves write the weighted fp32 feature rows into one LDS image [F+1][64] and contract it with
+//                       v_mfma_f64_16x16x4_f64 (rows widened exactly to fp64), each wave owning up to PP lower-triangular
+//                       16x16 tile pairs whose accumulators stay in registers over the whole chunk.  Operands are read as
+//                       ds_read_b128 (four k-steps per read).
+//   more_solve_kernel   per component, fp64: sums the chunk partials in fixed order into a register-resident lower
+//                       triangle, adds the ridge, Cholesky-factorises (1024 threads, one barrier per column), back-
+//                       substitutes, maps the coefficients back (least_squares.py:177-189) and emits
+//                       H = L^-T Q_w L^-1  and  g = Q mu - lin = -L^-T lin_w.
 //
-// Sizes: the packed F x F triangle must fit the 160 KB LDS: F + 1 <= 256  <=>  D <= 21.  The ridge system is solved by
-// Cholesky (the reference calls tf.linalg.solve = pivoted LU); a non-positive pivot marks the component's estimate as
-// NaN, which the component updaters treat as a rejected update.
+// Why fp64: the reference's ridge (1e-12) is far below fp32 resolution.  With fewer effective samples than features
+// (the usual state early in a run: 100 samples per component, F = 231 at D = 20) the fp32 normal equations are
+// numerically singular -- an fp32 LU/Cholesky returns noise-dominated coefficients (measured 10x the fp64 answer) or a
+// negative pivot -- while the Gram matrix of the fp32 feature rows accumulated in fp64 keeps its exact rank and the ridge
+// solution is the one the fp64 oracle computes.  MI355X runs fp64 MFMA at half the f32 rate, so this costs ~2x on the
+// contraction, not 10x+.
+//
+// Sizes: the (F+1)x(F+1) triangle is held by one 1024-thread workgroup (36 doubles per thread): F + 1 <= 256  <=>
+// D <= 21.  The ridge system is solved by Cholesky (the reference calls tf.linalg.solve = pivoted LU); a non-positive
+// pivot marks the component's estimate as NaN, which the component updaters treat as a rejected update.
 #include "common.h"
 #include "subst.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -75,15 +83,17 @@ __global__ __launch_bounds__(1024) void more_lse_kernel(int N, const float* __re
     }
 }
 
+// D[i][j] of v_mfma_f64_16x16x4_f64 on gfx950: lane l, register r  ->  i = 4 r + l / 16, j = l % 16 (probed on the
+// hardware: tools/probe/mfma_f64_layout.hip); operands A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16].
 template <int DP, int PP>
-__global__ __launch_bounds__(256, 2) void more_gram_kernel(int D, int N, int tiles_per_chunk, int nb,
-                                                           const float* __restrict__ packed, const float* __restrict__ X,
-                                                           const float* __restrict__ ld, const float* __restrict__ bg,
-                                                           const float* __restrict__ tlp, const float* __restrict__ logq,
-                                                           const int32_t* __restrict__ mapping, int map_offset, int flags,
-                                                           const float* __restrict__ lse, float* __restrict__ slab) {
+__global__ __launch_bounds__(512) void more_gram_kernel(int D, int N, int tiles_per_chunk, int nb,
+                                                        const float* __restrict__ packed, const float* __restrict__ X,
+                                                        const float* __restrict__ ld, const float* __restrict__ bg,
+                                                        const float* __restrict__ tlp, const float* __restrict__ logq,
+                                                        const int32_t* __restrict__ mapping, int map_offset, int flags,
+                                                        const float* __restrict__ lse, double* __restrict__ slab) {
     using PK = Pack<DP>;
-    extern __shared__ float phi[];                     // [32 nb][PHI_LD]
+    extern __shared__ float phi[];                     // [16 nb][PHI_LD]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,30 +106,28 @@ __global__ __launch_bounds__(256, 2) void more_gram_kernel(int D, int N, int til
     const float* __restrict__ P = packed + (size_t)k * PK::STRIDE;
     const float lse_k = self_norm ? lse[k] : 0.f;
 
-    // block pairs (bi >= bc) of this wave: p = wave + 4 pp
+    // 16x16 tile pairs (bi >= bc) of this wave: p = wave + 8 pp
     int row_of[PP], col_of[PP];
 #pragma unroll
     for (int pp = 0; pp < PP; ++pp) {
-        const int p = wave + 4 * pp;
+        const int p = wave + 8 * pp;
         int bi = 0;
         while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
         row_of[pp] = (p < n_pairs) ? bi : -1;
         col_of[pp] = p - bi * (bi + 1) / 2;
     }
-    f32x16 acc[PP];
+    f64x4 acc[PP];
 #pragma unroll
-    for (int pp = 0; pp < PP; ++pp)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) acc[pp][t] = 0.f;
+    for (int pp = 0; pp < PP; ++pp) acc[pp] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-    for (int e = tid; e < 32 * nb * PHI_LD; e += 256) phi[e] = 0.f;       // rows > F stay zero for the whole kernel
+    for (int e = tid; e < 16 * nb * PHI_LD; e += 512) phi[e] = 0.f;       // rows > F stay zero for the whole kernel
     __syncthreads();
 
-    const int col = lane & 31, half = lane >> 5;
+    const int r16 = lane & 15, kg = lane >> 4;
     const int tile_begin = chunk * tiles_per_chunk;
     const int tile_end = min((N + 63) / 64, tile_begin + tiles_per_chunk);
     for (int tile = tile_begin; tile < tile_end; ++tile) {
-        // ---- every wave whitens the same 64 samples (lane = sample); each writes a quarter of the feature rows ----------
+        // ---- every wave whitens the same 64 samples (lane = sample); each writes an eighth of the feature rows ----------
         const int n = tile * 64 + lane;
         const bool valid = n < N;
         float x[DP], z[DP];
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void more_gram_kernel(int D, int N, int til
 #pragma unroll
                 for (int j = i; j < DP; ++j) {
                     if (j < D) {
-                        if ((f & 3) == wave) phi[f * PHI_LD + lane] = live ? szi * z[j] : 0.f;   // least_squares.py:113-124
+                        if ((f & 7) == wave) phi[f * PHI_LD + lane] = live ? szi * z[j] : 0.f;   // least_squares.py:113-124
                         ++f;
                     }
                 }
@@ -151,150 +159,187 @@ __global__ __launch_bounds__(256, 2) void more_gram_kernel(int D, int N, int til
         }
 #pragma unroll
         for (int i = 0; i < DP; ++i)
-            if (i < D && ((T2 + i) & 3) == wave) phi[(T2 + i) * PHI_LD + lane] = live ? sw * z[i] : 0.f;
-        if (((F - 1) & 3) == wave) phi[(F - 1) * PHI_LD + lane] = live ? sw : 0.f;
-        if ((F & 3) == wave) phi[F * PHI_LD + lane] = live ? sw * rew : 0.f;
+            if (i < D && ((T2 + i) & 7) == wave) phi[(T2 + i) * PHI_LD + lane] = live ? sw * z[i] : 0.f;
+        if (((F - 1) & 7) == wave) phi[(F - 1) * PHI_LD + lane] = live ? sw : 0.f;
+        if ((F & 7) == wave) phi[F * PHI_LD + lane] = live ? sw * rew : 0.f;
         __syncthreads();
-        // ---- contraction over the 64 samples --------------------------------------------------------------------------
+        // ---- contraction over the 64 samples: fp32 rows widened (exactly) to fp64, fp64 accumulation --------------------
 #pragma unroll
         for (int pp = 0; pp < PP; ++pp) {
             if (row_of[pp] < 0) continue;
-            const float* pa = phi + (32 * row_of[pp] + col) * PHI_LD + 4 * half;
-            const float* pb = phi + (32 * col_of[pp] + col) * PHI_LD + 4 * half;
+            const float* pa = phi + (16 * row_of[pp] + r16) * PHI_LD + 4 * kg;
+            const float* pb = phi + (16 * col_of[pp] + r16) * PHI_LD + 4 * kg;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 a4 = *reinterpret_cast<const float4*>(pa + 8 * q);
-                const float4 b4 = *reinterpret_cast<const float4*>(pb + 8 * q);
-                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[pp], 0, 0, 0);
-                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[pp], 0, 0, 0);
-                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[pp], 0, 0, 0);
-                acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[pp], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                const float4 a4 = *reinterpret_cast<const float4*>(pa + 16 * q);
+                const float4 b4 = *reinterpret_cast<const float4*>(pb + 16 * q);
+                acc[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.x, (double)b4.x, acc[pp], 0, 0, 0);
+                acc[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.y, (double)b4.y, acc[pp], 0, 0, 0);
+                acc[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.z, (double)b4.z, acc[pp], 0, 0, 0);
+                acc[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.w, (double)b4.w, acc[pp], 0, 0, 0);
             }
         }
         __syncthreads();
     }
-    // ---- partial Gram blocks of this chunk: slab[k][chunk][pair][32][32] ------------------------------------------------
-    float* out = slab + ((size_t)k * n_chunks + chunk) * (size_t)n_pairs * 1024;
+    // ---- partial Gram tiles of this chunk: slab[k][chunk][pair][j][i]  (column-major inside a tile) -------------------
+    double* out = slab + ((size_t)k * n_chunks + chunk) * (size_t)n_pairs * 256;
 #pragma unroll
     for (int pp = 0; pp < PP; ++pp) {
         if (row_of[pp] < 0) continue;
-        float* o = out + (size_t)(wave + 4 * pp) * 1024;
+        double* o = out + (size_t)(wave + 8 * pp) * 256 + r16 * 16 + kg;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) o[((t & 3) + 8 * (t >> 2) + 4 * half) * 32 + col] = acc[pp][t];
+        for (int r = 0; r < 4; ++r) o[4 * r] = acc[pp][r];
     }
 }
 
-__device__ __forceinline__ int tri_ofs(int i) { return i * (i + 1) / 2; }
+__device__ __forceinline__ double half_wave_sum(double v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+    return v;
+}
 
-// One workgroup per component: assemble, factorise, solve, un-whiten.
-__global__ __launch_bounds__(1024) void more_solve_kernel(int D, int nb, int n_chunks, const float* __restrict__ slab,
+// One workgroup per component: assemble the (F+1)x(F+1) Gram matrix, factorise, solve, un-whiten -- in fp64.
+// The lower triangle lives in REGISTERS: thread (ti = tid % 32, tc = tid / 32) owns the elements (32 a + ti, 32 b + tc),
+// 0 <= b <= a < 8 (36 doubles).  Right-looking Cholesky, one barrier per column: the owners of column j publish it
+// (unscaled) and 1/pivot through a double-buffered LDS vector, every thread applies the rank-1 update to its elements.
+// Row F of the matrix is the right-hand side, so the factorisation leaves y = L^-1 b in it; the back substitution walks
+// the columns with a half-wave reduction (the owners of one column are 32 consecutive lanes).
+__global__ __launch_bounds__(1024) void more_solve_kernel(int D, int nb, int n_chunks, const double* __restrict__ slab,
                                                           const float* __restrict__ chols, const float* __restrict__ l2,
                                                           float* __restrict__ H_neg, float* __restrict__ g_neg) {
-    extern __shared__ float sm[];
+    __shared__ double cb[2][258];       // published column (unscaled) + [256] = 1 / pivot
+    __shared__ double ys[256], dg[256], beta[256];
+    extern __shared__ double smd[];     // Ls[D][D], Qs[D][D+1], Xs[D][D+1]
     const int tid = threadIdx.x;
+    const int ti = tid & 31, tc = tid >> 5;
     const int k = blockIdx.x;
     const int T2 = D * (D + 1) / 2;
     const int F = T2 + D + 1;
     const int n_pairs = nb * (nb + 1) / 2;
-    float* tri = sm;                                   // packed lower triangle of the F x F system
-    float* rhs = tri + tri_ofs(F);                     // [F]
-    float* colv = rhs + F;                             // [F] scaled pivot column
-    float* Ls = colv + F;                              // [D][D] component Cholesky factor
-    float* Qs = Ls + D * D;                            // [D][D+1]  Q_w | lin_w
-    float* Xs = Qs + D * (D + 1);                      // [D][D+1]
-    __shared__ int s_fail;
-    if (tid == 0) s_fail = 0;
+    double* Ls = smd;
+    double* Qs = Ls + D * D;
+    double* Xs = Qs + D * (D + 1);
 
     // ---- assemble: fixed-order sum over the sample chunks ------------------------------------------------------------
-    const float* base = slab + (size_t)k * n_chunks * (size_t)n_pairs * 1024;
-    const int il = tid >> 5, cl = tid & 31;
-    for (int bi = 0, p = 0; bi < nb; ++bi)
-        for (int bc = 0; bc <= bi; ++bc, ++p) {
-            const int i = 32 * bi + il, c = 32 * bc + cl;
-            if (i > F || c > i || c >= F) continue;
-            float s = 0.f;
-            for (int ch = 0; ch < n_chunks; ++ch) s += base[((size_t)ch * n_pairs + p) * 1024 + il * 32 + cl];
-            if (i < F) tri[tri_ofs(i) + c] = s;
-            else rhs[c] = s;
+    const double* base = slab + (size_t)k * n_chunks * (size_t)n_pairs * 256;
+    const double ridge = (double)l2[k];
+    double L[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            const int i = 32 * a + ti, c = 32 * b + tc;
+            double s = 0.0;
+            if (i <= F && c <= i && c < F) {
+                const int I = i >> 4, J = c >> 4;
+                const double* src = base + (size_t)(I * (I + 1) / 2 + J) * 256 + (c & 15) * 16 + (i & 15);
+                for (int ch = 0; ch < n_chunks; ++ch) s += src[(size_t)ch * n_pairs * 256];
+                if (i == c && i < F - 1) s += ridge;                        // least_squares.py:71-73 (bias unregularised)
+            }
+            L[a][b] = s;
         }
-    for (int e = tid; e < D * D; e += 1024) Ls[e] = chols[(size_t)k * D * D + e];
-    __syncthreads();
-    const float ridge = l2[k];
-    for (int i = tid; i < F - 1; i += 1024) tri[tri_ofs(i) + i] += ridge;          // least_squares.py:71-73 (bias unregularised)
-    __syncthreads();
+    for (int e = tid; e < D * D; e += 1024) Ls[e] = (double)chols[(size_t)k * D * D + e];
 
-    // ---- in-place Cholesky, right-looking, thread (ti, tc) covers rows ti (mod 32), columns tc (mod 32) -----------------
-    for (int j = 0; j < F; ++j) {
-        const float d = tri[tri_ofs(j) + j];
-        if (!(d > 0.f)) { if (tid == 0) s_fail = 1; break; }                      // uniform: every thread reads the same d
-        const float inv = rsqrtf(d);
-        __syncthreads();                                                           // everyone has read the pivot
-        for (int i = j + tid; i < F; i += 1024) {
-            const float v = (i == j) ? d * inv : tri[tri_ofs(i) + j] * inv;
-            tri[tri_ofs(i) + j] = v;
-            colv[i] = v;
+    // ---- Cholesky of the leading F x F block (row F rides along) -----------------------------------------------------
+    bool fail = false;
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        for (int jj = 0; jj < 32; ++jj) {
+            const int j = 32 * jb + jj;
+            if (j >= F || fail) break;
+            double* col = cb[j & 1];
+            if (tc == jj) {
+#pragma unroll
+                for (int a = jb; a < 8; ++a) col[32 * a + ti] = L[a][jb];
+                if (ti == jj) col[256] = 1.0 / L[jb][jb];
+            }
+            __syncthreads();
+            const double d = col[j];
+            if (!(d > 0.0)) { fail = true; break; }                          // uniform: every thread reads the same pivot
+            const double inv = col[256];
+            double ui[8], uc[8];
+#pragma unroll
+            for (int a = jb; a < 8; ++a) { ui[a] = col[32 * a + ti]; uc[a] = col[32 * a + tc] * inv; }
+#pragma unroll
+            for (int b = jb; b < 8; ++b) {
+                if (b == jb && tc <= jj) continue;                           // column c <= j: finished
+#pragma unroll
+                for (int a = b; a < 8; ++a) {
+                    if (a == b && ti < tc) continue;                         // above the diagonal
+                    L[a][b] = fma(-ui[a], uc[b], L[a][b]);
+                }
+            }
+            if (tc == jj) {                                                  // finalise column j: divide by sqrt(pivot)
+                const double rs = 1.0 / sqrt(d);
+#pragma unroll
+                for (int a = jb; a < 8; ++a) L[a][jb] *= rs;
+            }
         }
-        __syncthreads();
-        for (int i = j + 1 + il; i < F; i += 32) {
-            const float li = colv[i];
-            float* rowp = tri + tri_ofs(i);
-            for (int c = j + 1 + cl; c <= i; c += 32) rowp[c] = fmaf(-li, colv[c], rowp[c]);
-        }
-        __syncthreads();
     }
     __syncthreads();
-    const bool fail = s_fail != 0;
     if (!fail) {
-        // forward: L y = b
-        for (int j = 0; j < F; ++j) {
-            const float yj = rhs[j] / tri[tri_ofs(j) + j];
-            for (int i = j + 1 + tid; i < F; i += 1024) rhs[i] = fmaf(-tri[tri_ofs(i) + j], yj, rhs[i]);
-            __syncthreads();
+        // y = row F, diagonal -> LDS
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            if (ti == tc) dg[32 * a + ti] = L[a][a];
+            if (32 * a + ti == F) {
+#pragma unroll
+                for (int b = 0; b <= a; ++b) ys[32 * b + tc] = L[a][b];
+            }
         }
-        for (int i = tid; i < F; i += 1024) rhs[i] /= tri[tri_ofs(i) + i];
         __syncthreads();
-        // backward: L^T beta = y
-        for (int j = F - 1; j >= 0; --j) {
-            const float bj = rhs[j] / tri[tri_ofs(j) + j];
-            const float* rowp = tri + tri_ofs(j);
-            for (int i = tid; i < j; i += 1024) rhs[i] = fmaf(-rowp[i], bj, rhs[i]);
-            __syncthreads();
+        // back substitution L^T beta = y
+#pragma unroll
+        for (int jb = 7; jb >= 0; --jb) {
+            for (int jj = 31; jj >= 0; --jj) {
+                const int j = 32 * jb + jj;
+                if (j >= F) continue;
+                if (tc == jj) {
+                    double part = 0.0;
+#pragma unroll
+                    for (int a = jb; a < 8; ++a) {
+                        const int i = 32 * a + ti;
+                        if (i > j && i < F) part = fma(L[a][jb], beta[i], part);
+                    }
+                    part = half_wave_sum(part);
+                    if (ti == 0) beta[j] = (ys[j] - part) / dg[j];
+                }
+                __syncthreads();
+            }
         }
-        for (int i = tid; i < F; i += 1024) colv[i] = rhs[i] / tri[tri_ofs(i) + i];  // beta
-        __syncthreads();
         // Q_w = -(Qt + Qt^T) with Qt the upper-triangular fill of the quadratic coefficients (least_squares.py:177-179)
         for (int e = tid; e < D * (D + 1); e += 1024) {
             const int i = e / (D + 1), j = e % (D + 1);
-            float v;
-            if (j == D) v = colv[T2 + i];                                            // lin_w
+            double v;
+            if (j == D) v = beta[T2 + i];                                            // lin_w
             else {
                 const int a = min(i, j), b = max(i, j);
-                const float q = colv[a * D - a * (a - 1) / 2 + (b - a)];
-                v = (a == b) ? -2.f * q : -q;
+                const double q = beta[a * D - a * (a - 1) / 2 + (b - a)];
+                v = (a == b) ? -2.0 * q : -q;
             }
             Qs[e] = v;
         }
         __syncthreads();
-        // X = L^-T [Q_w | lin_w]   (lane = column)
+        // X = L_o^-T [Q_w | lin_w]   (lane = column)
         if (tid <= D) {
             for (int i = D - 1; i >= 0; --i) {
-                float t = Qs[i * (D + 1) + tid];
-                for (int j = i + 1; j < D; ++j) t = fmaf(-Ls[j * D + i], Xs[j * (D + 1) + tid], t);
+                double t = Qs[i * (D + 1) + tid];
+                for (int j = i + 1; j < D; ++j) t = fma(-Ls[j * D + i], Xs[j * (D + 1) + tid], t);
                 Xs[i * (D + 1) + tid] = t / Ls[i * D + i];
             }
         }
         __syncthreads();
-        // H = X L^-1: row r of H solves L^T h = (row r of X)^T   (least_squares.py:185); g = Q mu - lin = -L^-T lin_w (:186-188,
-        // ng_estimator.py:371-373)
+        // H = X L_o^-1: row r of H solves L_o^T h = (row r of X)^T (least_squares.py:185); g = Q mu - lin = -L_o^-T lin_w
+        // (:186-188, ng_estimator.py:371-373)
         if (tid < D) {
-            float* hrow = Qs + tid * (D + 1);                                        // reuse: row tid only touched by this lane
+            double* hrow = Qs + tid * (D + 1);                                       // row tid is only touched by this lane
             for (int i = D - 1; i >= 0; --i) {
-                float t = Xs[tid * (D + 1) + i];
-                for (int j = i + 1; j < D; ++j) t = fmaf(-Ls[j * D + i], hrow[j], t);
+                double t = Xs[tid * (D + 1) + i];
+                for (int j = i + 1; j < D; ++j) t = fma(-Ls[j * D + i], hrow[j], t);
                 hrow[i] = t / Ls[i * D + i];
             }
-            for (int i = 0; i < D; ++i) H_neg[((size_t)k * D + tid) * D + i] = hrow[i];
-            g_neg[(size_t)k * D + tid] = -Xs[tid * (D + 1) + D];
+            for (int i = 0; i < D; ++i) H_neg[((size_t)k * D + tid) * D + i] = (float)hrow[i];
+            g_neg[(size_t)k * D + tid] = (float)(-Xs[tid * (D + 1) + D]);
         }
     } else {
         const float nanv = __int_as_float(0x7fc00000);
@@ -303,31 +348,42 @@ __global__ __launch_bounds__(1024) void more_solve_kernel(int D, int nb, int n_c
     }
 }
 
+// workgroups per launch that fill the chip in whole rounds: the count c in [lo, hi] maximising c K / (ceil(c K / cus) cus)
+static int more_pick_chunks(int K, int cus, int tiles) {
+    int best = 1; double best_eff = 0.0;
+    const int hi = tiles < 4 ? 1 : tiles / 4;                 // at least four 64-sample tiles per workgroup
+    for (int c = 1; c <= hi && (long)c * K <= 6L * cus; ++c) {
+        const long wgs = (long)c * K;
+        const double eff = (double)wgs / (double)(((wgs + cus - 1) / cus) * cus);
+        const bool enough = wgs >= cus || c == hi;
+        if ((enough ? eff : eff * 0.5) > best_eff + 1e-9) { best_eff = enough ? eff : eff * 0.5; best = c; }
+    }
+    return best;
+}
+
 template <int DP, int PP>
 int launch_more(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* chols, const float* X, int N,
                 const float* ld, const float* logq, const float* bg, const float* tlp, const int32_t* mapping,
                 int map_offset, int flags, const float* l2, float* H_neg, float* g_neg) {
     const int F = D * (D + 1) / 2 + D + 1;
-    const int nb = (F + 1 + 31) / 32;
+    const int nb = (F + 1 + 15) / 16;
     const int n_pairs = nb * (nb + 1) / 2;
-    if (n_pairs > 4 * PP) return gmmvi_fail(ctx, GMMVI_ERR_ARG, "gmmvi_more: internal tiling error");
+    if (n_pairs > 8 * PP) return gmmvi_fail(ctx, GMMVI_ERR_ARG, "gmmvi_more: internal tiling error");
     const int tiles = (N + 63) / 64;
-    int n_chunks = (2 * ctx->num_cus + K - 1) / K;             // two workgroups per CU
-    if (n_chunks > tiles) n_chunks = tiles;
-    if (n_chunks < 1) n_chunks = 1;
+    int n_chunks = more_pick_chunks(K, ctx->num_cus, tiles);
     const int tiles_per_chunk = (tiles + n_chunks - 1) / n_chunks;
     n_chunks = (tiles + tiles_per_chunk - 1) / tiles_per_chunk;
-    const size_t slab_floats = (size_t)K * n_chunks * n_pairs * 1024;
-    int rc = gmmvi_ws_reserve(ctx, (slab_floats + (size_t)K) * sizeof(float));
+    const size_t slab_doubles = (size_t)K * n_chunks * n_pairs * 256;
+    int rc = gmmvi_ws_reserve(ctx, slab_doubles * sizeof(double) + (size_t)K * sizeof(float));
     if (rc != GMMVI_OK) return rc;
-    float* slab = (float*)ctx->ws;
-    float* lse = slab + slab_floats;
+    double* slab = (double*)ctx->ws;
+    float* lse = (float*)(slab + slab_doubles);
     if (flags & GMMVI_SELF_NORMALIZED) {
         GMMVI_PROF(ctx, "more_lse");
         hipLaunchKernelGGL(more_lse_kernel, dim3(K), dim3(1024), 0, ctx->stream, N, ld, bg, mapping, map_offset, flags, lse);
         GMMVI_LAUNCH_CHECK(ctx);
     }
-    const size_t gram_lds = (size_t)32 * nb * PHI_LD * sizeof(float);
+    const size_t gram_lds = (size_t)16 * nb * PHI_LD * sizeof(float);
     static size_t gram_attr = 0;
     if (gram_lds > gram_attr) {
         GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)more_gram_kernel<DP, PP>,
@@ -336,17 +392,11 @@ int launch_more(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* 
     }
     {
         GMMVI_PROF(ctx, "more_gram");
-        hipLaunchKernelGGL((more_gram_kernel<DP, PP>), dim3(n_chunks, K), dim3(256), gram_lds, ctx->stream, D, N,
+        hipLaunchKernelGGL((more_gram_kernel<DP, PP>), dim3(n_chunks, K), dim3(512), gram_lds, ctx->stream, D, N,
                            tiles_per_chunk, nb, packed, X, ld, bg, tlp, logq, mapping, map_offset, flags, lse, slab);
         GMMVI_LAUNCH_CHECK(ctx);
     }
-    const size_t solve_lds = ((size_t)F * (F + 1) / 2 + 2 * (size_t)F + (size_t)D * D + 2 * (size_t)D * (D + 1)) * sizeof(float);
-    static size_t solve_attr = 0;
-    if (solve_lds > solve_attr) {
-        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)more_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)solve_lds));
-        solve_attr = solve_lds;
-    }
+    const size_t solve_lds = ((size_t)D * D + 2 * (size_t)D * (D + 1)) * sizeof(double);
     GMMVI_PROF(ctx, "more_solve");
     hipLaunchKernelGGL(more_solve_kernel, dim3(K), dim3(1024), solve_lds, ctx->stream, D, nb, n_chunks, slab, chols, l2,
                        H_neg, g_neg);
@@ -374,10 +424,10 @@ extern "C" int gmmvi_more(gmmvi_ctx* ctx, int K, int D, const float* packed_dev,
         case 4: GMMVI_MORE_CASE(4, 1);
         case 8: GMMVI_MORE_CASE(8, 1);
         case 10: GMMVI_MORE_CASE(10, 2);
-        case 12: GMMVI_MORE_CASE(12, 2);
-        case 16: GMMVI_MORE_CASE(16, 4);
-        case 20: GMMVI_MORE_CASE(20, 9);
-        case 24: GMMVI_MORE_CASE(24, 9);
+        case 12: GMMVI_MORE_CASE(12, 3);
+        case 16: GMMVI_MORE_CASE(16, 7);
+        case 20: GMMVI_MORE_CASE(20, 15);
+        case 24: GMMVI_MORE_CASE(24, 17);
         default: return gmmvi_fail(ctx, GMMVI_ERR_ARG, "gmmvi_more: unsupported dimension");
     }
 #undef GMMVI_MORE_CASE

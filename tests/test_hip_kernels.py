@@ -197,9 +197,37 @@ def test_more(ctx, rng, k, d, n, snis):
     assert np.all(np.isfinite(h)) and np.all(np.isfinite(g))
     scale_h = np.abs(rh).max(axis=(1, 2), keepdims=True)
     scale_g = np.abs(rg).max(axis=1, keepdims=True)
-    # fp32 normal equations of a quartic design: error ~ cond(A) * 2^-24 of the per-component magnitude
-    assert np.all(np.abs(h - rh) <= 2e-2 * scale_h + 1e-5), np.abs(h - rh).max() / scale_h.max()
-    assert np.all(np.abs(g - rg) <= 2e-2 * scale_g + 1e-5), np.abs(g - rg).max() / scale_g.max()
+    # fp64 Gram + solve on fp32 inputs (z, weights, rewards carry ~1e-6 relative error from the fp32 density pass)
+    assert np.all(np.abs(h - rh) <= 2e-3 * scale_h + 1e-5), np.abs(h - rh).max() / scale_h.max()
+    assert np.all(np.abs(g - rg) <= 2e-3 * scale_g + 1e-5), np.abs(g - rg).max() / scale_g.max()
+
+
+@pytest.mark.parametrize("k,d,n", [(2, 10, 40), (3, 20, 150), (4, 20, 240)])
+def test_more_fewer_samples_than_features(ctx, rng, k, d, n):
+    """Rank-deficient ridge systems (N < F = D(D+1)/2 + D + 1), the state early in a run.  With a ridge that fp64 resolves
+    but fp32 does not (1e-6: cond ~ 1e8) the fp64 path must reproduce the oracle; with the reference's 1e-12 the
+    regression itself is ill-posed (the fp64 oracle moves by tens of percent under a 1e-6 perturbation of its inputs),
+    so only finiteness is asserted there."""
+    from oracle import more as omore
+    m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    xd = ctx.asarray(x)
+    ld, lp, _ = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_lp=True)
+    mp = mapping + 2
+    args = dict(mapping=ctx.asarray(mp, np.int32), map_offset=k - 1 - int(mp.max()), own_samples_only=True)
+    for ridge, tol in ((1e-6, 1e-2), (1e-12, None)):
+        l2 = np.full(k, ridge)
+        h, g = ops().more(ctx, packed, chols, xd, ld, lp, ctx.asarray(bg), ctx.asarray(tlp), ctx.asarray(l2), d, **args)
+        h, g = h.numpy(), g.numpy()
+        assert np.all(np.isfinite(h)) and np.all(np.isfinite(g))
+        if tol is None:
+            continue
+        rh, rg = omore.get_expected_hessian_and_grad(m, l2, x, mp, bg, tlp, True, True)
+        scale_h = np.abs(rh).max(axis=(1, 2), keepdims=True)
+        scale_g = np.abs(rg).max(axis=1, keepdims=True)
+        assert np.all(np.abs(h - rh) <= tol * scale_h), (np.abs(h - rh) / scale_h).max()
+        assert np.all(np.abs(g - rg) <= tol * scale_g), (np.abs(g - rg) / scale_g).max()
 
 
 def test_more_own_samples(ctx, rng):
