@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgmmvi_hip.so")
+LIB_PATH = os.environ.get("GMMVI_HIP_LIB", os.path.join(_HERE, "libgmmvi_hip.so"))    # override: experiments only
 
 GAUSS, STUDENT_T = 0, 1
 SELF_NORMALIZED, OWN_SAMPLES_ONLY = 1, 2

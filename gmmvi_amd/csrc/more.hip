@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512) void more_gram_kernel(int D, int N, int tiles_
                                                         const int32_t* __restrict__ mapping, int map_offset, int flags,
                                                         const float* __restrict__ lse, double* __restrict__ slab) {
     using PK = Pack<DP>;
-    extern __shared__ float phi[];                     // [16 nb][PHI_LD]
+    extern __shared__ float phi[];                     // [16 nb][PHI_LD] feature image, then 8 whitened tiles, then tab
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,87 +105,122 @@ __global__ __launch_bounds__(512) void more_gram_kernel(int D, int N, int tiles_
     const bool self_norm = (flags & GMMVI_SELF_NORMALIZED) != 0;
     const float* __restrict__ P = packed + (size_t)k * PK::STRIDE;
     const float lse_k = self_norm ? lse[k] : 0.f;
+    const int ZS_TILE = (D + 3) * 64;                  // per tile: rows 0..D-1 z, row D ones, D+1 reward, D+2 sqrt(weight)
+    float* zs = phi + 16 * nb * PHI_LD;                // 8 tiles, whitened one per wave
+    int* tab = reinterpret_cast<int*>(zs + 8 * ZS_TILE);   // feature f -> (row ia) | (row ib) << 16 of a zs tile
 
-    // 16x16 tile pairs (bi >= bc) of this wave: p = wave + 8 pp
+    // 16x16 tile pairs (bi >= bc) of this wave: p = wave + 8 pp; unused slots read tile 0 and are never stored
     int row_of[PP], col_of[PP];
+    bool used[PP];
 #pragma unroll
     for (int pp = 0; pp < PP; ++pp) {
         const int p = wave + 8 * pp;
         int bi = 0;
         while ((bi + 1) * (bi + 2) / 2 <= p) ++bi;
-        row_of[pp] = (p < n_pairs) ? bi : -1;
-        col_of[pp] = p - bi * (bi + 1) / 2;
+        used[pp] = p < n_pairs;
+        row_of[pp] = used[pp] ? bi : 0;
+        col_of[pp] = used[pp] ? p - bi * (bi + 1) / 2 : 0;
     }
     f64x4 acc[PP];
 #pragma unroll
     for (int pp = 0; pp < PP; ++pp) acc[pp] = f64x4{0.0, 0.0, 0.0, 0.0};
 
     for (int e = tid; e < 16 * nb * PHI_LD; e += 512) phi[e] = 0.f;       // rows > F stay zero for the whole kernel
+    for (int f = tid; f <= F; f += 512) {                                 // least_squares.py:113-124 feature order
+        int ia, ib;
+        if (f < T2) {
+            int i = 0, rem = f;
+            while (rem >= D - i) { rem -= D - i; ++i; }
+            ia = i; ib = i + rem;
+        } else if (f < T2 + D) { ia = f - T2; ib = D; }
+        else if (f == F - 1) { ia = D; ib = D; }
+        else { ia = D + 1; ib = D; }
+        tab[f] = ia | (ib << 16);
+    }
     __syncthreads();
 
     const int r16 = lane & 15, kg = lane >> 4;
     const int tile_begin = chunk * tiles_per_chunk;
     const int tile_end = min((N + 63) / 64, tile_begin + tiles_per_chunk);
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        // ---- every wave whitens the same 64 samples (lane = sample); each writes an eighth of the feature rows ----------
-        const int n = tile * 64 + lane;
-        const bool valid = n < N;
-        float x[DP], z[DP];
+    for (int t0 = tile_begin; t0 < tile_end; t0 += 8) {
+        // ---- wave w whitens the 64 samples of tile t0 + w (lane = sample) -----------------------------------------------
+        if (t0 + wave < tile_end) {
+            float* zw = zs + wave * ZS_TILE;
+            const int n = (t0 + wave) * 64 + lane;
+            const bool valid = n < N;
+            float x[DP], z[DP];
 #pragma unroll
-        for (int i = 0; i < DP; ++i) x[i] = (valid && i < D) ? X[(size_t)n * D + i] : P[PK::MU + i];
-        more_forward_subst<DP>(P, x, z);
-        float sw = 0.f, rew = 0.f;
-        if (valid) {
-            float a;
-            if (own_only) a = (mapping[n] + map_offset == k) ? 0.f : -3.0e38f;
-            else a = ld[(size_t)k * N + n] - bg[n];
-            if (a > -3.0e38f) sw = __expf(0.5f * (a - lse_k));           // sqrt of the importance weight (:353-358)
-            rew = tlp[n] - logq[n];                                      // ng_estimator.py:346
+            for (int i = 0; i < DP; ++i) x[i] = (valid && i < D) ? X[(size_t)n * D + i] : P[PK::MU + i];
+            more_forward_subst<DP>(P, x, z);
+            float sw = 0.f, rew = 0.f;
+            if (valid) {
+                float a;
+                if (own_only) a = (mapping[n] + map_offset == k) ? 0.f : -3.0e38f;
+                else a = ld[(size_t)k * N + n] - bg[n];
+                if (a > -3.0e38f) sw = __expf(0.5f * (a - lse_k));       // sqrt of the importance weight (:353-358)
+                rew = tlp[n] - logq[n];                                  // ng_estimator.py:346
+            }
+            const bool live = sw > 0.f;
+#pragma unroll
+            for (int i = 0; i < DP; ++i)
+                if (i < D) zw[i * 64 + lane] = live ? z[i] : 0.f;
+            zw[D * 64 + lane] = 1.f;
+            zw[(D + 1) * 64 + lane] = live ? rew : 0.f;
+            zw[(D + 2) * 64 + lane] = live ? sw : 0.f;
         }
-        const bool live = sw > 0.f;
-        int f = 0;
+        __syncthreads();
+      for (int u = 0; u < 8 && t0 + u < tile_end; ++u) {
+        // ---- all waves: weighted feature rows  phi[f][n] = sw_n * zs[ia][n] * zs[ib][n] ------------------------------------
+        {
+            const float* zu = zs + u * ZS_TILE;
+            const int n = tid & 63;
+            const float swn = zu[(D + 2) * 64 + n];
+#pragma unroll 4
+            for (int f = tid >> 6; f <= F; f += 8) {
+                const int t = tab[f];
+                phi[f * PHI_LD + n] = (swn * zu[(t & 0xffff) * 64 + n]) * zu[(t >> 16) * 64 + n];
+            }
+        }
+        __syncthreads();
+        // ---- contraction over the 64 samples: fp32 rows widened (exactly) to fp64, fp64 accumulation --------------------
 #pragma unroll
-        for (int i = 0; i < DP; ++i) {
-            if (i < D) {
-                const float szi = sw * z[i];
+        for (int pp = 0; pp < PP; pp += 2) {
+            constexpr int NQ = 2;
+            float4 av[NQ][4], bv[NQ][4];
 #pragma unroll
-                for (int j = i; j < DP; ++j) {
-                    if (j < D) {
-                        if ((f & 7) == wave) phi[f * PHI_LD + lane] = live ? szi * z[j] : 0.f;   // least_squares.py:113-124
-                        ++f;
+            for (int u = 0; u < NQ; ++u) {
+                const int pu = (pp + u < PP) ? pp + u : pp;
+                const float* pa = phi + (16 * row_of[pu] + r16) * PHI_LD + 4 * kg;
+                const float* pb = phi + (16 * col_of[pu] + r16) * PHI_LD + 4 * kg;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    av[u][q] = *reinterpret_cast<const float4*>(pa + 16 * q);
+                    bv[u][q] = *reinterpret_cast<const float4*>(pb + 16 * q);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int u = 0; u < NQ; ++u) {
+                        if (pp + u < PP) {
+                            const float a = t == 0 ? av[u][q].x : (t == 1 ? av[u][q].y : (t == 2 ? av[u][q].z : av[u][q].w));
+                            const float b = t == 0 ? bv[u][q].x : (t == 1 ? bv[u][q].y : (t == 2 ? bv[u][q].z : bv[u][q].w));
+                            acc[pp + u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a, (double)b, acc[pp + u], 0, 0, 0);
+                        }
                     }
                 }
             }
         }
-#pragma unroll
-        for (int i = 0; i < DP; ++i)
-            if (i < D && ((T2 + i) & 7) == wave) phi[(T2 + i) * PHI_LD + lane] = live ? sw * z[i] : 0.f;
-        if (((F - 1) & 7) == wave) phi[(F - 1) * PHI_LD + lane] = live ? sw : 0.f;
-        if ((F & 7) == wave) phi[F * PHI_LD + lane] = live ? sw * rew : 0.f;
         __syncthreads();
-        // ---- contraction over the 64 samples: fp32 rows widened (exactly) to fp64, fp64 accumulation --------------------
-#pragma unroll
-        for (int pp = 0; pp < PP; ++pp) {
-            if (row_of[pp] < 0) continue;
-            const float* pa = phi + (16 * row_of[pp] + r16) * PHI_LD + 4 * kg;
-            const float* pb = phi + (16 * col_of[pp] + r16) * PHI_LD + 4 * kg;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 a4 = *reinterpret_cast<const float4*>(pa + 16 * q);
-                const float4 b4 = *reinterpret_cast<const float4*>(pb + 16 * q);
-                acc[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.x, (double)b4.x, acc[pp], 0, 0, 0);
-                acc[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.y, (double)b4.y, acc[pp], 0, 0, 0);
-                acc[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.z, (double)b4.z, acc[pp], 0, 0, 0);
-                acc[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)a4.w, (double)b4.w, acc[pp], 0, 0, 0);
-            }
-        }
-        __syncthreads();
+      }
     }
     // ---- partial Gram tiles of this chunk: slab[k][chunk][pair][j][i]  (column-major inside a tile) -------------------
     double* out = slab + ((size_t)k * n_chunks + chunk) * (size_t)n_pairs * 256;
 #pragma unroll
     for (int pp = 0; pp < PP; ++pp) {
-        if (row_of[pp] < 0) continue;
+        if (!used[pp]) continue;
         double* o = out + (size_t)(wave + 8 * pp) * 256 + r16 * 16 + kg;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[4 * r] = acc[pp][r];
@@ -383,7 +418,7 @@ int launch_more(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* 
         hipLaunchKernelGGL(more_lse_kernel, dim3(K), dim3(1024), 0, ctx->stream, N, ld, bg, mapping, map_offset, flags, lse);
         GMMVI_LAUNCH_CHECK(ctx);
     }
-    const size_t gram_lds = (size_t)16 * nb * PHI_LD * sizeof(float);
+    const size_t gram_lds = ((size_t)16 * nb * PHI_LD + (size_t)8 * (D + 3) * 64 + (size_t)(F + 1)) * sizeof(float);
     static size_t gram_attr = 0;
     if (gram_lds > gram_attr) {
         GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)more_gram_kernel<DP, PP>,
