@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_FP32_TFLOPS = 157.3      # MI355X fp32 vector == f32-input MFMA rate (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix rate (half the f32 MFMA rate)
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -174,6 +175,7 @@ def main():
                     key=lambda nme: kernels[nme]["avg_us"] * kernels[nme]["launches_per_step"])
     fl = kernel_flops(roof_name, w["n_total"], k_local, w["d"])
     achieved = fl / (kernels[roof_name]["avg_us"] * 1e-6) / 1e12
+    roof_peak = PEAK_FP64_MFMA_TFLOPS if roof_name == "more_gram" else PEAK_FP32_TFLOPS
     d, n_tot, k_tot = w["d"], w["n_total"], w["k_total"]
     f_alg_iter = float(n_tot) * k_tot * (8 * d * d + 12 * d)                   # SURVEY.md 8d (probes reported apart)
     b_alg_iter = 4.0 * (3 * n_tot * d + 3 * n_tot + 2 * k_tot * (d * d + d + 1))
@@ -188,13 +190,13 @@ def main():
         "metric": "samples_components_per_sec", "value": n_tot * k_tot / (elapsed / args.steps),
         "unit": "samples*components/s", "train_iter_per_sec": args.steps / elapsed,
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if roof_name == "more_gram" else "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {w['kind']} target D={d}, K={k_tot} components "
                                f"({k_local}/GPU), {w['s']} samples/component, N={n_tot} samples/iter, SAMTRON "
                                f"({w['cfg']['ng_estimator_type']}, fixed K, reuse ratio 0, KL trust regions, improvement-based stepsizes)",
                    "K": k_tot, "D": d, "N": n_tot, "parallelism": f"component-shard x{n_gpus}"},
-        "roofline": {"kernel": roof_name, "bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS,
-                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS, "traffic": traffic,
+        "roofline": {"kernel": roof_name, "bound": "mfma", "achieved": achieved, "peak": roof_peak,
+                     "unit": "TFLOP/s", "frac": achieved / roof_peak, "traffic": traffic,
                      "avg_us": kernels[roof_name]["avg_us"], "flops_per_launch": fl,
                      "note": "fp32 FMA path (vector substitution + f32 MFMA contraction); peak = fp32 vector == f32 "
                              "MFMA rate. Algorithmic HBM bytes per iteration are tiny (see iter_roofline): the "

@@ -242,8 +242,9 @@ __device__ __forceinline__ double half_wave_sum(double v) {
 __global__ __launch_bounds__(1024) void more_solve_kernel(int D, int nb, int n_chunks, const double* __restrict__ slab,
                                                           const float* __restrict__ chols, const float* __restrict__ l2,
                                                           float* __restrict__ H_neg, float* __restrict__ g_neg) {
-    __shared__ double cb[2][258];       // published column (unscaled) + [256] = 1 / pivot
-    __shared__ double ys[256], dg[256], beta[256];
+    __shared__ double cb[2][256];       // published column (unscaled), double-buffered
+    __shared__ double ys[256], dg[256], beta[256];   // y = L^-1 b, reciprocal diagonal, solution
+    __shared__ double rblk[32], dblk[32 * 33];       // back substitution: block right-hand side, diagonal block
     extern __shared__ double smd[];     // Ls[D][D], Qs[D][D+1], Xs[D][D+1]
     const int tid = threadIdx.x;
     const int ti = tid & 31, tc = tid >> 5;
@@ -264,45 +265,70 @@ __global__ __launch_bounds__(1024) void more_solve_kernel(int D, int nb, int n_c
 #pragma unroll
         for (int b = 0; b <= a; ++b) {
             const int i = 32 * a + ti, c = 32 * b + tc;
-            double s = 0.0;
-            if (i <= F && c <= i && c < F) {
-                const int I = i >> 4, J = c >> 4;
-                const double* src = base + (size_t)(I * (I + 1) / 2 + J) * 256 + (c & 15) * 16 + (i & 15);
-                for (int ch = 0; ch < n_chunks; ++ch) s += src[(size_t)ch * n_pairs * 256];
-                if (i == c && i < F - 1) s += ridge;                        // least_squares.py:71-73 (bias unregularised)
-            }
-            L[a][b] = s;
+            L[a][b] = (i == c && i < F - 1) ? ridge : 0.0;                  // least_squares.py:71-73 (bias unregularised)
         }
+    // element (i, c) sits in tile (i / 16, c / 16) at [c % 16][i % 16]; with i = 32 a + ti, c = 32 b + tc that is tile
+    // (2 a + ti / 16, 2 b + tc / 16): a per-thread base offset plus compile-time multiples
+    const int th = ti >> 4, tch = tc >> 4;
+    const int in_tile = (tc & 15) * 16 + (ti & 15);
+    for (int ch = 0; ch < n_chunks; ++ch) {                                 // fixed order; independent loads in flight
+        const double* src = base + (size_t)ch * n_pairs * 256 + in_tile;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+                const int i = 32 * a + ti, c = 32 * b + tc;
+                const int I = 2 * a + th, J = 2 * b + tch;
+                if (i <= F && c <= i && c < F) L[a][b] += src[(I * (I + 1) / 2 + J) * 256];
+            }
+    }
     for (int e = tid; e < D * D; e += 1024) Ls[e] = (double)chols[(size_t)k * D * D + e];
 
     // ---- Cholesky of the leading F x F block (row F rides along) -----------------------------------------------------
+    // Per column j: [barrier] every thread reads the published column u = A[:, j] (unscaled) and applies
+    // A[i][c] -= u_i u_c / u_j to its elements; the owners of column j+1 do their column first and publish it at once
+    // (look-ahead), so the next barrier does not wait for a serial publish.  Elements above the diagonal of the diagonal
+    // blocks are never read; they hold finite Schur-complement mirrors, so no predicate is needed for them.
     bool fail = false;
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb) {
+        if (32 * jb >= F || fail) break;
+        if (tc == 0) {
+            double* col0 = cb[0];                                            // 32 jb is even
+#pragma unroll
+            for (int a = jb; a < 8; ++a) col0[32 * a + ti] = L[a][jb];
+        }
         for (int jj = 0; jj < 32; ++jj) {
             const int j = 32 * jb + jj;
-            if (j >= F || fail) break;
-            double* col = cb[j & 1];
-            if (tc == jj) {
-#pragma unroll
-                for (int a = jb; a < 8; ++a) col[32 * a + ti] = L[a][jb];
-                if (ti == jj) col[256] = 1.0 / L[jb][jb];
-            }
+            if (j >= F) break;
+            const double* col = cb[j & 1];
             __syncthreads();
             const double d = col[j];
             if (!(d > 0.0)) { fail = true; break; }                          // uniform: every thread reads the same pivot
-            const double inv = col[256];
-            double ui[8], uc[8];
+            double inv = __builtin_amdgcn_rcp(d);
+            inv = fma(fma(-d, inv, 1.0), inv, inv);
+            inv = fma(fma(-d, inv, 1.0), inv, inv);
+            double ui[8];
 #pragma unroll
-            for (int a = jb; a < 8; ++a) { ui[a] = col[32 * a + ti]; uc[a] = col[32 * a + tc] * inv; }
+            for (int a = jb; a < 8; ++a) ui[a] = col[32 * a + ti];
+            const double uc0 = col[32 * jb + tc] * inv;
+            const bool look = jj < 31 && j + 1 < F;
+            if (look && tc == jj + 1) {
+                double* nxt = cb[(j + 1) & 1];
 #pragma unroll
-            for (int b = jb; b < 8; ++b) {
-                if (b == jb && tc <= jj) continue;                           // column c <= j: finished
-#pragma unroll
-                for (int a = b; a < 8; ++a) {
-                    if (a == b && ti < tc) continue;                         // above the diagonal
-                    L[a][b] = fma(-ui[a], uc[b], L[a][b]);
+                for (int a = jb; a < 8; ++a) {
+                    L[a][jb] = fma(-ui[a], uc0, L[a][jb]);
+                    nxt[32 * a + ti] = L[a][jb];
                 }
+            }
+            const double ucj = (tc > jj + (look ? 1 : 0)) ? uc0 : 0.0;         // columns <= j are final, j+1 is done
+#pragma unroll
+            for (int a = jb; a < 8; ++a) L[a][jb] = fma(-ui[a], ucj, L[a][jb]);
+#pragma unroll
+            for (int b = jb + 1; b < 8; ++b) {
+                const double ucb = col[32 * b + tc] * inv;
+#pragma unroll
+                for (int a = b; a < 8; ++a) L[a][b] = fma(-ui[a], ucb, L[a][b]);
             }
             if (tc == jj) {                                                  // finalise column j: divide by sqrt(pivot)
                 const double rs = 1.0 / sqrt(d);
@@ -313,34 +339,43 @@ __global__ __launch_bounds__(1024) void more_solve_kernel(int D, int nb, int n_c
     }
     __syncthreads();
     if (!fail) {
-        // y = row F, diagonal -> LDS
+        // y = row F and the reciprocal diagonal -> LDS
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-            if (ti == tc) dg[32 * a + ti] = L[a][a];
+            if (ti == tc) dg[32 * a + ti] = 1.0 / L[a][a];
             if (32 * a + ti == F) {
 #pragma unroll
                 for (int b = 0; b <= a; ++b) ys[32 * b + tc] = L[a][b];
             }
         }
         __syncthreads();
-        // back substitution L^T beta = y
+        // back substitution L^T beta = y, one 32-column block per round: every half-wave reduces its column's product
+        // with the already known beta, the diagonal block goes to LDS and wave 0 finishes the 32 unknowns without barriers
 #pragma unroll
         for (int jb = 7; jb >= 0; --jb) {
-            for (int jj = 31; jj >= 0; --jj) {
-                const int j = 32 * jb + jj;
-                if (j >= F) continue;
-                if (tc == jj) {
-                    double part = 0.0;
+            if (32 * jb >= F) continue;
+            double part = 0.0;
 #pragma unroll
-                    for (int a = jb; a < 8; ++a) {
-                        const int i = 32 * a + ti;
-                        if (i > j && i < F) part = fma(L[a][jb], beta[i], part);
-                    }
-                    part = half_wave_sum(part);
-                    if (ti == 0) beta[j] = (ys[j] - part) / dg[j];
-                }
-                __syncthreads();
+            for (int a = jb + 1; a < 8; ++a) {
+                const int i = 32 * a + ti;
+                if (i < F) part = fma(L[a][jb], beta[i], part);
             }
+            part = half_wave_sum(part);
+            if (ti == 0) rblk[tc] = ys[32 * jb + tc] - part;
+            dblk[ti * 33 + tc] = L[jb][jb];
+            __syncthreads();
+            if (tid < 64) {
+                const int c = tid & 31;
+                double rc = rblk[c];
+                for (int jj = 31; jj >= 0; --jj) {
+                    const int j = 32 * jb + jj;
+                    if (j >= F) continue;
+                    const double bj = __shfl(rc, jj) * dg[j];
+                    if (tid == jj) beta[j] = bj;
+                    if (c < jj) rc = fma(-dblk[jj * 33 + c], bj, rc);
+                }
+            }
+            __syncthreads();
         }
         // Q_w = -(Qt + Qt^T) with Qt the upper-triangular fill of the quadratic coefficients (least_squares.py:177-179)
         for (int e = tid; e < D * (D + 1); e += 1024) {
