@@ -214,202 +214,213 @@ __global__ __launch_bounds__(256) void stein_finalize_kernel(int D, int R, int N
     for (int i = threadIdx.x; i < D; i += 256) g_neg[(size_t)k * D + i] = -A[i * D1 + D] * scale;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Component-stationary variant (DP <= 24): one wave = one component whose (mu, 1/diag, L) live in VGPRs for the whole
-// kernel; the wave streams over the sample tiles of its chunk.  The substitution then runs on register operands only
-// (no scalar-load or LDS feed in the dependent chain) and the (D+1)^2 accumulator stays in the MFMA registers across
-// all tiles (online rescaling with a wave-uniform running maximum).  A workgroup = 4 components sharing the
-// double-buffered, coalesced x / [g;1] tiles of 64 samples.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int DP>
-__global__ __launch_bounds__(256) void stein_cs_kernel(int K, int D, int tiles_per_chunk, const float* __restrict__ packed,
-                                                       const float* __restrict__ X, const float* __restrict__ TG,
-                                                       const float* __restrict__ QG, int N, const float* __restrict__ ld,
-                                                       const float* __restrict__ bg, const int32_t* __restrict__ mapping,
-                                                       int map_offset, int flags, float* __restrict__ part,
-                                                       float* __restrict__ part_m) {
-    using PK = Pack<DP>;
-    constexpr int W = 32, LDW = 33, T = PK::T;
-    extern __shared__ __align__(16) float sm[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int D1 = D + 1;
-    const int ldx = D | 1;
-    const int k = blockIdx.y * 4 + wave;
-    const bool has_comp = k < K;
-    const int chunk = blockIdx.x, n_chunks = gridDim.x;
-    const int tile_begin = chunk * tiles_per_chunk;
-    const int n_tiles_total = (N + 63) / 64;
-    const int tile_end = min(n_tiles_total, tile_begin + tiles_per_chunk);
-    const bool own_only = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
-    // LDS: Xs[2][64][ldx], Gs[2][64][LDW], Yw[4][64][LDW], Pw[4][STRIDE]
-    float* Xs = sm;
-    float* Gs = Xs + 2 * 64 * ldx;
-    float* Yw = Gs + 2 * 64 * LDW + wave * 64 * LDW;
-    float* Pw = Gs + 2 * 64 * LDW + 4 * 64 * LDW + wave * PK::STRIDE;
-
-    // ---- component block -> LDS (coalesced) -> registers ------------------------------------------------------------------
-    float mu[DP], rd[DP], Lr[T > 0 ? T : 1];
-    if (has_comp)
-        for (int i = lane; i < PK::STRIDE; i += 64) Pw[i] = packed[(size_t)k * PK::STRIDE + i];
-    for (int c = D1; c < W; ++c) Yw[lane * LDW + c] = 0.f;               // padded columns of the Y tile stay zero
-    __syncthreads();
+// Row tile [rows, D] (contiguous in memory) -> LDS image with row stride ld, all loads of a thread in flight at once:
+// 16-byte loads when the tile is 16-byte aligned, one division per float4; A minus B when B is given.
+template <int VMAX>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ A, const float* __restrict__ B, int total, int D,
+                                           float* dst, int ld, int tid) {
+    const bool vec = ((reinterpret_cast<uintptr_t>(A) | (B ? reinterpret_cast<uintptr_t>(B) : 0)) & 15) == 0;
+    if (vec) {
+        const int nv = total >> 2;
+        float4 v[VMAX];
 #pragma unroll
-    for (int i = 0; i < DP; ++i) { mu[i] = has_comp ? Pw[PK::MU + i] : 0.f; rd[i] = has_comp ? Pw[PK::RD + i] : 1.f; }
-#pragma unroll
-    for (int i = 0; i < T; ++i) Lr[i] = has_comp ? Pw[PK::LROW + i] : 0.f;
-
-    f32x16 acc;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) acc[t] = 0.f;
-    float m_run = -3.0e38f;
-    const int col = lane & 31, half = lane >> 5;
-
-    // software pipeline: the global loads of tile t+1 (x, g and the importance-weight logits) are issued before tile t is
-    // computed and land in LDS afterwards, so their latency hides behind the substitution + MFMA of tile t
-    constexpr int QX = (64 * DP + 255) / 256;
-    float xr[QX], gr[QX];
-    float a_next = -3.0e38f;
-    auto issue_loads = [&](int tile) {
-        const int n0 = tile * 64;
-        const int n_here = min(64, N - n0);
-#pragma unroll
-        for (int q = 0; q < QX; ++q) {
-            const int e = tid + 256 * q;
-            const bool ok = e < 64 * D && e / D < n_here;
-            const size_t gi = (size_t)n0 * D + e;
-            xr[q] = ok ? X[gi] : 0.f;
-            gr[q] = ok ? TG[gi] - QG[gi] : 0.f;                          // g = grad log p~ - grad log q (:248)
-        }
-        const int n = n0 + lane;
-        a_next = -3.0e38f;
-        if (has_comp && n < N) {
-            if (own_only) a_next = (mapping[n] + map_offset == k) ? 0.f : -3.0e38f;
-            else a_next = ld[(size_t)k * N + n] - bg[n];
-        }
-    };
-    auto commit_loads = [&](int tile, int buf) {
-        const int n_here = min(64, N - tile * 64);
-        float* xs = Xs + buf * 64 * ldx;
-        float* gs = Gs + buf * 64 * LDW;
-#pragma unroll
-        for (int q = 0; q < QX; ++q) {
-            const int e = tid + 256 * q;
-            if (e < 64 * D) {
-                xs[(e / D) * ldx + (e % D)] = xr[q];
-                gs[(e / D) * LDW + (e % D)] = gr[q];
+        for (int u = 0; u < VMAX; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < nv) {
+                v[u] = reinterpret_cast<const float4*>(A)[idx];
+                if (B) {
+                    const float4 b = reinterpret_cast<const float4*>(B)[idx];
+                    v[u].x -= b.x; v[u].y -= b.y; v[u].z -= b.z; v[u].w -= b.w;
+                }
             }
         }
-        if (tid < 64) gs[tid * LDW + D] = (tid < n_here) ? 1.f : 0.f;    // the appended 1 of [g;1]
-    };
-    // zero the padded columns of both g buffers once
-    for (int e = tid; e < 2 * 64 * (W - D1); e += 256) {
-        const int r = e / (W - D1), c = D1 + e % (W - D1);
-        Gs[r * LDW + c] = 0.f;
+#pragma unroll
+        for (int u = 0; u < VMAX; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < nv) {
+                int r = (4 * idx) / D, c = (4 * idx) - r * D;
+                const float vals[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    dst[r * ld + c] = vals[q];
+                    if (++c == D) { c = 0; ++r; }
+                }
+            }
+        }
+        for (int e = 4 * nv + tid; e < total; e += 256) dst[(e / D) * ld + (e % D)] = B ? A[e] - B[e] : A[e];
+    } else {
+        for (int e = tid; e < total; e += 256) dst[(e / D) * ld + (e % D)] = B ? A[e] - B[e] : A[e];
     }
-    if (tile_begin < tile_end) { issue_loads(tile_begin); commit_loads(tile_begin, 0); }
+}
+
+// Wave-per-component form (D <= 24): the workgroup stages a 256-sample tile once; wave w then takes the components
+// k_begin + w, + 4, ... of the chunk and runs over all four 64-sample sub-tiles itself, accumulating the augmented
+// matrix in its MFMA registers with an online rescale of the running maximum.  Nothing is merged across waves and the
+// component loop has no block barrier: one partial per (component, tile) leaves straight from the accumulators.  A
+// component's block is read through the scalar cache four times in a row (once per sub-tile) instead of by four waves
+// in four different places.
+template <int DP>
+__global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chunk, const float* __restrict__ packed,
+                                                          const float* __restrict__ X, const float* __restrict__ TG,
+                                                          const float* __restrict__ QG, int N,
+                                                          const float* __restrict__ ld, const float* __restrict__ bg,
+                                                          const int32_t* __restrict__ mapping, int map_offset, int flags,
+                                                          float* __restrict__ part, float* __restrict__ part_m) {
+    using PK = Pack<DP>;
+    constexpr int W = 32;
+    constexpr int LDW = W + 1;
+    extern __shared__ float sm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int n_tiles = gridDim.x;
+    const int D1 = D + 1;
+    const int n0 = tile * 256;
+    const int n_here = min(256, N - n0);
+    float* Gs = sm;                                   // [256][LDW]  rows [g;1;0...]
+    float* Ys = sm + 256 * LDW;                       // 4 x [64][LDW] wave-private rows e*[y;1;0...]; first: x staging
+    float* Yw = Ys + wave * 64 * LDW;
+    const bool own_only = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
+
+    // ---- stage the x tile (coalesced); every lane keeps its row of each of the four sub-tiles ---------------------------
+    const int ldx = D | 1;
+    constexpr int VMAX = (DP + 3) / 4;
+    stage_rows<VMAX>(X + (size_t)n0 * D, nullptr, n_here * D, D, Ys, ldx, tid);
+    for (int e = tid; e < 256 * LDW; e += 256) Gs[e] = ((e % LDW) == D && e / LDW < n_here) ? 1.f : 0.f;   // [.;1] column
     __syncthreads();
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
-        const int buf = (tile - tile_begin) & 1;
-        const float a_log = a_next;
-        const bool more = tile + 1 < tile_end;
-        if (more) issue_loads(tile + 1);
-        const int n = tile * 64 + lane;
-        const bool valid = n < N;
-        const float* xs = Xs + buf * 64 * ldx;
-        const float* gs = Gs + buf * 64 * LDW;
-        if (has_comp) {
-            const float m_new = fmaxf(m_run, wave_max(a_log));
-            const float rescale = __expf(m_run - m_new);
-            m_run = m_new;
-            const float e = (valid && a_log > -1.0e38f) ? __expf(a_log - m_new) : 0.f;
-            acc *= rescale;
-            // z = L^-1 (x - mu) in place, then y = L^-T z in place (register operands only)
-            float v[DP];
+    float x[4][DP];
 #pragma unroll
-            for (int i = 0; i < DP; ++i) v[i] = (i < D) ? xs[lane * ldx + i] - mu[i] : 0.f;
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int i = 0; i < DP; ++i) {
-                float t = v[i];
+        for (int i = 0; i < DP; ++i) x[t][i] = (64 * t + lane < n_here && i < D) ? Ys[(64 * t + lane) * ldx + i] : 0.f;
+    __syncthreads();                                   // x rows are in registers: Ys may be reused
+    // g = grad log p~ - grad log q (:248) into the first D columns of Gs
+    stage_rows<VMAX>(TG + (size_t)n0 * D, QG + (size_t)n0 * D, n_here * D, D, Gs, LDW, tid);
+    __syncthreads();
+    for (int c = D1; c < W; ++c) Yw[lane * LDW + c] = 0.f;
+    __syncthreads();
+
+    const int col = lane & 31, half = lane >> 5;
+    const int k_begin = blockIdx.y * chunk;
+    const int k_end = min(K, k_begin + chunk);
+    // per-sample constants of the four sub-tiles; the log-density row of the NEXT component is fetched while the
+    // current one is being worked on (an L2 round trip per sub-tile would otherwise sit in front of every wave_max)
+    float bgv[4], la[4];
+    int mp[4];
 #pragma unroll
-                for (int j = 0; j < i; ++j) t = fmaf(-Lr[PK::rowofs(i) + j], v[j], t);
-                v[i] = t * rd[i];
+    for (int t = 0; t < 4; ++t) {
+        const bool v = 64 * t + lane < n_here;
+        const int n = n0 + 64 * t + lane;
+        bgv[t] = (v && !own_only) ? bg[n] : 0.f;
+        mp[t] = (v && own_only) ? mapping[n] + map_offset : -1;
+        la[t] = (v && !own_only && k_begin + wave < k_end) ? ld[(size_t)(k_begin + wave) * N + n] : 0.f;
+    }
+    for (int k = k_begin + wave; k < k_end; k += 4) {
+        const float* __restrict__ P = packed + (size_t)k * PK::STRIDE;
+        float la_next[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            la_next[t] = (64 * t + lane < n_here && !own_only && k + 4 < k_end) ? ld[(size_t)(k + 4) * N + n0 + 64 * t + lane] : 0.f;
+        f32x16 acc;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+        float M = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (64 * t >= n_here) break;
+            const bool valid = 64 * t + lane < n_here;
+            float a_log = -3.0e38f;
+            if (valid) {
+                if (own_only) a_log = (mp[t] == k) ? 0.f : -3.0e38f;
+                else a_log = la[t] - bgv[t];
             }
+            const float m_t = wave_max(a_log);
+            if (m_t > M) {                                             // wave-uniform
+                const float f = __expf(M - m_t);
 #pragma unroll
-            for (int i = DP - 1; i >= 0; --i) {
-                float t = v[i];
-#pragma unroll
-                for (int j = i + 1; j < DP; ++j) t = fmaf(-Lr[PK::rowofs(j) + i], v[j], t);
-                v[i] = t * rd[i];
+                for (int r = 0; r < 16; ++r) acc[r] *= f;
+                M = m_t;
             }
+            const float e = (valid && a_log > -1.0e38f) ? __expf(a_log - M) : 0.f;
+            float z[DP], y[DP];
+#ifdef STEIN_EXP_NO_SUBST
+#pragma unroll
+            for (int i = 0; i < DP; ++i) { z[i] = x[t][i] + P[i]; y[i] = z[i]; }
+#else
+            forward_subst_s<DP>(P, x[t], z);
+            backward_subst_s<DP>(P, z, y);
+#endif
 #pragma unroll
             for (int i = 0; i < DP; ++i)
-                if (i < D) Yw[lane * LDW + i] = e * v[i];
+                if (i < D) Yw[lane * LDW + i] = e * y[i];
             Yw[lane * LDW + D] = e;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            // all 64 operand reads in flight, then the 32 dependent MFMAs
-            float af[32], bf[32];
+            const float* Gt = Gs + (64 * t + half) * LDW + col;
+            const float* Yt = Yw + half * LDW + col;
+#ifndef STEIN_EXP_NO_MFMA
 #pragma unroll
-            for (int s2 = 0; s2 < 32; ++s2) {
-                af[s2] = gs[(2 * s2 + half) * LDW + col];
-                bf[s2] = Yw[(2 * s2 + half) * LDW + col];
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 32; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s2], bf[s2], acc, 0, 0, 0);
+            for (int s2 = 0; s2 < 32; ++s2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Gt[2 * s2 * LDW], Yt[2 * s2 * LDW], acc, 0, 0, 0);
+#else
+            acc[0] += Gt[0] + Yt[0];
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
         }
-        if (more) commit_loads(tile + 1, buf ^ 1);
-        __syncthreads();       // tile t+1 visible to every wave; buffers of tile t free for the loads issued next round
-    }
-    if (!has_comp) return;
-    // ---- (component, chunk) partial straight from the accumulator registers -----------------------------------------------
-    float* out = part + ((size_t)k * n_chunks + chunk) * (size_t)(D1 * D1);
+        float* out = part + ((size_t)k * n_tiles + tile) * (size_t)(D1 * D1);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        const int i = (t & 3) + 8 * (t >> 2) + 4 * half;
-        if (i < D1 && col < D1) out[i * D1 + col] = acc[t];
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (i < D1 && col < D1) out[i * D1 + col] = acc[r];
+        }
+        if (lane == 0) part_m[(size_t)k * n_tiles + tile] = M;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) la[t] = la_next[t];
     }
-    if (lane == 0) part_m[(size_t)k * n_chunks + chunk] = m_run;
 }
 
 template <int DP>
-static int launch_stein_cs(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
-                           const float* qgrad, const float* bg, const float* tgrad, const int32_t* mapping,
-                           int map_offset, int flags, float* H_neg, float* g_neg) {
-    using PK = Pack<DP>;
+static int launch_stein_wc(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
+                           const float* qgrad, const float* bg, const float* tgrad, const int32_t* mapping, int map_offset,
+                           int flags, float* H_neg, float* g_neg) {
+    constexpr int LDW = 33;
     const int D1 = D + 1;
-    const int groups = (K + 3) / 4;
-    const int n_tiles = (N + 63) / 64;
-    // one workgroup per CU (the register-resident component limits occupancy to one wave per SIMD): chunks ~ CUs / groups
-    int n_chunks = ctx->num_cus / groups;
-    if (n_chunks < 1) n_chunks = 1;
-    if (n_chunks > n_tiles) n_chunks = n_tiles;
-    const int tiles_per_chunk = (n_tiles + n_chunks - 1) / n_chunks;
-    n_chunks = (n_tiles + tiles_per_chunk - 1) / tiles_per_chunk;
-    const size_t part_floats = (size_t)K * n_chunks * D1 * D1;
-    int rc = gmmvi_ws_reserve(ctx, (part_floats + (size_t)K * n_chunks) * sizeof(float));
+    const int n_tiles = (N + 255) / 256;
+    // components per workgroup: a multiple of the four waves, ~2 workgroups per CU in flight
+    int chunk = (int)(((long)n_tiles * K + 2L * ctx->num_cus - 1) / (2L * ctx->num_cus));
+    chunk = ((chunk + 3) / 4) * 4;
+    if (chunk < 4) chunk = 4;
+    if (chunk > 16) chunk = 16;
+    static const int env_chunk = getenv("GMMVI_STEIN_CHUNK") ? atoi(getenv("GMMVI_STEIN_CHUNK")) : 0;
+    if (env_chunk > 0) chunk = env_chunk;
+    const int n_chunks = (K + chunk - 1) / chunk;
+    const size_t part_floats = (size_t)K * n_tiles * D1 * D1;
+    int rc = gmmvi_ws_reserve(ctx, (part_floats + (size_t)K * n_tiles) * sizeof(float));
     if (rc != GMMVI_OK) return rc;
     float* part = (float*)ctx->ws;
     float* part_m = part + part_floats;
-    const size_t shmem = ((size_t)2 * 64 * (D | 1) + 2 * 64 * 33 + 4 * 64 * 33 + 4 * PK::STRIDE) * sizeof(float);
+    const size_t shmem = (size_t)(256 + 4 * 64) * LDW * sizeof(float);
     static bool attr_set = false;
-    if (!attr_set && shmem > 64 * 1024) {
-        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_cs_kernel<DP>,
+    if (!attr_set) {
+        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_wc_kernel<DP>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         attr_set = true;
     }
     {
         GMMVI_PROF(ctx, "stein_partial");
-        hipLaunchKernelGGL((stein_cs_kernel<DP>), dim3(n_chunks, groups), dim3(256), shmem, ctx->stream, K, D,
-                           tiles_per_chunk, packed, X, tgrad, qgrad, N, ld, bg, mapping, map_offset, flags, part, part_m);
+        hipLaunchKernelGGL((stein_wc_kernel<DP>), dim3(n_tiles, n_chunks), dim3(256), shmem, ctx->stream, K, D, chunk,
+                           packed, X, tgrad, qgrad, N, ld, bg, mapping, map_offset, flags, part, part_m);
     }
     GMMVI_LAUNCH_CHECK(ctx);
     GMMVI_PROF(ctx, "stein_finalize");
-    hipLaunchKernelGGL(stein_finalize_kernel, dim3(K), dim3(256), ((size_t)D1 * D1 + n_chunks) * sizeof(float),
-                       ctx->stream, D, n_chunks, N, flags, part, part_m, H_neg, g_neg);
+    hipLaunchKernelGGL(stein_finalize_kernel, dim3(K), dim3(256), ((size_t)D1 * D1 + n_tiles) * sizeof(float), ctx->stream,
+                       D, n_tiles, N, flags, part, part_m, H_neg, g_neg);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }
+
 
 template <int DP, int NB>
 static int launch_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
@@ -459,18 +470,16 @@ extern "C" int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev
     else GMMVI_ARG_CHECK(ctx, ld_dev && bg_dev);
     const int dp = gmmvi_padded_dim(D);
     const bool two = (D + 1) > 32;
-    // The component-stationary kernel is experimental (GMMVI_STEIN_CS=1, DP <= 24): measured slower than the tiled
-    // kernel on MI355X -- at DP = 20 the register-resident L spills to AGPRs (109 vs 82 us at the north-star shape), at
-    // DP = 10 both are bound by the 32x32 MFMA tile (226 vs 165 us at K = 200, N = 20000); profiles/r01_notes.md.
-    static const bool force_cs = getenv("GMMVI_STEIN_CS") != nullptr;
-    if (force_cs && dp <= 24) {
+    // D <= 24: wave-per-component kernel (GMMVI_STEIN_TILED=1 selects the tiled kernel with its cross-wave merge)
+    static const bool force_tiled = getenv("GMMVI_STEIN_TILED") != nullptr;
+    if (!force_tiled && dp <= 24) {
         switch (dp) {
-#define GMMVI_STEIN_CS(DPV)                                                                                          \
-    case DPV: return launch_stein_cs<DPV>(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,      \
+#define GMMVI_STEIN_WC(DPV)                                                                                          \
+    case DPV: return launch_stein_wc<DPV>(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,      \
                                           mapping_dev, map_offset, flags, H_neg_out_dev, g_neg_out_dev)
-            GMMVI_STEIN_CS(2); GMMVI_STEIN_CS(4); GMMVI_STEIN_CS(8); GMMVI_STEIN_CS(10); GMMVI_STEIN_CS(12);
-            GMMVI_STEIN_CS(16); GMMVI_STEIN_CS(20); GMMVI_STEIN_CS(24);
-#undef GMMVI_STEIN_CS
+            GMMVI_STEIN_WC(2); GMMVI_STEIN_WC(4); GMMVI_STEIN_WC(8); GMMVI_STEIN_WC(10); GMMVI_STEIN_WC(12);
+            GMMVI_STEIN_WC(16); GMMVI_STEIN_WC(20); GMMVI_STEIN_WC(24);
+#undef GMMVI_STEIN_WC
             default: break;
         }
     }
