@@ -65,6 +65,9 @@ inline int gmmvi_fail(gmmvi_ctx* ctx, int code, const std::string& msg) {
 #define GMMVI_LAUNCH_CHECK(ctx) GMMVI_HIP_CHECK(ctx, hipGetLastError())
 
 int gmmvi_ws_reserve(gmmvi_ctx* ctx, size_t nbytes);
+// weights.hip: trust-region (mode 0) / direct (mode 1) weight update; exp_out (optional) receives exp(new log weights)
+int gmmvi_update_weights_internal(gmmvi_ctx* ctx, int mode, int K, float* logw_dev, const float* E_dev,
+                                  const float* stepsize_dev, float beta, float* kl_eta_out_dev, float* exp_out_dev);
 
 // ---- padded dimensions the register-resident kernels are instantiated for --------------------------------
 // A problem of dimension D runs in the smallest DP >= D; padded coordinates carry x = mu = 0, L_ii = 1, so

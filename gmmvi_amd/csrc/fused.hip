@@ -1,15 +1,48 @@
 // gmmvi_train_iter_samtron: the whole SAMTRON iteration (GMMVI.train_iter, optimization/gmmvi.py:146-174, with a
 // component-based sample selector at reuse ratio 0) issued from ONE host call.  It is exactly the composition of the
 // public entry points of this library in the order the Python modules call them -- no extra arithmetic lives here --
+// (the element-wise bookkeeping between them -- DB mapping offset, model snapshot into the DB, the two stepsize rules,
+// the weight-history column -- is folded into one prep kernel / the weight-update kernel, same arithmetic per element)
 // so that the fast path and the modular plug-in path produce identical results (tests/test_hip_fused.py).  Purpose:
 // the modular path costs ~20 Python->C transitions per iteration (~340 us of host time, more than the kernels take).
 #include "common.h"
+#include "stepsize_rules.h"
 
 namespace {
 struct Arena {
     float *ld, *lq, *qgrad, *bg, *H, *g, *E;
     int32_t *mapping, *success;
 };
+
+struct PrepArgs {
+    // DB mapping: dst[i] = src[i] + base
+    int32_t* map_dst; const int32_t* map_src; int32_t map_base; int n_map;
+    // model snapshot into the sample DB (sample_db.py:113-124): up to three word-wise copies
+    uint32_t* cdst[3]; const uint32_t* csrc[3]; unsigned long long cwords[3];
+    // stepsize rules
+    int K; int cs_mode; float* stepsizes; const float* reward_prev; const float* reward_last;
+    float cs_min, cs_max, cs_inc, cs_dec;
+    int ws_mode; const float* logw; float* wstate; float ws_min, ws_max, ws_inc, ws_dec;
+};
+
+// block 0: the O(K) stepsize rules (wave 0 also runs the weight-stepsize reduction); blocks >= 1: copies
+__global__ __launch_bounds__(256) void iter_prep_kernel(PrepArgs a) {
+    if (blockIdx.x == 0) {
+        if (a.cs_mode == 1)
+            for (int k = threadIdx.x; k < a.K; k += 256)
+                a.stepsizes[k] = component_stepsize_rule(a.stepsizes[k], a.reward_prev[k], a.reward_last[k], a.cs_min,
+                                                         a.cs_max, a.cs_inc, a.cs_dec);
+        if (a.ws_mode == 1 && threadIdx.x < 64)
+            weight_stepsize_wave(a.K, a.logw, a.reward_last, a.wstate, a.ws_min, a.ws_max, a.ws_inc, a.ws_dec, threadIdx.x);
+        return;
+    }
+    const unsigned long long tid = (unsigned long long)(blockIdx.x - 1) * 256 + threadIdx.x;
+    const unsigned long long step = (unsigned long long)(gridDim.x - 1) * 256;
+    for (unsigned long long i = tid; i < (unsigned long long)a.n_map; i += step) a.map_dst[i] = a.map_src[i] + a.map_base;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (unsigned long long i = tid; i < a.cwords[c]; i += step) a.cdst[c][i] = a.csrc[c][i];
+}
 }  // namespace
 
 static int arena_reserve(gmmvi_ctx* ctx, size_t floats) {
@@ -56,7 +89,28 @@ extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan
     // ---- sample selection: draw, evaluate the target, append to the DB (sample_selector.py:160-219) --------------------
     GMMVI_TRY(gmmvi_sample_components(ctx, K, D, p->means, p->chols, p->offsets, N, p->seed, p->first_index, 0, nullptr, x,
                                       a.mapping));
-    GMMVI_TRY(gmmvi_add_scalar_i32(ctx, p->db_mapping, a.mapping, p->mapping_base, (size_t)N));
+    {
+        PrepArgs q{};
+        q.map_dst = p->db_mapping; q.map_src = a.mapping; q.map_base = p->mapping_base; q.n_map = N;
+        if (p->db_means && p->db_chols && p->db_packed) {
+            q.cdst[0] = (uint32_t*)p->db_means; q.csrc[0] = (const uint32_t*)p->means; q.cwords[0] = (size_t)K * D;
+            q.cdst[1] = (uint32_t*)p->db_chols; q.csrc[1] = (const uint32_t*)p->chols; q.cwords[1] = (size_t)K * D * D;
+            q.cdst[2] = (uint32_t*)p->db_packed; q.csrc[2] = (const uint32_t*)p->packed;
+            q.cwords[2] = (size_t)K * gmmvi_packed_stride(D);
+        }
+        q.K = K; q.cs_mode = p->component_stepsize_mode; q.stepsizes = p->stepsizes;
+        q.reward_prev = p->reward_prev; q.reward_last = p->reward_last;
+        q.cs_min = p->cs_min; q.cs_max = p->cs_max; q.cs_inc = p->cs_inc; q.cs_dec = p->cs_dec;
+        q.ws_mode = p->weight_stepsize_mode; q.logw = p->logw; q.wstate = p->wstate;
+        q.ws_min = p->ws_min; q.ws_max = p->ws_max; q.ws_inc = p->ws_inc; q.ws_dec = p->ws_dec;
+        const unsigned long long words = (unsigned long long)N + q.cwords[0] + q.cwords[1] + q.cwords[2];
+        int blocks = (int)((words + 1023) / 1024);
+        if (blocks > 512) blocks = 512;
+        if (blocks < 1) blocks = 1;
+        GMMVI_PROF(ctx, "iter_prep");
+        hipLaunchKernelGGL(iter_prep_kernel, dim3(1 + blocks), dim3(256), 0, ctx->stream, q);
+        GMMVI_LAUNCH_CHECK(ctx);
+    }
     if (p->target_kind == 1) {
         GMMVI_TRY(gmmvi_target_planar(ctx, D, p->planar_prior_std, p->planar_goals_count, p->planar_goals,
                                       p->planar_likelihood_std, x, N, p->db_tlp, p->db_tgrad));
@@ -64,37 +118,22 @@ extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan
         GMMVI_TRY(gmmvi_mixture_eval(ctx, p->target_family, p->target_nu, p->target_K, D, p->target_packed,
                                      p->target_logw, x, N, nullptr, p->db_tlp, p->db_tgrad));
     }
-    if (p->db_means && p->db_chols && p->db_packed) {
-        void* dst[3] = {p->db_means, p->db_chols, p->db_packed};
-        const void* src[3] = {p->means, p->chols, p->packed};
-        size_t nb[3] = {(size_t)K * D * 4, (size_t)K * D * D * 4, (size_t)K * gmmvi_packed_stride(D) * 4};
-        GMMVI_TRY(gmmvi_copy_batch(ctx, 3, dst, src, nb));
-    }
     // ---- background + model density / gradient in one sweep (sample_db.py:194-228, gmm.py:274-300) ------------------------
     GMMVI_TRY(gmmvi_mixture_eval_dual(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, p->logw, p->bg_logw, x, N, a.ld, a.lq, a.qgrad,
                                       a.bg));
     // ---- component update (gmmvi.py:165-169) -----------------------------------------------------------------------------
-    if (p->component_stepsize_mode == 1)
-        GMMVI_TRY(gmmvi_component_stepsize_improvement(ctx, K, p->stepsizes, p->reward_prev, p->reward_last, p->cs_min,
-                                                       p->cs_max, p->cs_inc, p->cs_dec));
     GMMVI_TRY(gmmvi_stein(ctx, K, D, p->packed, x, N, a.ld, a.qgrad, a.bg, p->db_tgrad, nullptr, 0, p->stein_flags, a.H,
                           a.g));
     GMMVI_TRY(gmmvi_update_components_kl(ctx, K, D, p->means, p->chols, a.H, a.g, p->stepsizes, p->temperature, p->l2_init,
                                          p->last_eta, p->l2, p->num_updates, p->success_out ? p->success_out : a.success,
                                          nullptr, nullptr, p->packed_new));
     // ---- weight update (gmmvi.py:172-173) ---------------------------------------------------------------------------------
-    if (p->weight_stepsize_mode == 1)
-        GMMVI_TRY(gmmvi_weight_stepsize_improvement(ctx, K, p->logw, p->reward_last, p->wstate, p->ws_min, p->ws_max,
-                                                    p->ws_inc, p->ws_dec));
     GMMVI_TRY(gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed_new, p->logw, x, N, a.ld, a.lq, nullptr));
     GMMVI_TRY(gmmvi_expected_log_ratios(ctx, K, N, a.ld, a.bg, p->db_tlp, a.lq, p->temperature, p->logw,
                                         (p->stein_flags & GMMVI_SELF_NORMALIZED) ? 1 : 0, a.E, p->reward_next, nullptr));
     if (K > 1) {
-        if (p->weight_update_mode == 0)
-            GMMVI_TRY(gmmvi_update_weights_kl(ctx, K, p->logw, a.E, p->wstate, p->temperature, nullptr));
-        else
-            GMMVI_TRY(gmmvi_update_weights_direct(ctx, K, p->logw, a.E, p->wstate, p->temperature));
-        if (p->weight_slot) GMMVI_TRY(gmmvi_exp_f32(ctx, p->weight_slot, p->logw, (size_t)K));
+        GMMVI_TRY(gmmvi_update_weights_internal(ctx, p->weight_update_mode == 0 ? 0 : 1, K, p->logw, a.E, p->wstate,
+                                                p->temperature, nullptr, p->weight_slot));
     }
     return GMMVI_OK;
 }

@@ -2,6 +2,7 @@
 // weight update (:164-279), the direct update (:123-141) and the improvement-based
 // stepsize rules (component_stepsize_adaptation.py:165-188, weight_stepsize_adaptation.py:141-156).
 #include "common.h"
+#include "stepsize_rules.h"
 #include <cfloat>
 
 namespace {
@@ -112,7 +113,8 @@ __device__ float weights_kl(float eta, float beta, const float* lw, const float*
 // mode 0: trust region (:193-279); mode 1: direct (:123-141).  Single wavefront; lw/E/nl live in LDS.
 __global__ __launch_bounds__(64) void update_weights_kernel(int mode, int K, float* __restrict__ logw,
                                                             const float* __restrict__ E_in, const float* __restrict__ stepsize,
-                                                            float beta, float* __restrict__ kl_eta_out) {
+                                                            float beta, float* __restrict__ kl_eta_out,
+                                                            float* __restrict__ exp_out) {
     extern __shared__ float sm[];
     float* lw = sm; float* E = sm + K; float* nl = sm + 2 * K;
     const int t = threadIdx.x;
@@ -159,7 +161,11 @@ __global__ __launch_bounds__(64) void update_weights_kernel(int mode, int K, flo
     }
     // GMM.replace_weights (models/gmm.py:181): renormalise
     const float l = wave_lse(nl, K);
-    for (int i = t; i < K; i += 64) logw[i] = nl[i] - l;
+    for (int i = t; i < K; i += 64) {
+        const float v = nl[i] - l;
+        logw[i] = v;
+        if (exp_out) exp_out[i] = expf(v);                  // GmmWrapper.replace_weights: weight history column (gmm_wrapper.py:182)
+    }
     if (t == 0 && kl_eta_out) { kl_eta_out[0] = kl; kl_eta_out[1] = eta; }
 }
 
@@ -167,8 +173,7 @@ __global__ void component_stepsize_kernel(int K, float* __restrict__ stepsizes, 
                                           const float* __restrict__ last, float mn, float mx, float inc, float dec) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
-    const float cur = stepsizes[k];
-    stepsizes[k] = (prev[k] >= last[k]) ? fmaxf(dec * cur, mn) : fminf(inc * cur, mx);    // :177-186
+    stepsizes[k] = component_stepsize_rule(stepsizes[k], prev[k], last[k], mn, mx, inc, dec);
 }
 
 // ELBO proxy sum_k w_k R_k - sum_k w_k log w_k accumulated in fp64 and rounded to fp32 before the comparison
@@ -176,19 +181,7 @@ __global__ void component_stepsize_kernel(int K, float* __restrict__ stepsizes, 
 __global__ __launch_bounds__(64) void weight_stepsize_kernel(int K, const float* __restrict__ logw,
                                                              const float* __restrict__ rewards_last, float* __restrict__ state,
                                                              float mn, float mx, float inc, float dec) {
-    double a = 0.0;
-    for (int i = threadIdx.x; i < K; i += 64) {
-        const double w = exp((double)logw[i]);
-        a += w * (double)rewards_last[i] - w * (double)logw[i];                           // :147
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-    if (threadIdx.x == 0) {
-        const float elbo = (float)a;
-        const float prev = state[1];
-        state[0] = (elbo > prev) ? fminf(inc * state[0], mx) : fmaxf(dec * state[0], mn);  // :149-156
-        state[1] = elbo;
-    }
+    weight_stepsize_wave(K, logw, rewards_last, state, mn, mx, inc, dec, threadIdx.x);
 }
 
 }  // namespace
@@ -207,25 +200,30 @@ int gmmvi_expected_log_ratios(gmmvi_ctx* ctx, int K, int N, const float* ld_dev,
     return GMMVI_OK;
 }
 
-static int launch_update_weights(gmmvi_ctx* ctx, int mode, int K, float* logw_dev, const float* E_dev,
-                                 const float* stepsize_dev, float beta, float* kl_eta_out_dev) {
+}  // extern "C"
+
+// update_weights with the weight-history column written by the same kernel (used by fused.hip); C++ linkage, not exported
+int gmmvi_update_weights_internal(gmmvi_ctx* ctx, int mode, int K, float* logw_dev, const float* E_dev,
+                                  const float* stepsize_dev, float beta, float* kl_eta_out_dev, float* exp_out_dev) {
     GMMVI_ARG_CHECK(ctx, K >= 1 && K <= 4096);
     GMMVI_ARG_CHECK(ctx, logw_dev && E_dev && stepsize_dev);
     GMMVI_PROF(ctx, "update_weights");
     hipLaunchKernelGGL(update_weights_kernel, dim3(1), dim3(64), (size_t)3 * K * sizeof(float), ctx->stream, mode, K,
-                       logw_dev, E_dev, stepsize_dev, beta, kl_eta_out_dev);
+                       logw_dev, E_dev, stepsize_dev, beta, kl_eta_out_dev, exp_out_dev);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }
 
+extern "C" {
+
 int gmmvi_update_weights_kl(gmmvi_ctx* ctx, int K, float* logw_dev, const float* E_dev, const float* stepsize_dev,
                             float beta, float* kl_eta_out_dev) {
-    return launch_update_weights(ctx, 0, K, logw_dev, E_dev, stepsize_dev, beta, kl_eta_out_dev);
+    return gmmvi_update_weights_internal(ctx, 0, K, logw_dev, E_dev, stepsize_dev, beta, kl_eta_out_dev, nullptr);
 }
 
 int gmmvi_update_weights_direct(gmmvi_ctx* ctx, int K, float* logw_dev, const float* E_dev,
                                 const float* stepsize_dev, float beta) {
-    return launch_update_weights(ctx, 1, K, logw_dev, E_dev, stepsize_dev, beta, nullptr);
+    return gmmvi_update_weights_internal(ctx, 1, K, logw_dev, E_dev, stepsize_dev, beta, nullptr, nullptr);
 }
 
 int gmmvi_component_stepsize_improvement(gmmvi_ctx* ctx, int K, float* stepsizes_dev, const float* rewards_prev_dev,
