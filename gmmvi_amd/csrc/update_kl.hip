@@ -118,23 +118,23 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
         s.y[t] = gt;
     }
     __syncthreads();
-    // ---- T1 = R_sym L (into Mc), M = L^T T1, w = L^T g~ ------------------------------------------------------------------
-    if (t < D) {
-        for (int j = 0; j < D; ++j) {
-            float a = 0.f;
+    // ---- T1 = R_sym L (into Mc), M = L^T T1, w = L^T g~ : the D^2 outputs are spread over all 64 lanes ---------------------
+    for (int o = t; o < D * D; o += 64) {
+        const int i = o / D, j = o % D;
+        float a = 0.f;
 #pragma unroll
-            for (int c = 0; c < D; ++c) a = fmaf(s.M[t * ld + c], s.L[c * ld + j], a);     // L[c][j] = 0 for c < j
-            s.Mc[t * ld + j] = a;
-        }
+        for (int c = 0; c < D; ++c) a = fmaf(s.M[i * ld + c], s.L[c * ld + j], a);         // L[c][j] = 0 for c < j
+        s.Mc[i * ld + j] = a;
     }
     __syncthreads();
-    if (t < D) {
-        for (int j = 0; j < D; ++j) {
-            float a = 0.f;
+    for (int o = t; o < D * D; o += 64) {
+        const int i = o / D, j = o % D;
+        float a = 0.f;
 #pragma unroll
-            for (int c = 0; c < D; ++c) a = fmaf(s.L[c * ld + t], s.Mc[c * ld + j], a);    // L[c][t] = 0 for c < t
-            s.M[t * ld + j] = a;
-        }
+        for (int c = 0; c < D; ++c) a = fmaf(s.L[c * ld + i], s.Mc[c * ld + j], a);        // L[c][i] = 0 for c < i
+        s.M[i * ld + j] = a;
+    }
+    if (t < D) {
         float a = 0.f;
 #pragma unroll
         for (int c = 0; c < D; ++c) a = fmaf(s.L[c * ld + t], s.y[c], a);
@@ -142,31 +142,37 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
         s.wt[t] = a;
     }
     __syncthreads();
-    if (t < D) {                                   // exact symmetry for the reflectors; keep a copy for the final step
-        for (int j = 0; j < t; ++j) {
-            const float m = 0.5f * (s.M[t * ld + j] + s.M[j * ld + t]);
-            s.M[t * ld + j] = m; s.M[j * ld + t] = m;
+    for (int o = t; o < D * D; o += 64) {          // exact symmetry for the reflectors; keep a copy for the final step
+        const int i = o / D, j = o % D;
+        if (j < i) {
+            const float m = 0.5f * (s.M[i * ld + j] + s.M[j * ld + i]);
+            s.M[i * ld + j] = m; s.M[j * ld + i] = m;
+            s.Mc[i * ld + j] = m; s.Mc[j * ld + i] = m;
+        } else if (j == i) {
+            s.Mc[i * ld + i] = s.M[i * ld + i];
         }
     }
     __syncthreads();
-    if (t < D)
-        for (int j = 0; j < D; ++j) s.Mc[t * ld + j] = s.M[t * ld + j];
-    __syncthreads();
 
-    // ---- Householder tridiagonalisation of M (in place), reflectors applied to wt -----------------------------------------
+    // ---- Householder tridiagonalisation of M (in place), reflectors applied to wt.  Every lane forms the column norms and
+    // the two dot products itself from LDS (broadcast reads): no cross-lane reduction chains on the critical path. ---------
     for (int c = 0; c + 2 < D; ++c) {
-        const bool act = (t > c) && (t < D);
-        const float x = act ? s.M[t * ld + c] : 0.f;
-        const float x1 = __shfl(x, c + 1);
-        const float tail = wsum((t > c + 1) ? x * x : 0.f);
+        const float x1 = s.M[(c + 1) * ld + c];
+        float tail = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const float xj = s.M[j * ld + c];
+            tail = (j > c + 1) ? fmaf(xj, xj, tail) : tail;
+        }
         if (!(tail > 0.f)) {                        // column already tridiagonal (also covers NaN: handled later)
             if (t == 0) s.te[c] = x1;
-            continue;
+            continue;                               // uniform: every lane computed the same tail
         }
         const float nrm = sqrtf(tail + x1 * x1);
         const float alpha = (x1 > 0.f) ? -nrm : nrm;
-        const float vv = act ? (t == c + 1 ? x - alpha : x) : 0.f;
         const float beta = 1.f / (nrm * nrm - alpha * x1);          // 2 / |v|^2, |v|^2 = 2 (alpha^2 - alpha x1)
+        const bool act = (t > c) && (t < D);
+        const float vv = act ? (t == c + 1 ? x1 - alpha : s.M[t * ld + c]) : 0.f;
         if (t < D) s.v[t] = vv;
         __syncthreads();
         float p = 0.f;
@@ -175,14 +181,25 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             for (int j = 0; j < D; ++j) p = fmaf(s.M[t * ld + j], s.v[j], p);              // v[j] = 0 for j <= c
             p *= beta;
         }
-        const float kk = 0.5f * beta * wsum(vv * p);
-        const float qq = p - kk * vv;
-        if (t < D) s.q[t] = qq;
-        const float wdot = beta * wsum(act ? vv * s.wt[t] : 0.f);
+        if (t < D) s.q[t] = p;                                                             // p_j = 0 for j <= c
         __syncthreads();
+        float kk = 0.f, wdot = 0.f;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const float vj = s.v[j];
+            kk = fmaf(vj, s.q[j], kk);
+            wdot = fmaf(vj, s.wt[j], wdot);
+        }
+        kk *= 0.5f * beta;
+        wdot *= beta;
+        const float qq = p - kk * vv;
+        __syncthreads();                            // everyone has read wt / q before they change
         if (act) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) s.M[t * ld + j] -= vv * s.q[j] + qq * s.v[j];      // q[j] = v[j] = 0 for j <= c
+            for (int j = 0; j < D; ++j) {
+                const float vj = s.v[j];
+                s.M[t * ld + j] -= vv * (s.q[j] - kk * vj) + qq * vj;                      // q[j] = v[j] = 0 for j <= c
+            }
             s.wt[t] -= wdot * vv;
         }
         if (t == 0) s.te[c] = alpha;
@@ -236,8 +253,10 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
     }
     if (success) {
         // ---- B = I + Mc/eta*  ->  UL factor U (upper, B = U U^T) built in M -------------------------------------------------
-        if (t < D)
-            for (int j = t; j < D; ++j) s.M[t * ld + j] = (j == t ? 1.f : 0.f) + s.Mc[t * ld + j] * inv;
+        for (int o = t; o < D * D; o += 64) {
+            const int i = o / D, j = o % D;
+            if (j >= i) s.M[i * ld + j] = (j == i ? 1.f : 0.f) + s.Mc[i * ld + j] * inv;
+        }
         __syncthreads();
         for (int j = D - 1; j >= 0 && success; --j) {
             float a = 0.f;
@@ -245,18 +264,31 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
                 a = s.M[t * ld + j];
                 for (int c = j + 1; c < D; ++c) a = fmaf(-s.M[t * ld + c], s.M[j * ld + c], a);
             }
-            const float p = __shfl(a, j);
+            const float p = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), j));   // j is wave-uniform
             if (!(p > 0.f) || !(p < FLT_MAX)) { success = false; break; }
             const float d = sqrtf(p);
-            __syncthreads();
-            if (t == j) s.M[t * ld + j] = d;
+            if (t == j) s.M[t * ld + j] = d;                  // column j only: nobody reads it in this step
             else if (t < j) s.M[t * ld + j] = a / d;
             __syncthreads();
         }
     }
     if (success) {
-        // ---- Uinv (upper) into Mc: lane c solves U x = e_c from the bottom ---------------------------------------------------
-        if (t < D) {
+        // ---- Uinv (upper) into Mc: lane c solves U x = e_c from the bottom, its column in registers when D is static ------
+        if (DC > 0) {
+            constexpr int DR = DC > 0 ? DC : 1;
+            float xr[DR];
+#pragma unroll
+            for (int i = DR - 1; i >= 0; --i) {
+                float a = (i == t) ? 1.f : 0.f;
+#pragma unroll
+                for (int j = i + 1; j < DR; ++j) a = fmaf(-s.M[i * ld + j], xr[j], a);    // x_j = 0 for j > t
+                xr[i] = (i <= t) ? a / s.M[i * ld + i] : 0.f;
+            }
+            if (t < D) {
+#pragma unroll
+                for (int i = 0; i < DR; ++i) s.Mc[i * ld + t] = xr[i];
+            }
+        } else if (t < D) {
             for (int i = D - 1; i >= 0; --i) {
                 float a = (i == t) ? 1.f : 0.f;
                 for (int j = i + 1; j < D; ++j) a = fmaf(-s.M[i * ld + j], s.Mc[j * ld + t], a);   // Mc[j][t] = 0, j > t
@@ -279,7 +311,8 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             s.y[t] = a;
         }
         __syncthreads();
-        // new mean mu' = mu - L y / eta* ; new factor L' = L Uinv^T (row t), written to M (U no longer needed)
+        // new mean mu' = mu - L y / eta* ; new factor L' = L Uinv^T, its D(D+1)/2 entries spread over the 64 lanes,
+        // written to M (U no longer needed)
         float new_mu = 0.f;
         bool bad = false;
         if (t < D) {
@@ -290,15 +323,16 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             bad = !(new_mu == new_mu);
         }
         __syncthreads();
-        if (t < D) {
-            for (int j = 0; j <= t; ++j) {
+        for (int o = t; o < D * D; o += 64) {
+            const int i = o / D, j = o % D;
+            if (j <= i) {
                 float a = 0.f;
 #pragma unroll
-                for (int c = 0; c < D; ++c) a = fmaf(s.L[t * ld + c], s.Mc[j * ld + c], a);
-                s.M[t * ld + j] = a;
+                for (int c = 0; c < D; ++c) a = fmaf(s.L[i * ld + c], s.Mc[j * ld + c], a);
+                s.M[i * ld + j] = a;
                 bad |= !(a == a);
+                if (i == j) bad |= !(a > 0.f);
             }
-            bad |= !(s.M[t * ld + t] > 0.f);
         }
         success = (__any(bad) == 0);                                                       // :493 is_nan(new_chol)
         __syncthreads();
