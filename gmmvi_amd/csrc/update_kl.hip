@@ -154,60 +154,139 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
     }
     __syncthreads();
 
-    // ---- Householder tridiagonalisation of M (in place), reflectors applied to wt.  Every lane forms the column norms and
-    // the two dot products itself from LDS (broadcast reads): no cross-lane reduction chains on the critical path. ---------
+    // ---- Householder tridiagonalisation of M, reflectors applied to wt.  Every lane forms the column norm and the two dot
+    // products itself from broadcast LDS vectors: no cross-lane reduction chains on the critical path.  With a static D the
+    // lane keeps its row of M (and a replica of wt) in registers, so a step costs ~20 LDS operations instead of ~200 --
+    // a single wavefront pays the full issue latency of every one of them. --------------------------------------------------
+    if (DC > 0) {
+        constexpr int DR = DC > 0 ? DC : 1;
+        constexpr int D4 = (DR + 3) / 4;
+        float mrow[DR], wtr[DR];
+#pragma unroll
+        for (int j = 0; j < DR; ++j) { mrow[j] = (t < DR) ? s.M[t * ld + j] : 0.f; wtr[j] = s.wt[j]; }
+        float* xv = s.pr;                           // column c of M and p as 16-byte aligned broadcast vectors (the probe
+        float* pv = s.pr + 64;                      // scratch is free until the search starts; 3 D (D + 4) floats precede it)
+        for (int c = 0; c + 2 < DR; ++c) {
+            float mc = 0.f;                         // mrow[c] (c is wave-uniform but not a compile-time constant)
+#pragma unroll
+            for (int j = 0; j < DR; ++j) mc = (j == c) ? mrow[j] : mc;
+            if (t < DR) xv[t] = mc;
+            __syncthreads();
+            float x[4 * D4];
+#pragma unroll
+            for (int q4 = 0; q4 < D4; ++q4) {
+                const float4 v4 = reinterpret_cast<const float4*>(xv)[q4];
+                x[4 * q4] = v4.x; x[4 * q4 + 1] = v4.y; x[4 * q4 + 2] = v4.z; x[4 * q4 + 3] = v4.w;
+            }
+            float x1 = 0.f, tail = 0.f;
+#pragma unroll
+            for (int j = 0; j < DR; ++j) {
+                x1 = (j == c + 1) ? x[j] : x1;
+                tail = (j > c + 1) ? fmaf(x[j], x[j], tail) : tail;
+            }
+            if (!(tail > 0.f)) {                    // column already tridiagonal (also covers NaN: handled later)
+                if (t == 0) s.te[c] = x1;
+                __syncthreads();
+                continue;                           // uniform: every lane computed the same tail
+            }
+            const float nrm = sqrtf(tail + x1 * x1);
+            const float alpha = (x1 > 0.f) ? -nrm : nrm;
+            const float beta = 1.f / (nrm * nrm - alpha * x1);      // 2 / |v|^2, |v|^2 = 2 (alpha^2 - alpha x1)
+            // v_j: 0 for j <= c, x1 - alpha for j = c + 1, x_j below
+#pragma unroll
+            for (int j = 0; j < DR; ++j) x[j] = (j <= c) ? 0.f : (j == c + 1 ? x1 - alpha : x[j]);
+            const bool act = (t > c) && (t < DR);
+            float vv = 0.f, p = 0.f;
+#pragma unroll
+            for (int j = 0; j < DR; ++j) { vv = (j == t) ? x[j] : vv; p = fmaf(mrow[j], x[j], p); }
+            p = act ? p * beta : 0.f;
+            vv = act ? vv : 0.f;
+            if (t < DR) pv[t] = p;
+            __syncthreads();
+            float pj[4 * D4];
+#pragma unroll
+            for (int q4 = 0; q4 < D4; ++q4) {
+                const float4 v4 = reinterpret_cast<const float4*>(pv)[q4];
+                pj[4 * q4] = v4.x; pj[4 * q4 + 1] = v4.y; pj[4 * q4 + 2] = v4.z; pj[4 * q4 + 3] = v4.w;
+            }
+            float kk = 0.f, wdot = 0.f;
+#pragma unroll
+            for (int j = 0; j < DR; ++j) { kk = fmaf(x[j], pj[j], kk); wdot = fmaf(x[j], wtr[j], wdot); }
+            kk *= 0.5f * beta;
+            wdot *= beta;
+            const float qq = p - kk * vv;
+#pragma unroll
+            for (int j = 0; j < DR; ++j) {
+                mrow[j] -= vv * (pj[j] - kk * x[j]) + qq * x[j];
+                wtr[j] -= wdot * x[j];              // replica of wt in every lane
+            }
+            if (t == 0) s.te[c] = alpha;
+        }
+        __syncthreads();
+        if (t < DR) {
+            float dd = 0.f, sub = 0.f, wme = 0.f;
+#pragma unroll
+            for (int j = 0; j < DR; ++j) { dd = (j == t) ? mrow[j] : dd; wme = (j == t) ? wtr[j] : wme; }
+            sub = mrow[DR >= 2 ? DR - 2 : 0];
+            s.td[t] = dd;
+            s.wt[t] = wme;
+            if (t == DR - 1 && DR >= 2) s.te[DR - 2] = sub;
+        }
+        __syncthreads();
+    } else {
     for (int c = 0; c + 2 < D; ++c) {
-        const float x1 = s.M[(c + 1) * ld + c];
-        float tail = 0.f;
+            const float x1 = s.M[(c + 1) * ld + c];
+            float tail = 0.f;
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const float xj = s.M[j * ld + c];
-            tail = (j > c + 1) ? fmaf(xj, xj, tail) : tail;
-        }
-        if (!(tail > 0.f)) {                        // column already tridiagonal (also covers NaN: handled later)
-            if (t == 0) s.te[c] = x1;
-            continue;                               // uniform: every lane computed the same tail
-        }
-        const float nrm = sqrtf(tail + x1 * x1);
-        const float alpha = (x1 > 0.f) ? -nrm : nrm;
-        const float beta = 1.f / (nrm * nrm - alpha * x1);          // 2 / |v|^2, |v|^2 = 2 (alpha^2 - alpha x1)
-        const bool act = (t > c) && (t < D);
-        const float vv = act ? (t == c + 1 ? x1 - alpha : s.M[t * ld + c]) : 0.f;
-        if (t < D) s.v[t] = vv;
-        __syncthreads();
-        float p = 0.f;
-        if (act) {
+            for (int j = 0; j < D; ++j) {
+                const float xj = s.M[j * ld + c];
+                tail = (j > c + 1) ? fmaf(xj, xj, tail) : tail;
+            }
+            if (!(tail > 0.f)) {                        // column already tridiagonal (also covers NaN: handled later)
+                if (t == 0) s.te[c] = x1;
+                continue;                               // uniform: every lane computed the same tail
+            }
+            const float nrm = sqrtf(tail + x1 * x1);
+            const float alpha = (x1 > 0.f) ? -nrm : nrm;
+            const float beta = 1.f / (nrm * nrm - alpha * x1);          // 2 / |v|^2, |v|^2 = 2 (alpha^2 - alpha x1)
+            const bool act = (t > c) && (t < D);
+            const float vv = act ? (t == c + 1 ? x1 - alpha : s.M[t * ld + c]) : 0.f;
+            if (t < D) s.v[t] = vv;
+            __syncthreads();
+            float p = 0.f;
+            if (act) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) p = fmaf(s.M[t * ld + j], s.v[j], p);              // v[j] = 0 for j <= c
-            p *= beta;
-        }
-        if (t < D) s.q[t] = p;                                                             // p_j = 0 for j <= c
-        __syncthreads();
-        float kk = 0.f, wdot = 0.f;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const float vj = s.v[j];
-            kk = fmaf(vj, s.q[j], kk);
-            wdot = fmaf(vj, s.wt[j], wdot);
-        }
-        kk *= 0.5f * beta;
-        wdot *= beta;
-        const float qq = p - kk * vv;
-        __syncthreads();                            // everyone has read wt / q before they change
-        if (act) {
+                for (int j = 0; j < D; ++j) p = fmaf(s.M[t * ld + j], s.v[j], p);              // v[j] = 0 for j <= c
+                p *= beta;
+            }
+            if (t < D) s.q[t] = p;                                                             // p_j = 0 for j <= c
+            __syncthreads();
+            float kk = 0.f, wdot = 0.f;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 const float vj = s.v[j];
-                s.M[t * ld + j] -= vv * (s.q[j] - kk * vj) + qq * vj;                      // q[j] = v[j] = 0 for j <= c
+                kk = fmaf(vj, s.q[j], kk);
+                wdot = fmaf(vj, s.wt[j], wdot);
             }
-            s.wt[t] -= wdot * vv;
+            kk *= 0.5f * beta;
+            wdot *= beta;
+            const float qq = p - kk * vv;
+            __syncthreads();                            // everyone has read wt / q before they change
+            if (act) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const float vj = s.v[j];
+                    s.M[t * ld + j] -= vv * (s.q[j] - kk * vj) + qq * vj;                      // q[j] = v[j] = 0 for j <= c
+                }
+                s.wt[t] -= wdot * vv;
+            }
+            if (t == 0) s.te[c] = alpha;
+            __syncthreads();
         }
-        if (t == 0) s.te[c] = alpha;
+        if (t < D) s.td[t] = s.M[t * ld + t];
+        if (t == 0 && D >= 2) s.te[D - 2] = s.M[(D - 1) * ld + (D - 2)];
         __syncthreads();
     }
-    if (t < D) s.td[t] = s.M[t * ld + t];
-    if (t == 0 && D >= 2) s.te[D - 2] = s.M[(D - 1) * ld + (D - 2)];
-    __syncthreads();
 
     // ---- speculative bisection: 63 tree nodes (6 levels) per round, one lane per node ------------------------------------
     const float eps = stepsizes[k];
