@@ -296,6 +296,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
     else { lb = fmaxf(0.f, __logf(last) - 3.f); ub = __logf(last) + 3.f; }                 // :467-471
     bool ub_ok = false, done = false;
     int probes = 0, iters = 0;
+    float kl_ub = -1.f;                 // KL at the current upper bracket end (the probe that set it)
     while (!done && iters < 1000) {                                                        // :399
         // node of this lane: heap index t (1 = root); follow its bits from the root
         float nlb = lb, nub = ub;
@@ -315,8 +316,8 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             const float diff = __shfl(ndiff, n), klv = __shfl(nkl, n), eta = __shfl(neta, n);
             if (diff < 1e-1f) { done = true; break; }                                      // :404-405
             ++probes;
-            if (fabsf(eps - klv) < 1e-1f * eps) { lb = ub = eta; done = true; break; }     // :410-413
-            if (eps > klv) { ub = eta; ub_ok = true; n = 2 * n; }                          // :415-417
+            if (fabsf(eps - klv) < 1e-1f * eps) { lb = ub = eta; kl_ub = klv; done = true; break; }   // :410-413
+            if (eps > klv) { ub = eta; ub_ok = true; kl_ub = klv; n = 2 * n; }             // :415-417
             else { lb = eta; n = 2 * n + 1; }                                              // :418-419
         }
     }
@@ -327,9 +328,88 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
     float kl_val = -1.f;
     const float inv = 1.f / eta_star;
     if (success) {
-        kl_val = __shfl(kl_tridiag<DC>(s, eta_star), 0);                                       // :480-482
+        // :480-482 evaluates KL at eta*; when eta* is the accepted bracket end (the usual case, eta* = lo >= temperature)
+        // that is the value the search already holds for exactly this eta
+        kl_val = (eta_star == lo && kl_ub >= 0.f) ? kl_ub : __shfl(kl_tridiag<DC>(s, eta_star), 0);
         success = kl_val < FLT_MAX;                                                        // :488
     }
+    if (DC > 0) {
+        // ---- static D: B = I + Mc/eta* = U U^T (U upper) factorised right-looking with the lane's row in registers; then
+        // L' = L U^-T and z = U^-1 w by one back substitution per lane (lane t: row t of L, every lane also carries w), and
+        // mu' = mu - L' z / eta*.  U is shared through an LDS image with 16-byte aligned rows (broadcast ds_read_b128). -----
+        constexpr int DR = DC > 0 ? DC : 1;
+        constexpr int LU = ((DR + 3) / 4) * 4;                     // row stride of the U image
+        float* Us = s.pr + 64;                                     // D x LU image in the (idle) probe scratch, 16-byte aligned
+        float xr[DR];                                              // B row, later the solution row (L' row t)
+        float new_mu = 0.f;
+        if (success) {
+#pragma unroll
+            for (int c = 0; c < DR; ++c)
+                xr[c] = (t < DR && c >= t) ? ((c == t ? 1.f : 0.f) + s.Mc[t * ld + c] * inv) : 0.f;
+            float* uv = s.pr;                                      // column j of U as a broadcast vector
+            for (int j = DR - 1; j >= 0; --j) {
+                float bj = 0.f;                                    // xr[j] (j is wave-uniform, not a compile-time constant)
+#pragma unroll
+                for (int c = 0; c < DR; ++c) bj = (c == j) ? xr[c] : bj;
+                const float p = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bj), j));
+                if (!(p > 0.f) || !(p < FLT_MAX)) { success = false; break; }
+                const float d = sqrtf(p);
+                const float u = (t == j) ? d : (t < j ? bj / d : 0.f);
+                if (t < DR) { uv[t] = u; Us[t * LU + j] = u; }
+                __syncthreads();
+                float uc[LU];
+#pragma unroll
+                for (int q4 = 0; q4 < LU / 4; ++q4) {
+                    const float4 v4 = reinterpret_cast<const float4*>(uv)[q4];
+                    uc[4 * q4] = v4.x; uc[4 * q4 + 1] = v4.y; uc[4 * q4 + 2] = v4.z; uc[4 * q4 + 3] = v4.w;
+                }
+#pragma unroll
+                for (int c = 0; c < DR; ++c) xr[c] = (c < j && c >= t) ? fmaf(-u, uc[c], xr[c]) : xr[c];
+                __syncthreads();
+            }
+        }
+        if (success) {
+            // back substitution U x = r for r = row t of L (x = row t of L') and, in every lane, r = w (z)
+            float zr[DR];
+#pragma unroll
+            for (int c = 0; c < DR; ++c) { xr[c] = (t < DR) ? s.L[t * ld + c] : 0.f; zr[c] = s.w[c]; }
+#pragma unroll
+            for (int i = DR - 1; i >= 0; --i) {
+                float ur[LU];
+#pragma unroll
+                for (int q4 = i / 4; q4 < LU / 4; ++q4) {
+                    const float4 v4 = reinterpret_cast<const float4*>(Us + i * LU)[q4];
+                    ur[4 * q4] = v4.x; ur[4 * q4 + 1] = v4.y; ur[4 * q4 + 2] = v4.z; ur[4 * q4 + 3] = v4.w;
+                }
+                float a = xr[i], b = zr[i];
+#pragma unroll
+                for (int j = i + 1; j < DR; ++j) { a = fmaf(-ur[j], xr[j], a); b = fmaf(-ur[j], zr[j], b); }
+                const float rd = 1.f / ur[i];
+                xr[i] = a * rd;
+                zr[i] = b * rd;
+            }
+            float acc = 0.f;
+            bool bad = false;
+#pragma unroll
+            for (int c = 0; c < DR; ++c) {
+                acc = fmaf(xr[c], zr[c], acc);
+                bad |= !(xr[c] == xr[c]);
+                if (c == t) bad |= !(xr[c] > 0.f);
+            }
+            new_mu = s.mu[t < DR ? t : 0] - acc * inv;
+            bad |= !(new_mu == new_mu);
+            success = (__any(bad && t < DR) == 0);                                         // :493 is_nan(new_chol)
+            __syncthreads();                                       // all reads of the U image are done: M becomes L'
+            if (success && t < DR) {
+#pragma unroll
+                for (int c = 0; c < DR; ++c) {
+                    s.M[t * ld + c] = xr[c];
+                    Lg[t * DR + c] = (c <= t) ? xr[c] : 0.f;
+                }
+                mug[t] = new_mu;
+            }
+        }
+    } else {
     if (success) {
         // ---- B = I + Mc/eta*  ->  UL factor U (upper, B = U U^T) built in M -------------------------------------------------
         for (int o = t; o < D * D; o += 64) {
@@ -422,6 +502,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             }
             if (t < D) mug[t] = new_mu;
         }
+    }
     }
     if (packed_out != nullptr) {
         // packed parameter block of the (new or kept) component for the density kernels: layout of common.h Pack<DP>
