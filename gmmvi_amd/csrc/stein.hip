@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, int ch
     }
 }
 
-__global__ __launch_bounds__(256) void stein_finalize_kernel(int D, int R, int N, int flags, const float* __restrict__ part,
+__global__ __launch_bounds__(1024) void stein_finalize_kernel(int D, int R, int N, int flags, const float* __restrict__ part,
                                                              const float* __restrict__ part_m, float* __restrict__ H_neg,
                                                              float* __restrict__ g_neg) {
     extern __shared__ float A[];       // (D+1)^2, then R scale factors
@@ -186,32 +186,57 @@ __global__ __launch_bounds__(256) void stein_finalize_kernel(int D, int R, int N
     float M = -3.0e38f;
     for (int r = threadIdx.x & 63; r < R; r += 64) M = fmaxf(M, part_m[(size_t)k * R + r]);
     M = wave_max(M);
-    for (int r = threadIdx.x; r < R; r += 256) scale_r[r] = __expf(part_m[(size_t)k * R + r] - M);
+    for (int r = threadIdx.x; r < R; r += blockDim.x) scale_r[r] = __expf(part_m[(size_t)k * R + r] - M);
     __syncthreads();
+    // partial sums: the R partials of an element are split over G = blockDim / 256 thread groups (r = g, g + G, ...), eight
+    // independent chains per thread keep the loads in flight; the groups are combined through LDS in fixed order
     const float* pk = part + (size_t)k * R * (size_t)(D1 * D1);
-    for (int e = threadIdx.x; e < D1 * D1; e += 256) {
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;                    // four chains in flight, fixed final order
-        int r = 0;
-        for (; r + 3 < R; r += 4) {
-            v0 = fmaf(pk[(size_t)(r + 0) * (D1 * D1) + e], scale_r[r + 0], v0);
-            v1 = fmaf(pk[(size_t)(r + 1) * (D1 * D1) + e], scale_r[r + 1], v1);
-            v2 = fmaf(pk[(size_t)(r + 2) * (D1 * D1) + e], scale_r[r + 2], v2);
-            v3 = fmaf(pk[(size_t)(r + 3) * (D1 * D1) + e], scale_r[r + 3], v3);
+    const int G = blockDim.x >> 8, g = threadIdx.x >> 8, tl = threadIdx.x & 255;
+    float* Ag = scale_r + R;                                              // [G][(D+1)^2]
+    for (int e = tl; e < D1 * D1; e += 256) {
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int r = g;
+        for (; r + 7 * G < R; r += 8 * G) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = fmaf(pk[(size_t)(r + u * G) * (D1 * D1) + e], scale_r[r + u * G], v[u]);
         }
-        for (; r < R; ++r) v0 = fmaf(pk[(size_t)r * (D1 * D1) + e], scale_r[r], v0);
-        A[e] = (v0 + v1) + (v2 + v3);
+        for (int u = 0; r < R; r += G, ++u) v[u & 7] = fmaf(pk[(size_t)r * (D1 * D1) + e], scale_r[r], v[u & 7]);
+        Ag[g * D1 * D1 + e] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < D1 * D1; e += blockDim.x) {
+        float a = 0.f;
+        for (int gg = 0; gg < G; ++gg) a += Ag[gg * D1 * D1 + e];
+        A[e] = a;
     }
     __syncthreads();
     const bool snis = (flags & GMMVI_SELF_NORMALIZED) != 0;
     // A[i][j] = sum e g_i y_j, A[i][D] = sum e g_i, A[D][D] = sum e.
     // plain importance weights: 1/N * sum exp(ld - bg) v   (ng_estimator.py:146-152), Hessian not symmetrised
     const float scale = snis ? 1.f / A[D * D1 + D] : __expf(M) / (float)N;
-    for (int e = threadIdx.x; e < D * D; e += 256) {
+    for (int e = threadIdx.x; e < D * D; e += blockDim.x) {
         const int i = e / D, j = e % D;
         const float v = snis ? 0.5f * (A[i * D1 + j] + A[j * D1 + i]) : A[i * D1 + j];
         H_neg[(size_t)k * D * D + e] = -v * scale;
     }
-    for (int i = threadIdx.x; i < D; i += 256) g_neg[(size_t)k * D + i] = -A[i * D1 + D] * scale;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) g_neg[(size_t)k * D + i] = -A[i * D1 + D] * scale;
+}
+
+static int launch_stein_finalize(gmmvi_ctx* ctx, int K, int D, int R, int N, int flags, const float* part,
+                                 const float* part_m, float* H_neg, float* g_neg) {
+    const int D1 = D + 1;
+    const size_t shmem = ((size_t)5 * D1 * D1 + R) * sizeof(float);
+    static size_t attr = 64 * 1024;
+    if (shmem > attr) {
+        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_finalize_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        attr = shmem;
+    }
+    GMMVI_PROF(ctx, "stein_finalize");
+    hipLaunchKernelGGL(stein_finalize_kernel, dim3(K), dim3(1024), shmem, ctx->stream, D, R, N, flags, part, part_m, H_neg,
+                       g_neg);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
 }
 
 // Row tile [rows, D] (contiguous in memory) -> LDS image with row stride ld, all loads of a thread in flight at once:
@@ -414,11 +439,7 @@ static int launch_stein_wc(gmmvi_ctx* ctx, int K, int D, const float* packed, co
                            packed, X, tgrad, qgrad, N, ld, bg, mapping, map_offset, flags, part, part_m);
     }
     GMMVI_LAUNCH_CHECK(ctx);
-    GMMVI_PROF(ctx, "stein_finalize");
-    hipLaunchKernelGGL(stein_finalize_kernel, dim3(K), dim3(256), ((size_t)D1 * D1 + n_tiles) * sizeof(float), ctx->stream,
-                       D, n_tiles, N, flags, part, part_m, H_neg, g_neg);
-    GMMVI_LAUNCH_CHECK(ctx);
-    return GMMVI_OK;
+    return launch_stein_finalize(ctx, K, D, n_tiles, N, flags, part, part_m, H_neg, g_neg);
 }
 
 
@@ -453,11 +474,7 @@ static int launch_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
                            chunk, packed, X, tgrad, qgrad, N, ld, bg, mapping, map_offset, flags, part, part_m);
     }
     GMMVI_LAUNCH_CHECK(ctx);
-    GMMVI_PROF(ctx, "stein_finalize");
-    hipLaunchKernelGGL(stein_finalize_kernel, dim3(K), dim3(256), ((size_t)D1 * D1 + n_tiles) * sizeof(float), ctx->stream,
-                       D, n_tiles, N, flags, part, part_m, H_neg, g_neg);
-    GMMVI_LAUNCH_CHECK(ctx);
-    return GMMVI_OK;
+    return launch_stein_finalize(ctx, K, D, n_tiles, N, flags, part, part_m, H_neg, g_neg);
 }
 
 extern "C" int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* X_dev, int N,
