@@ -17,6 +17,7 @@
 //     summation order) and the (component, tile) partial goes to a slab.
 // stein_finalize sums the slab in fixed order (bitwise reproducible), normalises, symmetrises and negates.
 #include "common.h"
+#include "wave_reduce.h"
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -45,11 +46,7 @@ __device__ __forceinline__ void backward_subst_s(const float* __restrict__ P, co
     }
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return gmmvi_wave_max(v); }
 
 template <int DP, int NB>
 __global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, int chunk, const float* __restrict__ packed,

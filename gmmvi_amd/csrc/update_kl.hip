@@ -13,15 +13,12 @@
 // "Cholesky failed" (non-positive pivot / NaN) maps to KL = float32.max and to the reject branch (:320-324, :493).
 // One wavefront per component, matrices in LDS (row stride D+1), lane = row (D <= 64).
 #include "common.h"
+#include "wave_reduce.h"
 #include <cfloat>
 
 namespace {
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float wsum(float v) { return gmmvi_wave_sum(v); }
 
 struct Ws {
     int D, ld;

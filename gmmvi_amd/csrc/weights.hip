@@ -3,20 +3,13 @@
 // stepsize rules (component_stepsize_adaptation.py:165-188, weight_stepsize_adaptation.py:141-156).
 #include "common.h"
 #include "stepsize_rules.h"
+#include "wave_reduce.h"
 #include <cfloat>
 
 namespace {
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-__device__ __forceinline__ float wmax(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
+__device__ __forceinline__ float wsum(float v) { return gmmvi_wave_sum(v); }
+__device__ __forceinline__ float wmax(float v) { return gmmvi_wave_max(v); }
 
 // block-wide reductions for 256 threads (4 waves); result identical in every thread
 __device__ float block_max(float v, float* red) {
