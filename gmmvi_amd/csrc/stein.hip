@@ -348,46 +348,49 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = 0.f;
         float M = -3.0e38f;
+        // Software pipeline over the four sub-tiles: the substitution of sub-tile t + 1 (VALU, scalar loads) is issued in the
+        // same straight-line region as the 32 MFMAs of sub-tile t, so the matrix pipe works in the shadow of the vector
+        // work of the same wave; the rescale by the running maximum sits between the regions and is branch-free.
+        float yn[DP], a_n;
+        {
+            const bool v0 = lane < n_here;
+            a_n = !v0 ? -3.0e38f : (own_only ? ((mp[0] == k) ? 0.f : -3.0e38f) : la[0] - bgv[0]);
+            float z[DP];
+            forward_subst_s<DP>(P, x[0], z);
+            backward_subst_s<DP>(P, z, yn);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            if (64 * t >= n_here) break;
-            const bool valid = 64 * t + lane < n_here;
-            float a_log = -3.0e38f;
-            if (valid) {
-                if (own_only) a_log = (mp[t] == k) ? 0.f : -3.0e38f;
-                else a_log = la[t] - bgv[t];
-            }
-            const float m_t = wave_max(a_log);
-            if (m_t > M) {                                             // wave-uniform
-                const float f = __expf(M - m_t);
+            // ---- region B: new running maximum, rescale, publish e * [y; 1] of sub-tile t ---------------------------------
+            const float m_t = wave_max(a_n);
+            const float Mn = fmaxf(M, m_t);
+            const float f = __expf(M - Mn);                            // 1 when the maximum did not move, 0 at the start
+            M = Mn;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] *= f;
-                M = m_t;
-            }
-            const float e = (valid && a_log > -1.0e38f) ? __expf(a_log - M) : 0.f;
-            float z[DP], y[DP];
-#ifdef STEIN_EXP_NO_SUBST
-#pragma unroll
-            for (int i = 0; i < DP; ++i) { z[i] = x[t][i] + P[i]; y[i] = z[i]; }
-#else
-            forward_subst_s<DP>(P, x[t], z);
-            backward_subst_s<DP>(P, z, y);
-#endif
+            for (int r = 0; r < 16; ++r) acc[r] *= f;
+            const float e = (a_n > -1.0e38f) ? __expf(a_n - M) : 0.f;
 #pragma unroll
             for (int i = 0; i < DP; ++i)
-                if (i < D) Yw[lane * LDW + i] = e * y[i];
+                if (i < D) Yw[lane * LDW + i] = e * yn[i];
             Yw[lane * LDW + D] = e;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
+            // ---- region A: MFMAs of sub-tile t  ||  substitution of sub-tile t + 1 ---------------------------------------
             const float* Gt = Gs + (64 * t + half) * LDW + col;
             const float* Yt = Yw + half * LDW + col;
-#ifndef STEIN_EXP_NO_MFMA
+            float ga[32], yb[32];
 #pragma unroll
-            for (int s2 = 0; s2 < 32; ++s2)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Gt[2 * s2 * LDW], Yt[2 * s2 * LDW], acc, 0, 0, 0);
-#else
-            acc[0] += Gt[0] + Yt[0];
-#endif
+            for (int s2 = 0; s2 < 32; ++s2) { ga[s2] = Gt[2 * s2 * LDW]; yb[s2] = Yt[2 * s2 * LDW]; }
+            if (t < 3) {
+                const bool v1 = 64 * (t + 1) + lane < n_here;
+                a_n = !v1 ? -3.0e38f : (own_only ? ((mp[t + 1 < 4 ? t + 1 : 3] == k) ? 0.f : -3.0e38f)
+                                                  : la[t + 1 < 4 ? t + 1 : 3] - bgv[t + 1 < 4 ? t + 1 : 3]);
+                float z[DP];
+                forward_subst_s<DP>(P, x[t + 1 < 4 ? t + 1 : 3], z);
+                backward_subst_s<DP>(P, z, yn);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s2], yb[s2], acc, 0, 0, 0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             __builtin_amdgcn_wave_barrier();
         }
