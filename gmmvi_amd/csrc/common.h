@@ -65,6 +65,11 @@ inline int gmmvi_fail(gmmvi_ctx* ctx, int code, const std::string& msg) {
 #define GMMVI_LAUNCH_CHECK(ctx) GMMVI_HIP_CHECK(ctx, hipGetLastError())
 
 int gmmvi_ws_reserve(gmmvi_ctx* ctx, size_t nbytes);
+// sampling.hip: gmmvi_sample_components with a caller-known bound on the samples per component (fewer empty workgroups)
+int gmmvi_sample_components_bounded(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
+                                    const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed,
+                                    uint64_t first_index, int stream_id, const float* eps_dev, float* X_out_dev,
+                                    int32_t* mapping_out_dev);
 // weights.hip: trust-region (mode 0) / direct (mode 1) weight update; exp_out (optional) receives exp(new log weights)
 int gmmvi_update_weights_internal(gmmvi_ctx* ctx, int mode, int K, float* logw_dev, const float* E_dev,
                                   const float* stepsize_dev, float beta, float* kl_eta_out_dev, float* exp_out_dev);

@@ -87,8 +87,9 @@ extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan
 
     float* x = p->db_samples;          // the new samples ARE the active samples (reuse ratio 0): no copy
     // ---- sample selection: draw, evaluate the target, append to the DB (sample_selector.py:160-219) --------------------
-    GMMVI_TRY(gmmvi_sample_components(ctx, K, D, p->means, p->chols, p->offsets, N, p->seed, p->first_index, 0, nullptr, x,
-                                      a.mapping));
+    // every component draws N / K samples on this path (optimization/fused.py: equal counts)
+    GMMVI_TRY(gmmvi_sample_components_bounded(ctx, K, D, p->means, p->chols, p->offsets, N, (N + K - 1) / K, p->seed,
+                                              p->first_index, 0, nullptr, x, a.mapping));
     {
         PrepArgs q{};
         q.map_dst = p->db_mapping; q.map_src = a.mapping; q.map_base = p->mapping_base; q.n_map = N;

@@ -86,18 +86,18 @@ __global__ void philox_uniforms_kernel(uint64_t seed, uint64_t first_index, uint
     out[n] = philox_u01(p.w[0]);
 }
 
-extern "C" {
-
-int gmmvi_sample_components(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
-                            const int32_t* offsets_dev, int N, uint64_t seed, uint64_t first_index, int stream_id,
-                            const float* eps_dev, float* X_out_dev, int32_t* mapping_out_dev) {
-    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM && N >= 0);
+// C++ linkage (common.h): as gmmvi_sample_components, with an upper bound on the samples of any one component known to
+// the caller -- the launch then covers ceil(bound / 256) chunks per component instead of ceil(N / 256)
+int gmmvi_sample_components_bounded(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
+                                    const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed,
+                                    uint64_t first_index, int stream_id, const float* eps_dev, float* X_out_dev,
+                                    int32_t* mapping_out_dev) {
+    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM && N >= 0 && max_per_component >= 0);
     if (N == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && offsets_dev && X_out_dev);
     GMMVI_PROF(ctx, "sample_components");
-    // the per-component counts live on the device: cover the worst case (all N samples in one component); empty
-    // chunks exit immediately
-    const int chunks = (N + 255) / 256;
+    const int bound = max_per_component < N ? max_per_component : N;
+    const int chunks = (bound + 255) / 256 > 0 ? (bound + 255) / 256 : 1;
     const size_t shmem = ((size_t)D * D + D + 256 * (size_t)(D | 1)) * sizeof(float);
     const int dp = gmmvi_padded_dim(D);
     GMMVI_DISPATCH_DP(dp, hipLaunchKernelGGL((sample_components_kernel<DP>), dim3(K, chunks), dim3(256), shmem,
@@ -105,6 +105,17 @@ int gmmvi_sample_components(gmmvi_ctx* ctx, int K, int D, const float* means_dev
                                              (uint32_t)stream_id, eps_dev, X_out_dev, mapping_out_dev));
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
+}
+
+extern "C" {
+
+int gmmvi_sample_components(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
+                            const int32_t* offsets_dev, int N, uint64_t seed, uint64_t first_index, int stream_id,
+                            const float* eps_dev, float* X_out_dev, int32_t* mapping_out_dev) {
+    // the per-component counts live on the device: cover the worst case (all N samples in one component); empty
+    // chunks exit immediately
+    return gmmvi_sample_components_bounded(ctx, K, D, means_dev, chols_dev, offsets_dev, N, N, seed, first_index, stream_id,
+                                           eps_dev, X_out_dev, mapping_out_dev);
 }
 
 int gmmvi_philox_normals(gmmvi_ctx* ctx, uint64_t seed, uint64_t first_index, int stream_id, int N, int D,

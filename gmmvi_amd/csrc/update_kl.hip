@@ -186,9 +186,10 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
                 __syncthreads();
                 continue;                           // uniform: every lane computed the same tail
             }
-            const float nrm = sqrtf(tail + x1 * x1);
+            const float nrm = __builtin_amdgcn_sqrtf(tail + x1 * x1);       // v_sqrt_f32 / v_rcp_f32 (1 ulp): the reflector only
+                                                                            // has to be orthogonal to working precision
             const float alpha = (x1 > 0.f) ? -nrm : nrm;
-            const float beta = 1.f / (nrm * nrm - alpha * x1);      // 2 / |v|^2, |v|^2 = 2 (alpha^2 - alpha x1)
+            const float beta = __builtin_amdgcn_rcpf(nrm * nrm - alpha * x1);      // 2 / |v|^2, |v|^2 = 2 (alpha^2 - alpha x1)
             // v_j: 0 for j <= c, x1 - alpha for j = c + 1, x_j below
 #pragma unroll
             for (int j = 0; j < DR; ++j) x[j] = (j <= c) ? 0.f : (j == c + 1 ? x1 - alpha : x[j]);
@@ -565,6 +566,7 @@ extern "C" int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* m
         case 10: GMMVI_UKL(10); break;
         case 20: GMMVI_UKL(20); break;
         case 32: GMMVI_UKL(32); break;
+        case 50: GMMVI_UKL(50); break;
         default: GMMVI_UKL(0); break;
     }
 #undef GMMVI_UKL
