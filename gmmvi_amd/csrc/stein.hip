@@ -18,6 +18,7 @@
 // stein_finalize sums the slab in fixed order (bitwise reproducible), normalises, symmetrises and negates.
 #include "common.h"
 #include "wave_reduce.h"
+#include "subst_asm_gen.h"
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -355,9 +356,15 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
         {
             const bool v0 = lane < n_here;
             a_n = !v0 ? -3.0e38f : (own_only ? ((mp[0] == k) ? 0.f : -3.0e38f) : la[0] - bgv[0]);
-            float z[DP];
-            forward_subst_s<DP>(P, x[0], z);
-            backward_subst_s<DP>(P, z, yn);
+            if constexpr (SubstAsm<DP>::available) {
+#pragma unroll
+                for (int i = 0; i < DP; ++i) yn[i] = x[0][i];
+                SubstAsm<DP>::run(P, yn);                              // hand-scheduled: double-buffered scalar feed
+            } else {
+                float z[DP];
+                forward_subst_s<DP>(P, x[0], z);
+                backward_subst_s<DP>(P, z, yn);
+            }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -385,9 +392,15 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
                 const bool v1 = 64 * (t + 1) + lane < n_here;
                 a_n = !v1 ? -3.0e38f : (own_only ? ((mp[t + 1 < 4 ? t + 1 : 3] == k) ? 0.f : -3.0e38f)
                                                   : la[t + 1 < 4 ? t + 1 : 3] - bgv[t + 1 < 4 ? t + 1 : 3]);
-                float z[DP];
-                forward_subst_s<DP>(P, x[t + 1 < 4 ? t + 1 : 3], z);
-                backward_subst_s<DP>(P, z, yn);
+                if constexpr (SubstAsm<DP>::available) {
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) yn[i] = x[t + 1 < 4 ? t + 1 : 3][i];
+                    SubstAsm<DP>::run(P, yn);
+                } else {
+                    float z[DP];
+                    forward_subst_s<DP>(P, x[t + 1 < 4 ? t + 1 : 3], z);
+                    backward_subst_s<DP>(P, z, yn);
+                }
             }
 #pragma unroll
             for (int s2 = 0; s2 < 32; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s2], yb[s2], acc, 0, 0, 0);
