@@ -184,6 +184,42 @@ int gmmvi_copy_batch(gmmvi_ctx* ctx, int n, void* const* dst_dev, const void* co
     return GMMVI_OK;
 }
 
+struct UnpackArgs {
+    const uint32_t* src; int n_ranks; unsigned long long chunk; int n_seg;
+    unsigned long long off[4], words[4]; uint32_t* dst[4];
+};
+__global__ void unpack_gathered_kernel(UnpackArgs a) {
+    const int j = blockIdx.y;
+    if (j >= a.n_seg) return;
+    const unsigned long long total = a.words[j] * (unsigned long long)a.n_ranks;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned long long r = i / a.words[j], e = i - r * a.words[j];
+        a.dst[j][i] = a.src[r * a.chunk + a.off[j] + e];
+    }
+}
+
+int gmmvi_unpack_gathered(gmmvi_ctx* ctx, const void* src_dev, int n_ranks, size_t chunk_words, int n_seg,
+                          const size_t* seg_words, void* const* dst_dev) {
+    GMMVI_ARG_CHECK(ctx, src_dev && n_ranks >= 1 && n_seg >= 1 && n_seg <= 4 && seg_words && dst_dev);
+    UnpackArgs a{};
+    a.src = (const uint32_t*)src_dev; a.n_ranks = n_ranks; a.chunk = chunk_words; a.n_seg = n_seg;
+    unsigned long long off = 0, mx = 0;
+    for (int j = 0; j < n_seg; ++j) {
+        GMMVI_ARG_CHECK(ctx, dst_dev[j] != nullptr || seg_words[j] == 0);
+        a.off[j] = off; a.words[j] = seg_words[j]; a.dst[j] = (uint32_t*)dst_dev[j];
+        off += seg_words[j];
+        if (seg_words[j] > mx) mx = seg_words[j];
+    }
+    GMMVI_ARG_CHECK(ctx, off == chunk_words);
+    if (mx == 0) return GMMVI_OK;
+    unsigned long long bx = (mx * (unsigned long long)n_ranks + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(unpack_gathered_kernel, dim3((unsigned)bx, n_seg), dim3(256), 0, ctx->stream, a);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
 __global__ void fill_strided_kernel(float* dst, size_t stride, size_t count, float v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;

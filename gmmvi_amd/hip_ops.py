@@ -286,3 +286,30 @@ def copy_batch(ctx, pairs):
         src = (C.c_void_p * n)(*[s.ptr for _, s in grp])
         nb = (C.c_size_t * n)(*[s.nbytes for _, s in grp])
         ctx.check(ctx.lib.gmmvi_copy_batch(ctx.handle, n, dst, src, nb))
+
+
+def concat(ctx, parts):
+    """One flat fp32 buffer holding the (flattened) parts back to back; a single copy launch (<= 8 parts)."""
+    total = sum(int(p.size) for p in parts)
+    out = ctx.empty((total,))
+    pairs, off = [], 0
+    for p in parts:
+        n = int(p.size)
+        pairs.append((out.rows(off, off + n), p.reshape(-1)))
+        off += n
+    copy_batch(ctx, pairs)
+    return out
+
+
+def unpack_gathered(ctx, gathered, n_ranks, sizes):
+    """Inverse of concat after an all-gather: gathered = [n_ranks][sum(sizes)] -> one [n_ranks * size_j] array per part."""
+    import ctypes as C
+    chunk = int(sum(sizes))
+    if gathered.size != n_ranks * chunk:
+        raise ValueError("unpack_gathered: gathered buffer has the wrong size")
+    outs = [ctx.empty((n_ranks * int(sz),)) for sz in sizes]
+    n = len(sizes)
+    words = (C.c_size_t * n)(*[int(sz) for sz in sizes])
+    dst = (C.c_void_p * n)(*[o.ptr for o in outs])
+    ctx.check(ctx.lib.gmmvi_unpack_gathered(ctx.handle, gathered.ptr, int(n_ranks), chunk, n, words, dst))
+    return outs

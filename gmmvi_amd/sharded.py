@@ -7,7 +7,9 @@ three exchange steps, each an RCCL all-gather over xGMI followed by a local comb
   E1  samples, target log-densities and target gradients of the locally drawn samples      [N/R, 2D+1] per rank
   E2  per-sample partial mixtures over the local components: background (max,sum) folded into one log value,
       model log q partial and its responsibility-weighted gradient partial                  [N, D+2]   per rank
-  E3  post-update log q partial [N] and the per-component expected log-ratios / rewards    [N] + [2 Kl] per rank
+  E3a post-update log q partial [N];  E3b per-component expected log-ratios / rewards      [N], [2 Kl] per rank
+Each step is ONE all-gather: the arrays of a step travel back to back in one buffer (xGMI collectives at these sizes are
+latency-bound, ~tens of microseconds each whatever the payload) and one de-interleave launch restores them.
 
 Stein estimate and the KL-constrained component update are local to the owner.  The mixture weights [K], the
 reward history and the weight trust-region step are replicated (every rank computes the identical [K]-sized update
@@ -67,8 +69,18 @@ class HipOps:
     def mixture(self, packed, logw, x, d, want_ld=False, want_grad=False):
         return self.h.mixture_eval(self.ctx, packed, logw, x, d, want_ld=want_ld, want_lp=True, want_grad=want_grad)
 
+    def mixture_dual(self, packed, logw, logw2, x, d):
+        """(ld, partial log q, partial gradient, partial background) in one sweep over the local components."""
+        return self.h.mixture_eval_dual(self.ctx, packed, logw, logw2, x, d)
+
     def combine(self, lp_parts, grad_parts, d):
         return self.h.combine_partials(self.ctx, lp_parts, grad_parts, d)
+
+    def concat(self, parts):
+        return self.h.concat(self.ctx, parts)
+
+    def unpack(self, gathered, n_ranks, sizes):
+        return self.h.unpack_gathered(self.ctx, gathered, n_ranks, sizes)
 
     def component_stepsize(self, steps, prev, last, c):
         self.h.component_stepsize_improvement(self.ctx, steps, prev, last, c["min_stepsize"], c["max_stepsize"],
@@ -78,8 +90,10 @@ class HipOps:
         return self.h.stein(self.ctx, packed, x, ld, qgrad, bg, tgrad, d)
 
     def update_kl(self, means, chols, h_neg, g_neg, steps, temperature, l2_init, last_eta, l2, nupd):
-        return self.h.update_components_kl(self.ctx, means, chols, h_neg, g_neg, steps, temperature, l2_init, last_eta,
-                                           l2, nupd)[0]
+        """-> (success, packed blocks of the updated components)."""
+        out = self.h.update_components_kl(self.ctx, means, chols, h_neg, g_neg, steps, temperature, l2_init, last_eta,
+                                          l2, nupd, want_packed=True)
+        return out[0], out[3]
 
     def elr(self, ld, bg, tlp, logq, beta, logw_loc):
         k = ld.shape[0]
@@ -203,6 +217,7 @@ class ShardedGMMVI:
         self.num_samples_written = 0
         self.num_updates = 0
         self.last_success = None
+        self.packed = None                         # packed blocks of the local components (kept up to date by update_kl)
 
     # reward ring helpers (same convention as GmmWrapper)
     def _slot(self, back):
@@ -210,23 +225,29 @@ class ShardedGMMVI:
         return self.ops.rows(self.reward_ring, s, s + 1)
 
     def train_iter(self):
-        o, ex, d, R, N = self.ops, self.exchange, self.d, self.R, self.N
-        # ---- sampling + target (local components) and exchange E1 -------------------------------------------------
+        o, ex, d, R, N, Nl = self.ops, self.exchange, self.d, self.R, self.N, self.Nl
+        # ---- sampling + target (local components); exchange E1: [x | log p~ | grad log p~] in ONE all-gather ---------------
         first = self.num_samples_written + self.rank * self.Nl
         x_loc = o.sample(self.means, self.chols, self.counts_loc, self.seed, first)
         tlp_loc, tgrad_loc = o.target_eval(x_loc)
-        x = ex.allgather(x_loc)
-        tlp = ex.allgather(tlp_loc)
-        tgrad = ex.allgather(tgrad_loc)
-        self.num_samples_written += N
-        # ---- partial background / model densities over the local components, exchange E2 --------------------------
-        packed = o.pack(self.means, self.chols)
-        logw_loc = o.rows(self.log_weights, self.lo, self.hi)
-        _, bg_part, _ = o.mixture(packed, self.logc_loc, x, d)
-        ld, lq_part, qg_part = o.mixture(packed, logw_loc, x, d, want_ld=True, want_grad=True)
         if R > 1:
-            bg, _ = o.combine(self._stack(ex.allgather(bg_part), N), None, d)
-            logq, qgrad = o.combine(self._stack(ex.allgather(lq_part), N), self._stack(ex.allgather(qg_part), N, d), d)
+            g1 = ex.allgather(o.concat([x_loc, tlp_loc, tgrad_loc]))
+            x, tlp, tgrad = o.unpack(g1, R, [Nl * d, Nl, Nl * d])
+            x, tgrad = x.reshape((N, d)), tgrad.reshape((N, d))
+        else:
+            x, tlp, tgrad = x_loc, tlp_loc, tgrad_loc
+        self.num_samples_written += N
+        # ---- partial background / model densities over the local components (one sweep); exchange E2 ------------------------
+        if self.packed is None:
+            self.packed = o.pack(self.means, self.chols)
+        packed = self.packed
+        logw_loc = o.rows(self.log_weights, self.lo, self.hi)
+        ld, lq_part, qg_part, bg_part = o.mixture_dual(packed, logw_loc, self.logc_loc, x, d)
+        if R > 1:
+            g2 = ex.allgather(o.concat([bg_part, lq_part, qg_part]))
+            bgp, lqp, qgp = o.unpack(g2, R, [N, N, N * d])
+            bg, _ = o.combine(bgp.reshape((R, N)), None, d)
+            logq, qgrad = o.combine(lqp.reshape((R, N)), qgp.reshape((R, N, d)), d)
         else:
             bg, logq, qgrad = bg_part, lq_part, qg_part
         # ---- component updates (local) ----------------------------------------------------------------------------------
@@ -234,16 +255,18 @@ class ShardedGMMVI:
                       o.rows(self._row1d(self._slot(0)), self.lo, self.hi))
         o.component_stepsize(self.stepsizes, prev, last, self.cs)
         h_neg, g_neg = o.stein(packed, x, ld, qgrad, bg, tgrad, d)
-        self.last_success = o.update_kl(self.means, self.chols, h_neg, g_neg, self.stepsizes, self.temperature, 1e-12,
-                                        self.last_eta, self.l2, self.num_received_updates)
-        # ---- weight update: post-update density, exchange E3 -------------------------------------------------------------
+        self.last_success, self.packed = o.update_kl(self.means, self.chols, h_neg, g_neg, self.stepsizes,
+                                                     self.temperature, 1e-12, self.last_eta, self.l2,
+                                                     self.num_received_updates)
+        # ---- weight update: post-update density (E3a), expected log-ratios + rewards (E3b) ------------------------------------
         o.weight_stepsize(self.log_weights, self._row1d(self._slot(0)), self.wstate, self.ws)
-        packed = o.pack(self.means, self.chols)
-        ld2, lq2_part, _ = o.mixture(packed, logw_loc, x, d, want_ld=True)
+        ld2, lq2_part, _ = o.mixture(self.packed, logw_loc, x, d, want_ld=True)
         logq2 = o.combine(self._stack(ex.allgather(lq2_part), N), None, d)[0] if R > 1 else lq2_part
         e_loc, reward_loc = o.elr(ld2, bg, tlp, logq2, self.temperature, logw_loc)
-        e = ex.allgather(e_loc)
-        reward = ex.allgather(reward_loc)
+        if R > 1:
+            e, reward = o.unpack(ex.allgather(o.concat([e_loc, reward_loc])), R, [self.Kl, self.Kl])
+        else:
+            e, reward = e_loc, reward_loc
         s = self.t_reward % self.H
         o.copy_into(self._row1d(o.rows(self.reward_ring, s, s + 1)), reward)
         self.t_reward += 1

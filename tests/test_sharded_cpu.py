@@ -66,6 +66,22 @@ class OracleOps:
         lq, cld = m.log_densities_also_individual(x)
         return (cld if want_ld else None), lq, None
 
+    def mixture_dual(self, packed, logw, logw2, x, d):
+        ld, lq, g = self.mixture(packed, logw, x, d, want_ld=True, want_grad=True)
+        _, bg, _ = self.mixture(packed, logw2, x, d)
+        return ld, lq, g, bg
+
+    def concat(self, parts):
+        return np.concatenate([np.asarray(p).reshape(-1) for p in parts])
+
+    def unpack(self, gathered, n_ranks, sizes):
+        g = np.asarray(gathered).reshape(n_ranks, int(sum(sizes)))
+        outs, off = [], 0
+        for sz in sizes:
+            outs.append(np.ascontiguousarray(g[:, off:off + sz]).reshape(-1))
+            off += sz
+        return outs
+
     def combine(self, lp_parts, grad_parts, d):
         lp = logsumexp(lp_parts, axis=0)
         g = None if grad_parts is None else np.einsum('rn,rnd->nd', np.exp(lp_parts - lp[None]), grad_parts)
@@ -95,7 +111,7 @@ class OracleOps:
         succ, _, _, _ = oupd.apply_ng_update_kl(w, h_neg, g_neg, steps, temperature)
         means[...] = w.model.means; chols[...] = w.model.chol_cov
         last_eta[...] = w.last_log_etas; l2[...] = w.l2_regularizers; nupd[...] = w.num_received_updates
-        return succ
+        return succ, self.pack(means, chols)
 
     def elr(self, ld, bg, tlp, logq, beta, logw_loc):
         lw = ld - bg[None]
