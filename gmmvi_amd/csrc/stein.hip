@@ -20,8 +20,10 @@
 #include "wave_reduce.h"
 #include "subst_asm_gen.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int DP>
 __device__ __forceinline__ void forward_subst_s(const float* __restrict__ P, const float (&x)[DP], float (&z)[DP]) {
@@ -282,7 +284,10 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ A, const fl
 // component loop has no block barrier: one partial per (component, tile) leaves straight from the accumulators.  A
 // component's block is read through the scalar cache four times in a row (once per sub-tile) instead of by four waves
 // in four different places.
-template <int DP>
+// W = 32: v_mfma_f32_32x32x2 (D + 1 <= 32); W = 16: v_mfma_f32_16x16x4 for D + 1 <= 16 -- a quarter of the matrix-pipe time
+// and half the LDS, the 32-wide tile is 88 % padding at D = 10.  D[i][j] of the 16x16x4 form: i = 4 (l / 16) + r, j = l % 16
+// (probed: tools/probe/mfma_f32_16x16x4_layout.hip).
+template <int DP, int W>
 __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chunk, const float* __restrict__ packed,
                                                           const float* __restrict__ X, const float* __restrict__ TG,
                                                           const float* __restrict__ QG, int N,
@@ -290,8 +295,9 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
                                                           const int32_t* __restrict__ mapping, int map_offset, int flags,
                                                           float* __restrict__ part, float* __restrict__ part_m) {
     using PK = Pack<DP>;
-    constexpr int W = 32;
     constexpr int LDW = W + 1;
+    constexpr int NACC = W == 16 ? 4 : 16;
+    using AccT = typename std::conditional<W == 16, f32x4, f32x16>::type;
     extern __shared__ float sm[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -345,9 +351,9 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
 #pragma unroll
         for (int t = 0; t < 4; ++t)
             la_next[t] = (64 * t + lane < n_here && !own_only && k + 4 < k_end) ? ld[(size_t)(k + 4) * N + n0 + 64 * t + lane] : 0.f;
-        f32x16 acc;
+        AccT acc;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+        for (int t = 0; t < NACC; ++t) acc[t] = 0.f;
         float M = -3.0e38f;
         // Software pipeline over the four sub-tiles: the substitution of sub-tile t + 1 (VALU, scalar loads) is issued in the
         // same straight-line region as the 32 MFMAs of sub-tile t, so the matrix pipe works in the shadow of the vector
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
             const float f = __expf(M - Mn);                            // 1 when the maximum did not move, 0 at the start
             M = Mn;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] *= f;
+            for (int r = 0; r < NACC; ++r) acc[r] *= f;
             const float e = (a_n > -1.0e38f) ? __expf(a_n - M) : 0.f;
 #pragma unroll
             for (int i = 0; i < DP; ++i)
@@ -383,11 +389,15 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             // ---- region A: MFMAs of sub-tile t  ||  substitution of sub-tile t + 1 ---------------------------------------
-            const float* Gt = Gs + (64 * t + half) * LDW + col;
-            const float* Yt = Yw + half * LDW + col;
-            float ga[32], yb[32];
+            // operand fragments: 32x32x2 -> lane (row/col = l % 32, k = l / 32), 32 steps of 2 samples;
+            //                    16x16x4 -> lane (row/col = l % 16, k = l / 16), 16 steps of 4 samples
+            constexpr int KS = W == 16 ? 4 : 2, NS = 64 / KS;
+            const int fr = W == 16 ? (lane & 15) : col, fk = W == 16 ? (lane >> 4) : half;
+            const float* Gt = Gs + (64 * t + fk) * LDW + fr;
+            const float* Yt = Yw + fk * LDW + fr;
+            float ga[NS], yb[NS];
 #pragma unroll
-            for (int s2 = 0; s2 < 32; ++s2) { ga[s2] = Gt[2 * s2 * LDW]; yb[s2] = Yt[2 * s2 * LDW]; }
+            for (int s2 = 0; s2 < NS; ++s2) { ga[s2] = Gt[KS * s2 * LDW]; yb[s2] = Yt[KS * s2 * LDW]; }
             if (t < 3) {
                 const bool v1 = 64 * (t + 1) + lane < n_here;
                 a_n = !v1 ? -3.0e38f : (own_only ? ((mp[t + 1 < 4 ? t + 1 : 3] == k) ? 0.f : -3.0e38f)
@@ -403,15 +413,19 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
                 }
             }
 #pragma unroll
-            for (int s2 = 0; s2 < 32; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s2], yb[s2], acc, 0, 0, 0);
+            for (int s2 = 0; s2 < NS; ++s2) {
+                if constexpr (W == 16) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s2], yb[s2], acc, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s2], yb[s2], acc, 0, 0, 0);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             __builtin_amdgcn_wave_barrier();
         }
         float* out = part + ((size_t)k * n_tiles + tile) * (size_t)(D1 * D1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (i < D1 && col < D1) out[i * D1 + col] = acc[r];
+        for (int r = 0; r < NACC; ++r) {
+            const int i = W == 16 ? 4 * (lane >> 4) + r : (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int j = W == 16 ? (lane & 15) : col;
+            if (i < D1 && j < D1) out[i * D1 + j] = acc[r];
         }
         if (lane == 0) part_m[(size_t)k * n_tiles + tile] = M;
 #pragma unroll
@@ -419,11 +433,11 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
     }
 }
 
-template <int DP>
+template <int DP, int W>
 static int launch_stein_wc(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
                            const float* qgrad, const float* bg, const float* tgrad, const int32_t* mapping, int map_offset,
                            int flags, float* H_neg, float* g_neg) {
-    constexpr int LDW = 33;
+    constexpr int LDW = W + 1;
     const int D1 = D + 1;
     const int n_tiles = (N + 255) / 256;
     // components per workgroup: a multiple of the four waves, ~2 workgroups per CU in flight
@@ -442,13 +456,13 @@ static int launch_stein_wc(gmmvi_ctx* ctx, int K, int D, const float* packed, co
     const size_t shmem = (size_t)(256 + 4 * 64) * LDW * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_wc_kernel<DP>,
+        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_wc_kernel<DP, W>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         attr_set = true;
     }
     {
         GMMVI_PROF(ctx, "stein_partial");
-        hipLaunchKernelGGL((stein_wc_kernel<DP>), dim3(n_tiles, n_chunks), dim3(256), shmem, ctx->stream, K, D, chunk,
+        hipLaunchKernelGGL((stein_wc_kernel<DP, W>), dim3(n_tiles, n_chunks), dim3(256), shmem, ctx->stream, K, D, chunk,
                            packed, X, tgrad, qgrad, N, ld, bg, mapping, map_offset, flags, part, part_m);
     }
     GMMVI_LAUNCH_CHECK(ctx);
@@ -504,11 +518,18 @@ extern "C" int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev
     static const bool force_tiled = getenv("GMMVI_STEIN_TILED") != nullptr;
     if (!force_tiled && dp <= 24) {
         switch (dp) {
-#define GMMVI_STEIN_WC(DPV)                                                                                          \
-    case DPV: return launch_stein_wc<DPV>(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,      \
-                                          mapping_dev, map_offset, flags, H_neg_out_dev, g_neg_out_dev)
-            GMMVI_STEIN_WC(2); GMMVI_STEIN_WC(4); GMMVI_STEIN_WC(8); GMMVI_STEIN_WC(10); GMMVI_STEIN_WC(12);
-            GMMVI_STEIN_WC(16); GMMVI_STEIN_WC(20); GMMVI_STEIN_WC(24);
+#define GMMVI_STEIN_WC(DPV, WV)                                                                                      \
+    case DPV: return launch_stein_wc<DPV, WV>(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,  \
+                                              mapping_dev, map_offset, flags, H_neg_out_dev, g_neg_out_dev)
+            GMMVI_STEIN_WC(2, 16); GMMVI_STEIN_WC(4, 16); GMMVI_STEIN_WC(8, 16); GMMVI_STEIN_WC(10, 16);
+            GMMVI_STEIN_WC(12, 16);
+            case 16:
+                if (D + 1 <= 16)
+                    return launch_stein_wc<16, 16>(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,
+                                                   mapping_dev, map_offset, flags, H_neg_out_dev, g_neg_out_dev);
+                return launch_stein_wc<16, 32>(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,
+                                               mapping_dev, map_offset, flags, H_neg_out_dev, g_neg_out_dev);
+            GMMVI_STEIN_WC(20, 32); GMMVI_STEIN_WC(24, 32);
 #undef GMMVI_STEIN_WC
             default: break;
         }
