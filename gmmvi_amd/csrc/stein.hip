@@ -5,16 +5,16 @@
 // y_kn = Sigma_k^-1 (x_n - mu_k).  The (D+1)x(D+1) matrix A_k carries sum e g y^T, sum e g (last column) and sum e
 // (corner), so one contraction over the samples yields the Hessian, the gradient and the normaliser.
 //
-// Mapping (DESIGN.md "stein"): grid = (256-sample tiles, component chunks); 4 waves per workgroup, 64 samples each.
-//   * the x and g tiles of the workgroup are fetched ONCE with fully coalesced loads and staged through LDS (the
-//     per-lane rows of a row-major [N, D] array are 4*D bytes apart: loading them lane-by-lane costs one cache line per
-//     lane per element and was the dominant stall of the first version of this kernel);
-//   * each lane keeps its sample x in VGPRs and each wave keeps the [g;1] MFMA A-fragments of its 64 samples in VGPRs;
-//     both are reused for every component of the chunk;
-//   * per component: y by the register-resident forward/backward substitution (component block through scalar
-//     loads), e*[y;1] rows written to the wave's LDS tile (row stride 32*NB+1: conflict-free), contraction of the 64
-//     samples with v_mfma_f32_32x32x2_f32, then the four waves are merged through LDS (own maximum per wave, fixed
-//     summation order) and the (component, tile) partial goes to a slab.
+// Two kernels produce per-(component, 256-sample tile) partials of A_k; grid = (tiles, component chunks),
+// 4 waves per workgroup, the x and g tiles of the workgroup fetched ONCE with coalesced 16-byte loads and staged through LDS
+// (per-lane row loads of a row-major [N, D] array were the dominant stall of the first version):
+//   * stein_wc_kernel (D <= 24, the production path): wave = component.  Every lane keeps its x row of the four 64-sample
+//     sub-tiles in VGPRs; wave w walks the components w, w + 4, ... of the chunk and for each of them substitutes the four
+//     sub-tiles (generated hand-scheduled scalar-fed asm for D = 10 / 20, subst_asm_gen.h), writes e * [y; 1] rows to its
+//     private LDS tile and contracts with v_mfma_f32_32x32x2 (16x16x4 for D + 1 <= 16), rescaling the accumulators online
+//     by the running maximum.  No cross-wave merge, no block barrier in the component loop.
+//   * stein_partial_kernel (D > 24): wave = 64 samples, [g;1] A-fragments in VGPRs reused for every component of the chunk,
+//     the four waves merged through LDS per component (own maximum per wave, fixed summation order).
 // stein_finalize sums the slab in fixed order (bitwise reproducible), normalises, symmetrises and negates.
 #include "common.h"
 #include "wave_reduce.h"
