@@ -70,6 +70,10 @@ int gmmvi_sample_components_bounded(gmmvi_ctx* ctx, int K, int D, const float* m
                                     const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed,
                                     uint64_t first_index, int stream_id, const float* eps_dev, float* X_out_dev,
                                     int32_t* mapping_out_dev);
+struct PrepArgs;
+int gmmvi_sample_components_prep(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
+                                 const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed, uint64_t first_index,
+                                 float* X_out_dev, int32_t* mapping_out_dev, int32_t mapping_base, const PrepArgs& prep);
 // weights.hip: trust-region (mode 0) / direct (mode 1) weight update; exp_out (optional) receives exp(new log weights)
 int gmmvi_update_weights_internal(gmmvi_ctx* ctx, int mode, int K, float* logw_dev, const float* E_dev,
                                   const float* stepsize_dev, float beta, float* kl_eta_out_dev, float* exp_out_dev);

@@ -7,6 +7,7 @@
 // the modular path costs ~20 Python->C transitions per iteration (~340 us of host time, more than the kernels take).
 #include "common.h"
 #include "stepsize_rules.h"
+#include "iter_prep.h"
 
 namespace {
 struct Arena {
@@ -14,35 +15,6 @@ struct Arena {
     int32_t *mapping, *success;
 };
 
-struct PrepArgs {
-    // DB mapping: dst[i] = src[i] + base
-    int32_t* map_dst; const int32_t* map_src; int32_t map_base; int n_map;
-    // model snapshot into the sample DB (sample_db.py:113-124): up to three word-wise copies
-    uint32_t* cdst[3]; const uint32_t* csrc[3]; unsigned long long cwords[3];
-    // stepsize rules
-    int K; int cs_mode; float* stepsizes; const float* reward_prev; const float* reward_last;
-    float cs_min, cs_max, cs_inc, cs_dec;
-    int ws_mode; const float* logw; float* wstate; float ws_min, ws_max, ws_inc, ws_dec;
-};
-
-// block 0: the O(K) stepsize rules (wave 0 also runs the weight-stepsize reduction); blocks >= 1: copies
-__global__ __launch_bounds__(256) void iter_prep_kernel(PrepArgs a) {
-    if (blockIdx.x == 0) {
-        if (a.cs_mode == 1)
-            for (int k = threadIdx.x; k < a.K; k += 256)
-                a.stepsizes[k] = component_stepsize_rule(a.stepsizes[k], a.reward_prev[k], a.reward_last[k], a.cs_min,
-                                                         a.cs_max, a.cs_inc, a.cs_dec);
-        if (a.ws_mode == 1 && threadIdx.x < 64)
-            weight_stepsize_wave(a.K, a.logw, a.reward_last, a.wstate, a.ws_min, a.ws_max, a.ws_inc, a.ws_dec, threadIdx.x);
-        return;
-    }
-    const unsigned long long tid = (unsigned long long)(blockIdx.x - 1) * 256 + threadIdx.x;
-    const unsigned long long step = (unsigned long long)(gridDim.x - 1) * 256;
-    for (unsigned long long i = tid; i < (unsigned long long)a.n_map; i += step) a.map_dst[i] = a.map_src[i] + a.map_base;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-        for (unsigned long long i = tid; i < a.cwords[c]; i += step) a.cdst[c][i] = a.csrc[c][i];
-}
 }  // namespace
 
 static int arena_reserve(gmmvi_ctx* ctx, size_t floats) {
@@ -87,12 +59,11 @@ extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan
 
     float* x = p->db_samples;          // the new samples ARE the active samples (reuse ratio 0): no copy
     // ---- sample selection: draw, evaluate the target, append to the DB (sample_selector.py:160-219) --------------------
-    // every component draws N / K samples on this path (optimization/fused.py: equal counts)
-    GMMVI_TRY(gmmvi_sample_components_bounded(ctx, K, D, p->means, p->chols, p->offsets, N, (N + K - 1) / K, p->seed,
-                                              p->first_index, 0, nullptr, x, a.mapping));
+    // every component draws N / K samples on this path (optimization/fused.py: equal counts); the element-wise bookkeeping
+    // (model snapshot into the DB, the two stepsize rules) rides in extra blocks of the same launch, and the sampling blocks
+    // write the DB mapping (component index + base) directly
     {
         PrepArgs q{};
-        q.map_dst = p->db_mapping; q.map_src = a.mapping; q.map_base = p->mapping_base; q.n_map = N;
         if (p->db_means && p->db_chols && p->db_packed) {
             q.cdst[0] = (uint32_t*)p->db_means; q.csrc[0] = (const uint32_t*)p->means; q.cwords[0] = (size_t)K * D;
             q.cdst[1] = (uint32_t*)p->db_chols; q.csrc[1] = (const uint32_t*)p->chols; q.cwords[1] = (size_t)K * D * D;
@@ -104,13 +75,8 @@ extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan
         q.cs_min = p->cs_min; q.cs_max = p->cs_max; q.cs_inc = p->cs_inc; q.cs_dec = p->cs_dec;
         q.ws_mode = p->weight_stepsize_mode; q.logw = p->logw; q.wstate = p->wstate;
         q.ws_min = p->ws_min; q.ws_max = p->ws_max; q.ws_inc = p->ws_inc; q.ws_dec = p->ws_dec;
-        const unsigned long long words = (unsigned long long)N + q.cwords[0] + q.cwords[1] + q.cwords[2];
-        int blocks = (int)((words + 1023) / 1024);
-        if (blocks > 512) blocks = 512;
-        if (blocks < 1) blocks = 1;
-        GMMVI_PROF(ctx, "iter_prep");
-        hipLaunchKernelGGL(iter_prep_kernel, dim3(1 + blocks), dim3(256), 0, ctx->stream, q);
-        GMMVI_LAUNCH_CHECK(ctx);
+        GMMVI_TRY(gmmvi_sample_components_prep(ctx, K, D, p->means, p->chols, p->offsets, N, (N + K - 1) / K, p->seed,
+                                               p->first_index, x, p->db_mapping, p->mapping_base, q));
     }
     if (p->target_kind == 1) {
         GMMVI_TRY(gmmvi_target_planar(ctx, D, p->planar_prior_std, p->planar_goals_count, p->planar_goals,

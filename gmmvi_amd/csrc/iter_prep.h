@@ -1,0 +1,37 @@
+// Bookkeeping of the single-call iteration as device code shared by fused.hip (stand-alone launch) and sampling.hip (extra
+// blocks of the sampling launch).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "stepsize_rules.h"
+
+struct PrepArgs {
+    // DB mapping: dst[i] = src[i] + base
+    int32_t* map_dst; const int32_t* map_src; int32_t map_base; int n_map;
+    // model snapshot into the sample DB (sample_db.py:113-124): up to three word-wise copies
+    uint32_t* cdst[3]; const uint32_t* csrc[3]; unsigned long long cwords[3];
+    // stepsize rules
+    int K; int cs_mode; float* stepsizes; const float* reward_prev; const float* reward_last;
+    float cs_min, cs_max, cs_inc, cs_dec;
+    int ws_mode; const float* logw; float* wstate; float ws_min, ws_max, ws_inc, ws_dec;
+};
+
+// block 0 of n_blocks: the O(K) stepsize rules (wave 0 also runs the weight-stepsize reduction); blocks >= 1: copies
+__device__ __forceinline__ void iter_prep_block(const PrepArgs& a, int block, int n_blocks) {
+    if (block == 0) {
+        if (a.cs_mode == 1)
+            for (int k = threadIdx.x; k < a.K; k += 256)
+                a.stepsizes[k] = component_stepsize_rule(a.stepsizes[k], a.reward_prev[k], a.reward_last[k], a.cs_min,
+                                                         a.cs_max, a.cs_inc, a.cs_dec);
+        if (a.ws_mode == 1 && threadIdx.x < 64)
+            weight_stepsize_wave(a.K, a.logw, a.reward_last, a.wstate, a.ws_min, a.ws_max, a.ws_inc, a.ws_dec, threadIdx.x);
+        if (n_blocks > 1) return;                      // a single block does the copies as well
+    }
+    const int copy_blocks = n_blocks > 1 ? n_blocks - 1 : 1;
+    const unsigned long long tid = (unsigned long long)(n_blocks > 1 ? block - 1 : 0) * 256 + threadIdx.x;
+    const unsigned long long step = (unsigned long long)copy_blocks * 256;
+    for (unsigned long long i = tid; i < (unsigned long long)a.n_map; i += step) a.map_dst[i] = a.map_src[i] + a.map_base;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        for (unsigned long long i = tid; i < a.cwords[c]; i += step) a.cdst[c][i] = a.csrc[c][i];
+}

@@ -4,6 +4,7 @@
 // density kernels).
 #include "common.h"
 #include "philox.h"
+#include "iter_prep.h"
 
 // grid = (component, 256-sample chunk of that component); (mu_k, L_k) staged in LDS and read as broadcasts, eps and x in
 // registers (DP = padded dimension, loops unrolled), the output tile leaves through LDS with coalesced stores.
@@ -13,8 +14,13 @@ __global__ __launch_bounds__(256) void sample_components_kernel(int K, int D, co
                                                                 const int32_t* __restrict__ offsets, int N, uint64_t seed,
                                                                 uint64_t first_index, uint32_t stream_id,
                                                                 const float* __restrict__ eps_in, float* __restrict__ X,
-                                                                int32_t* __restrict__ mapping) {
+                                                                int32_t* __restrict__ mapping, int32_t mapping_base,
+                                                                int n_chunks, PrepArgs prep) {
     extern __shared__ float sm[];
+    if ((int)blockIdx.y >= n_chunks) {                 // bookkeeping blocks of the single-call iteration (iter_prep.h)
+        iter_prep_block(prep, blockIdx.x, gridDim.x);
+        return;
+    }
     const int k = blockIdx.x;
     const int begin = offsets[k], end = offsets[k + 1];
     const int base = begin + blockIdx.y * 256;
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(256) void sample_components_kernel(int K, int D, co
                 tile[t * ldx + i] = v;
             }
         }
-        if (mapping) mapping[base + t] = k;
+        if (mapping) mapping[base + t] = k + mapping_base;
     }
     __syncthreads();
     for (int e = t; e < n_here * D; e += 256) X[(size_t)base * D + e] = tile[(e / D) * ldx + (e % D)];
@@ -88,23 +94,44 @@ __global__ void philox_uniforms_kernel(uint64_t seed, uint64_t first_index, uint
 
 // C++ linkage (common.h): as gmmvi_sample_components, with an upper bound on the samples of any one component known to
 // the caller -- the launch then covers ceil(bound / 256) chunks per component instead of ceil(N / 256)
-int gmmvi_sample_components_bounded(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
-                                    const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed,
-                                    uint64_t first_index, int stream_id, const float* eps_dev, float* X_out_dev,
-                                    int32_t* mapping_out_dev) {
+static int launch_sample(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
+                         const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed, uint64_t first_index,
+                         int stream_id, const float* eps_dev, float* X_out_dev, int32_t* mapping_out_dev, int32_t mapping_base,
+                         const PrepArgs* prep) {
     GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM && N >= 0 && max_per_component >= 0);
-    if (N == 0) return GMMVI_OK;
+    if (N == 0 && !prep) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && offsets_dev && X_out_dev);
     GMMVI_PROF(ctx, "sample_components");
     const int bound = max_per_component < N ? max_per_component : N;
     const int chunks = (bound + 255) / 256 > 0 ? (bound + 255) / 256 : 1;
     const size_t shmem = ((size_t)D * D + D + 256 * (size_t)(D | 1)) * sizeof(float);
     const int dp = gmmvi_padded_dim(D);
-    GMMVI_DISPATCH_DP(dp, hipLaunchKernelGGL((sample_components_kernel<DP>), dim3(K, chunks), dim3(256), shmem,
-                                             ctx->stream, K, D, means_dev, chols_dev, offsets_dev, N, seed, first_index,
-                                             (uint32_t)stream_id, eps_dev, X_out_dev, mapping_out_dev));
+    PrepArgs none{};
+    GMMVI_DISPATCH_DP(dp, hipLaunchKernelGGL((sample_components_kernel<DP>), dim3(K, chunks + (prep ? 1 : 0)), dim3(256),
+                                             shmem, ctx->stream, K, D, means_dev, chols_dev, offsets_dev, N, seed,
+                                             first_index, (uint32_t)stream_id, eps_dev, X_out_dev, mapping_out_dev,
+                                             mapping_base, chunks, prep ? *prep : none));
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
+}
+
+// C++ linkage (common.h): as gmmvi_sample_components, with an upper bound on the samples of any one component known to
+// the caller -- the launch then covers ceil(bound / 256) chunks per component instead of ceil(N / 256)
+int gmmvi_sample_components_bounded(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
+                                    const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed,
+                                    uint64_t first_index, int stream_id, const float* eps_dev, float* X_out_dev,
+                                    int32_t* mapping_out_dev) {
+    return launch_sample(ctx, K, D, means_dev, chols_dev, offsets_dev, N, max_per_component, seed, first_index, stream_id,
+                         eps_dev, X_out_dev, mapping_out_dev, 0, nullptr);
+}
+
+// C++ linkage (common.h): sampling for the single-call iteration -- mapping written as component index + mapping_base,
+// the bookkeeping of iter_prep.h in K extra blocks of the same launch
+int gmmvi_sample_components_prep(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
+                                 const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed, uint64_t first_index,
+                                 float* X_out_dev, int32_t* mapping_out_dev, int32_t mapping_base, const PrepArgs& prep) {
+    return launch_sample(ctx, K, D, means_dev, chols_dev, offsets_dev, N, max_per_component, seed, first_index, 0, nullptr,
+                         X_out_dev, mapping_out_dev, mapping_base, &prep);
 }
 
 extern "C" {
