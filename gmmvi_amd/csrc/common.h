@@ -74,6 +74,10 @@ struct PrepArgs;
 int gmmvi_sample_components_prep(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
                                  const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed, uint64_t first_index,
                                  float* X_out_dev, int32_t* mapping_out_dev, int32_t mapping_base, const PrepArgs& prep);
+// comm.hip: gmmvi_combine_partials plus an optional second set of log-value partials
+int gmmvi_combine_partials_internal(gmmvi_ctx* ctx, int R, int N, int D, const float* lp_parts_dev,
+                                    const float* grad_parts_dev, float* lp_out_dev, float* grad_out_dev,
+                                    const float* lp2_parts_dev, float* lp2_out_dev);
 // weights.hip: trust-region (mode 0) / direct (mode 1) weight update; exp_out (optional) receives exp(new log weights)
 int gmmvi_update_weights_internal(gmmvi_ctx* ctx, int mode, int K, float* logw_dev, const float* E_dev,
                                   const float* stepsize_dev, float beta, float* kl_eta_out_dev, float* exp_out_dev);

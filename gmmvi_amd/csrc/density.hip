@@ -122,6 +122,7 @@ __global__ __launch_bounds__(GMMVI_ME_THREADS, GMMVI_ME_MINW) void mixture_eval_
     const int K = min(K_total, k_lo + kchunk);
     if (gridDim.y > 1) {
         if (lp_out) lp_out += (size_t)blockIdx.y * N;
+        if (lp2_out) lp2_out += (size_t)blockIdx.y * N;
         if (GRAD && grad_out) grad_out += (size_t)blockIdx.y * N * D;
     }
     const int lane = threadIdx.x & 63;
@@ -270,15 +271,17 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         return (lds_feed ? (size_t)nw * PK::STRIDE : 0) + (merge > stage ? merge : stage);
     };
     const int tiles = (N + 63) / 64;
-    // geometry: ky chunks of components over blockIdx.y, nw waves per workgroup; aim at >= ~6 waves per SIMD overall
-    // Measured on MI355X at the north-star shape (tools/tune_mixture_eval.py, profiles/r01_tune_mixture_eval.log):
-    // scalar-load feed, 16 waves per tile and no K split is the fastest geometry (19.9 / 35.0 us without / with the
-    // gradient); splitting K over blockIdx.y only pays for very few sample tiles.
+    // geometry: ky chunks of components over blockIdx.y (partials merged by combine_partials), nw waves per workgroup.
+    // Measured on MI355X (tools/tune_mixture_eval.py; profiles/r01_notes.md): with few sample tiles (N = 10^4: 157) one
+    // 16-wave workgroup per tile leaves 40 % of the CUs idle; 8 waves per workgroup and K split so that ~2 workgroups per CU
+    // are in flight is 11-13 % faster including the (coalesced) combine launch.  Plenty of tiles: 16 waves, no split.
     int ky = 1, nw = K < 16 ? K : 16;
-    if (logw2 != nullptr) ky = 1;                      // the dual mixture is merged inside the workgroup only
-    else if (env_ky > 0) ky = env_ky < K ? env_ky : K;
-    else {
-        while (ky < 8 && (long)tiles * nw * ky < ctx->num_cus && K / (ky + 1) >= 16) ++ky;
+    if (env_ky > 0) ky = env_ky < K ? env_ky : K;
+    else if (K >= 16 && 2L * tiles <= 3L * ctx->num_cus) {
+        ky = (int)((2L * ctx->num_cus + tiles / 2) / tiles);
+        if (ky > K / 8) ky = K / 8;
+        if (ky < 1) ky = 1;
+        if (ky > 1) nw = 8;
     }
     const int kchunk = (K + ky - 1) / ky;
     ky = (K + kchunk - 1) / kchunk;
@@ -288,12 +291,14 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     size_t shmem = lds_floats(nw) * 4;
     float* lp_k = lp;
     float* grad_k = grad;
+    float* lp2_k = lp2;
     if (ky > 1 && want_merge) {
-        size_t need = ((size_t)ky * N + (want_grad ? (size_t)ky * N * D : 0)) * sizeof(float);
+        size_t need = ((size_t)ky * N * (logw2 ? 2 : 1) + (want_grad ? (size_t)ky * N * D : 0)) * sizeof(float);
         int rc = gmmvi_ws_reserve(ctx, need);
         if (rc != GMMVI_OK) return rc;
         lp_k = (float*)ctx->ws;
-        grad_k = want_grad ? lp_k + (size_t)ky * N : nullptr;
+        lp2_k = logw2 ? lp_k + (size_t)ky * N : nullptr;
+        grad_k = want_grad ? lp_k + (size_t)ky * N * (logw2 ? 2 : 1) : nullptr;
     }
     dim3 grid(tiles, ky), block(nw * 64);
     {
@@ -304,7 +309,7 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
             GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_kernel<DP, FAM, G, F>,               \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
         hipLaunchKernelGGL((mixture_eval_kernel<DP, FAM, G, F>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
-                           logw, X, N, ld, lp_k, grad_k, logw2, lp2);                                               \
+                           logw, X, N, ld, lp_k, grad_k, logw2, lp2_k);                                               \
     } while (0)
 #define GMMVI_LAUNCH_ME2(FAM, G) do { if (lds_feed) GMMVI_LAUNCH_ME(FAM, G, true); else GMMVI_LAUNCH_ME(FAM, G, false); } while (0)
         if (family == GMMVI_GAUSS) {
@@ -318,7 +323,7 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     GMMVI_LAUNCH_CHECK(ctx);
     if (ky > 1 && want_merge) {
         GMMVI_PROF(ctx, "mixture_combine");
-        int rc = gmmvi_combine_partials(ctx, ky, N, D, lp_k, grad_k, lp, grad);
+        int rc = gmmvi_combine_partials_internal(ctx, ky, N, D, lp_k, grad_k, lp, grad, lp2_k, lp2);
         if (rc != GMMVI_OK) return rc;
     }
     return GMMVI_OK;
