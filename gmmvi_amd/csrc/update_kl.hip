@@ -163,8 +163,12 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
         for (int j = 0; j < DR; ++j) { mrow[j] = (t < DR) ? s.M[t * ld + j] : 0.f; wtr[j] = s.wt[j]; }
         float* xv = s.pr;                           // column c of M and p as 16-byte aligned broadcast vectors (the probe
         float* pv = s.pr + 64;                      // scratch is free until the search starts; 3 D (D + 4) floats precede it)
+        // fully unrolled for D <= 32: c becomes a compile-time constant, the selects below fold away and the j loops shrink
+        // to the live part of the column
+        constexpr int UNR_C = DR <= 32 ? DR : 1;
+#pragma unroll UNR_C
         for (int c = 0; c + 2 < DR; ++c) {
-            float mc = 0.f;                         // mrow[c] (c is wave-uniform but not a compile-time constant)
+            float mc = 0.f;                         // mrow[c] (c is wave-uniform; a constant when unrolled)
 #pragma unroll
             for (int j = 0; j < DR; ++j) mc = (j == c) ? mrow[j] : mc;
             if (t < DR) xv[t] = mc;
@@ -345,8 +349,10 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             for (int c = 0; c < DR; ++c)
                 xr[c] = (t < DR && c >= t) ? ((c == t ? 1.f : 0.f) + s.Mc[t * ld + c] * inv) : 0.f;
             float* uv = s.pr;                                      // column j of U as a broadcast vector
+            constexpr int UNR_J = DR <= 32 ? DR : 1;
+#pragma unroll UNR_J
             for (int j = DR - 1; j >= 0; --j) {
-                float bj = 0.f;                                    // xr[j] (j is wave-uniform, not a compile-time constant)
+                float bj = 0.f;                                    // xr[j] (j is wave-uniform; a constant when unrolled)
 #pragma unroll
                 for (int c = 0; c < DR; ++c) bj = (c == j) ? xr[c] : bj;
                 const float p = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bj), j));
