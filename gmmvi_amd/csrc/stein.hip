@@ -355,70 +355,111 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
 #pragma unroll
         for (int t = 0; t < NACC; ++t) acc[t] = 0.f;
         float M = -3.0e38f;
-        // Software pipeline over the four sub-tiles: the substitution of sub-tile t + 1 (VALU, scalar loads) is issued in the
-        // same straight-line region as the 32 MFMAs of sub-tile t, so the matrix pipe works in the shadow of the vector
-        // work of the same wave; the rescale by the running maximum sits between the regions and is branch-free.
-        float yn[DP], a_n;
-        {
-            const bool v0 = lane < n_here;
-            a_n = !v0 ? -3.0e38f : (own_only ? ((mp[0] == k) ? 0.f : -3.0e38f) : la[0] - bgv[0]);
-            if constexpr (SubstAsm<DP>::available) {
+        if constexpr (SubstAsmPk<DP>::available) {
+            // Sub-tiles substituted in PAIRS: two samples per lane as packed float2 registers, one v_pk_fma_f32 per element of
+            // L for both (subst_asm_gen.h) -- the packed rate is the fp32 peak of the vector unit, the plain v_fma_f32 form
+            // runs at half of it.
+            gmmvi_f32x2 yp[DP];
 #pragma unroll
-                for (int i = 0; i < DP; ++i) yn[i] = x[0][i];
-                SubstAsm<DP>::run(P, yn);                              // hand-scheduled: double-buffered scalar feed
-            } else {
-                float z[DP];
-                forward_subst_s<DP>(P, x[0], z);
-                backward_subst_s<DP>(P, z, yn);
+            for (int t = 0; t < 4; ++t) {
+                if ((t & 1) == 0) {
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) { yp[i].x = x[t][i]; yp[i].y = x[t + 1 < 4 ? t + 1 : 3][i]; }
+                    SubstAsmPk<DP>::run(P, yp);
+                }
+                const bool vt = 64 * t + lane < n_here;
+                const float a_t = !vt ? -3.0e38f : (own_only ? ((mp[t] == k) ? 0.f : -3.0e38f) : la[t] - bgv[t]);
+                const float m_t = wave_max(a_t);
+                const float Mn = fmaxf(M, m_t);
+                const float f = __expf(M - Mn);                        // 1 when the maximum did not move, 0 at the start
+                M = Mn;
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) acc[r] *= f;
+                const float e = (a_t > -1.0e38f) ? __expf(a_t - M) : 0.f;
+#pragma unroll
+                for (int i = 0; i < DP; ++i)
+                    if (i < D) Yw[lane * LDW + i] = e * ((t & 1) ? yp[i].y : yp[i].x);
+                Yw[lane * LDW + D] = e;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                constexpr int KS = W == 16 ? 4 : 2, NS = 64 / KS;
+                const int fr = W == 16 ? (lane & 15) : col, fk = W == 16 ? (lane >> 4) : half;
+                const float* Gt = Gs + (64 * t + fk) * LDW + fr;
+                const float* Yt = Yw + fk * LDW + fr;
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) {
+                    if constexpr (W == 16) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Gt[KS * s2 * LDW], Yt[KS * s2 * LDW], acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Gt[KS * s2 * LDW], Yt[KS * s2 * LDW], acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
             }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            // ---- region B: new running maximum, rescale, publish e * [y; 1] of sub-tile t ---------------------------------
-            const float m_t = wave_max(a_n);
-            const float Mn = fmaxf(M, m_t);
-            const float f = __expf(M - Mn);                            // 1 when the maximum did not move, 0 at the start
-            M = Mn;
-#pragma unroll
-            for (int r = 0; r < NACC; ++r) acc[r] *= f;
-            const float e = (a_n > -1.0e38f) ? __expf(a_n - M) : 0.f;
-#pragma unroll
-            for (int i = 0; i < DP; ++i)
-                if (i < D) Yw[lane * LDW + i] = e * yn[i];
-            Yw[lane * LDW + D] = e;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            // ---- region A: MFMAs of sub-tile t  ||  substitution of sub-tile t + 1 ---------------------------------------
-            // operand fragments: 32x32x2 -> lane (row/col = l % 32, k = l / 32), 32 steps of 2 samples;
-            //                    16x16x4 -> lane (row/col = l % 16, k = l / 16), 16 steps of 4 samples
-            constexpr int KS = W == 16 ? 4 : 2, NS = 64 / KS;
-            const int fr = W == 16 ? (lane & 15) : col, fk = W == 16 ? (lane >> 4) : half;
-            const float* Gt = Gs + (64 * t + fk) * LDW + fr;
-            const float* Yt = Yw + fk * LDW + fr;
-            float ga[NS], yb[NS];
-#pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2) { ga[s2] = Gt[KS * s2 * LDW]; yb[s2] = Yt[KS * s2 * LDW]; }
-            if (t < 3) {
-                const bool v1 = 64 * (t + 1) + lane < n_here;
-                a_n = !v1 ? -3.0e38f : (own_only ? ((mp[t + 1 < 4 ? t + 1 : 3] == k) ? 0.f : -3.0e38f)
-                                                  : la[t + 1 < 4 ? t + 1 : 3] - bgv[t + 1 < 4 ? t + 1 : 3]);
+        } else {
+        // Software pipeline over the four sub-tiles: the substitution of sub-tile t + 1 (VALU, scalar loads) is issued in the
+            // same straight-line region as the 32 MFMAs of sub-tile t, so the matrix pipe works in the shadow of the vector
+            // work of the same wave; the rescale by the running maximum sits between the regions and is branch-free.
+            float yn[DP], a_n;
+            {
+                const bool v0 = lane < n_here;
+                a_n = !v0 ? -3.0e38f : (own_only ? ((mp[0] == k) ? 0.f : -3.0e38f) : la[0] - bgv[0]);
                 if constexpr (SubstAsm<DP>::available) {
 #pragma unroll
-                    for (int i = 0; i < DP; ++i) yn[i] = x[t + 1 < 4 ? t + 1 : 3][i];
-                    SubstAsm<DP>::run(P, yn);
+                    for (int i = 0; i < DP; ++i) yn[i] = x[0][i];
+                    SubstAsm<DP>::run(P, yn);                              // hand-scheduled: double-buffered scalar feed
                 } else {
                     float z[DP];
-                    forward_subst_s<DP>(P, x[t + 1 < 4 ? t + 1 : 3], z);
+                    forward_subst_s<DP>(P, x[0], z);
                     backward_subst_s<DP>(P, z, yn);
                 }
             }
 #pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2) {
-                if constexpr (W == 16) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s2], yb[s2], acc, 0, 0, 0);
-                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s2], yb[s2], acc, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+                // ---- region B: new running maximum, rescale, publish e * [y; 1] of sub-tile t ---------------------------------
+                const float m_t = wave_max(a_n);
+                const float Mn = fmaxf(M, m_t);
+                const float f = __expf(M - Mn);                            // 1 when the maximum did not move, 0 at the start
+                M = Mn;
+#pragma unroll
+                for (int r = 0; r < NACC; ++r) acc[r] *= f;
+                const float e = (a_n > -1.0e38f) ? __expf(a_n - M) : 0.f;
+#pragma unroll
+                for (int i = 0; i < DP; ++i)
+                    if (i < D) Yw[lane * LDW + i] = e * yn[i];
+                Yw[lane * LDW + D] = e;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                // ---- region A: MFMAs of sub-tile t  ||  substitution of sub-tile t + 1 ---------------------------------------
+                // operand fragments: 32x32x2 -> lane (row/col = l % 32, k = l / 32), 32 steps of 2 samples;
+                //                    16x16x4 -> lane (row/col = l % 16, k = l / 16), 16 steps of 4 samples
+                constexpr int KS = W == 16 ? 4 : 2, NS = 64 / KS;
+                const int fr = W == 16 ? (lane & 15) : col, fk = W == 16 ? (lane >> 4) : half;
+                const float* Gt = Gs + (64 * t + fk) * LDW + fr;
+                const float* Yt = Yw + fk * LDW + fr;
+                float ga[NS], yb[NS];
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) { ga[s2] = Gt[KS * s2 * LDW]; yb[s2] = Yt[KS * s2 * LDW]; }
+                if (t < 3) {
+                    const bool v1 = 64 * (t + 1) + lane < n_here;
+                    a_n = !v1 ? -3.0e38f : (own_only ? ((mp[t + 1 < 4 ? t + 1 : 3] == k) ? 0.f : -3.0e38f)
+                                                      : la[t + 1 < 4 ? t + 1 : 3] - bgv[t + 1 < 4 ? t + 1 : 3]);
+                    if constexpr (SubstAsm<DP>::available) {
+#pragma unroll
+                        for (int i = 0; i < DP; ++i) yn[i] = x[t + 1 < 4 ? t + 1 : 3][i];
+                        SubstAsm<DP>::run(P, yn);
+                    } else {
+                        float z[DP];
+                        forward_subst_s<DP>(P, x[t + 1 < 4 ? t + 1 : 3], z);
+                        backward_subst_s<DP>(P, z, yn);
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) {
+                    if constexpr (W == 16) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s2], yb[s2], acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s2], yb[s2], acc, 0, 0, 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
         }
         float* out = part + ((size_t)k * n_tiles + tile) * (size_t)(D1 * D1);
 #pragma unroll

@@ -102,6 +102,97 @@ def gen(dp, part="both"):
     return lines
 
 
+def gen_pk(dp):
+    """Two samples per lane (float2 operands, v_pk_fma_f32): every scalar of L feeds two FMAs in ONE instruction -- the only
+    way to the packed fp32 rate of the vector unit.  fwd + bwd in place, same element order as gen()."""
+    assert 2 <= dp <= 20
+    T = dp * (dp - 1) // 2
+    MU, RD, LROW, LCOL = 0, dp, 2 * dp, 2 * dp + T
+    lines = []
+    emit = lines.append
+    P = f"%{dp}"
+
+    def sload(dst, n, float_off):
+        emit(f"s_load_dwordx{n} s[{dst}:{dst + n - 1}], {P}, {hex(4 * float_off)}" if n > 1 else
+             f"s_load_dword s{dst}, {P}, {hex(4 * float_off)}")
+
+    def load_span(dst, float_off, count):
+        done = 0
+        while done < count:
+            rem = count - done
+            n = 16 if rem >= 16 else 8 if rem >= 8 else 4 if rem >= 4 else 2 if rem >= 2 else 1
+            while (dst + done) % min(n, 4) != 0:
+                n //= 2
+            sload(dst + done, n, float_off + done)
+            done += n
+
+    def spair(reg):                                   # (aligned SGPR pair holding reg, which half)
+        return f"s[{reg & ~1}:{(reg & ~1) + 1}]", reg & 1
+
+    def pk_fma(i, reg, j):                            # v_i -= s_reg * v_j   (both samples)
+        sp, h = spair(reg)
+        emit(f"v_pk_fma_f32 %{i}, {sp}, %{j}, %{i} op_sel:[{h},0,0] op_sel_hi:[{h},1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]")
+
+    def pk_mul(i, reg):                               # v_i *= s_reg
+        sp, h = spair(reg)
+        emit(f"v_pk_mul_f32 %{i}, %{i}, {sp} op_sel:[0,{h}] op_sel_hi:[1,{h}]")
+
+    def pk_sub(i, reg):                               # v_i -= s_reg
+        sp, h = spair(reg)
+        emit(f"v_pk_add_f32 %{i}, %{i}, {sp} op_sel:[0,{h}] op_sel_hi:[1,{h}] neg_lo:[0,1] neg_hi:[0,1]")
+
+    load_span(BUF_A, MU, min(dp, 16))
+    if dp > 16:
+        load_span(BUF_B, MU + 16, dp - 16)
+    load_span(RD0, RD, min(dp, 16))
+    if dp > 16:
+        load_span(RD0 + 16, RD + 16, dp - 16)
+    emit("s_waitcnt lgkmcnt(0)")
+    for i in range(dp):
+        pk_sub(i, BUF_A + i if i < 16 else BUF_B + i - 16)
+    pk_mul(0, RD0)
+
+    def stream(n_elems, base_off, descending, consume):
+        nch = (n_elems + 15) // 16
+        def span(c):
+            lo = 16 * c
+            cnt = min(16, n_elems - lo)
+            if not descending:
+                return base_off + lo, cnt, lo
+            return base_off + n_elems - lo - cnt, cnt, lo
+        bufs = (BUF_A, BUF_B)
+        off, cnt, _ = span(0)
+        load_span(bufs[0], off, cnt)
+        emit("s_waitcnt lgkmcnt(0)")
+        for c in range(nch):
+            if c + 1 < nch:
+                off, cnt, _ = span(c + 1)
+                load_span(bufs[(c + 1) & 1], off, cnt)
+            off, cnt, lo = span(c)
+            for e in range(cnt):
+                reg = bufs[c & 1] + (e if not descending else cnt - 1 - e)
+                consume(lo + e, reg)
+            if c + 1 < nch:
+                emit("s_waitcnt lgkmcnt(0)")
+
+    rows = [(i, j) for i in range(1, dp) for j in range(i)]
+    def fwd(idx, reg):
+        i, j = rows[idx]
+        pk_fma(i, reg, j)
+        if j == i - 1:
+            pk_mul(i, RD0 + i)
+    stream(T, LROW, False, fwd)
+    cols = [(i, j) for i in range(dp - 1) for j in range(i + 1, dp)]
+    pk_mul(dp - 1, RD0 + dp - 1)
+    def bwd(idx, reg):
+        i, j = cols[T - 1 - idx]
+        pk_fma(i, reg, j)
+        if j == i + 1:
+            pk_mul(i, RD0 + i)
+    stream(T, LCOL, True, bwd)
+    return lines
+
+
 def main(out):
     w = []
     w.append("// GENERATED by tools/gen_subst_asm.py -- do not edit.  See that file for the scheme.")
@@ -127,6 +218,25 @@ def main(out):
             w.append('            : "s"(P)')
             w.append(f"            : {clob});")
             w.append("    }")
+        w.append("};")
+    w.append("")
+    w.append("typedef float gmmvi_f32x2 __attribute__((ext_vector_type(2)));")
+    w.append("template <int DP> struct SubstAsmPk { static constexpr bool available = false; };")
+    for dp in (10, 20):
+        ops = ", ".join(f'"+v"(v[{i}])' for i in range(dp))
+        clob = ", ".join(f'"s{r}"' for r in range(BUF_A, RD0 + 20))
+        w.append("")
+        w.append(f"template <> struct SubstAsmPk<{dp}> {{")
+        w.append("    static constexpr bool available = true;")
+        w.append("    // v[i] = (x_i of sample A, x_i of sample B)  ->  Sigma^-1 (x - mu) of both, one v_pk_fma_f32 per element of L")
+        w.append(f"    static __device__ __forceinline__ void run(const float* P, gmmvi_f32x2 (&v)[{dp}]) {{")
+        w.append("        asm volatile(")
+        for ln in gen_pk(dp):
+            w.append(f'            "{ln}\\n"')
+        w.append(f"            : {ops}")
+        w.append('            : "s"(P)')
+        w.append(f"            : {clob});")
+        w.append("    }")
         w.append("};")
     open(out, "w").write("\n".join(w) + "\n")
 
