@@ -12,6 +12,8 @@ forward_subst_s) -> y (backward, columns descending, rows descending within a co
 """
 import sys
 
+import os
+
 BUF_A, BUF_B, RD0 = 40, 56, 72          # SGPR bases: two 16-dword buffers, 1/diag (DP <= 20)
 
 
@@ -102,10 +104,15 @@ def gen(dp, part="both"):
     return lines
 
 
+PK_CH = int(os.environ.get("PK_CH", "16")) if "os" in dir() else 16
+
+
 def gen_pk(dp):
     """Two samples per lane (float2 operands, v_pk_fma_f32): every scalar of L feeds two FMAs in ONE instruction -- the only
     way to the packed fp32 rate of the vector unit.  fwd + bwd in place, same element order as gen()."""
     assert 2 <= dp <= 20
+    CH = PK_CH
+    A0, B0, R0 = (40, 56, 72) if CH == 16 else ((32, 56, 80) if CH == 24 else (16, 48, 80))
     T = dp * (dp - 1) // 2
     MU, RD, LROW, LCOL = 0, dp, 2 * dp, 2 * dp + T
     lines = []
@@ -141,26 +148,22 @@ def gen_pk(dp):
         sp, h = spair(reg)
         emit(f"v_pk_add_f32 %{i}, %{i}, {sp} op_sel:[0,{h}] op_sel_hi:[1,{h}] neg_lo:[0,1] neg_hi:[0,1]")
 
-    load_span(BUF_A, MU, min(dp, 16))
-    if dp > 16:
-        load_span(BUF_B, MU + 16, dp - 16)
-    load_span(RD0, RD, min(dp, 16))
-    if dp > 16:
-        load_span(RD0 + 16, RD + 16, dp - 16)
+    load_span(A0, MU, dp)                           # mu transits through buffer A (dp <= 20 <= CH + slack)
+    load_span(R0, RD, dp)
     emit("s_waitcnt lgkmcnt(0)")
     for i in range(dp):
-        pk_sub(i, BUF_A + i if i < 16 else BUF_B + i - 16)
-    pk_mul(0, RD0)
+        pk_sub(i, A0 + i)
+    pk_mul(0, R0)
 
     def stream(n_elems, base_off, descending, consume):
-        nch = (n_elems + 15) // 16
+        nch = (n_elems + CH - 1) // CH
         def span(c):
-            lo = 16 * c
-            cnt = min(16, n_elems - lo)
+            lo = CH * c
+            cnt = min(CH, n_elems - lo)
             if not descending:
                 return base_off + lo, cnt, lo
             return base_off + n_elems - lo - cnt, cnt, lo
-        bufs = (BUF_A, BUF_B)
+        bufs = (A0, B0)
         off, cnt, _ = span(0)
         load_span(bufs[0], off, cnt)
         emit("s_waitcnt lgkmcnt(0)")
@@ -180,15 +183,15 @@ def gen_pk(dp):
         i, j = rows[idx]
         pk_fma(i, reg, j)
         if j == i - 1:
-            pk_mul(i, RD0 + i)
+            pk_mul(i, R0 + i)
     stream(T, LROW, False, fwd)
     cols = [(i, j) for i in range(dp - 1) for j in range(i + 1, dp)]
-    pk_mul(dp - 1, RD0 + dp - 1)
+    pk_mul(dp - 1, R0 + dp - 1)
     def bwd(idx, reg):
         i, j = cols[T - 1 - idx]
         pk_fma(i, reg, j)
         if j == i + 1:
-            pk_mul(i, RD0 + i)
+            pk_mul(i, R0 + i)
     stream(T, LCOL, True, bwd)
     return lines
 
@@ -224,7 +227,8 @@ def main(out):
     w.append("template <int DP> struct SubstAsmPk { static constexpr bool available = false; };")
     for dp in (10, 20):
         ops = ", ".join(f'"+v"(v[{i}])' for i in range(dp))
-        clob = ", ".join(f'"s{r}"' for r in range(BUF_A, RD0 + 20))
+        lo_c, hi_c = (40, 92) if PK_CH == 16 else ((32, 100) if PK_CH == 24 else (16, 100))
+        clob = ", ".join(f'"s{r}"' for r in range(lo_c, hi_c))
         w.append("")
         w.append(f"template <> struct SubstAsmPk<{dp}> {{")
         w.append("    static constexpr bool available = true;")
