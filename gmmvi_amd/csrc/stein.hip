@@ -287,6 +287,15 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ A, const fl
 // W = 32: v_mfma_f32_32x32x2 (D + 1 <= 32); W = 16: v_mfma_f32_16x16x4 for D + 1 <= 16 -- a quarter of the matrix-pipe time
 // and half the LDS, the 32-wide tile is 88 % padding at D = 10.  D[i][j] of the 16x16x4 form: i = 4 (l / 16) + r, j = l % 16
 // (probed: tools/probe/mfma_f32_16x16x4_layout.hip).
+// The e * [y; 1] tile is private to the wave: ordering its LDS writes against the MFMA operand reads only needs the wave's own
+// LDS queue drained (and the compiler kept from moving the accesses).  A workgroup-scope fence would also wait for every
+// outstanding GLOBAL access -- the prefetched log-density rows, the previous component's partial stores -- ~1 us each time.
+#define WAVE_LDS_SYNC()                                        \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
+
 template <int DP, int W>
 __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chunk, const float* __restrict__ packed,
                                                           const float* __restrict__ X, const float* __restrict__ TG,
@@ -380,8 +389,7 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
                 for (int i = 0; i < DP; ++i)
                     if (i < D) Yw[lane * LDW + i] = e * ((t & 1) ? yp[i].y : yp[i].x);
                 Yw[lane * LDW + D] = e;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+                WAVE_LDS_SYNC();
                 constexpr int KS = W == 16 ? 4 : 2, NS = 64 / KS;
                 const int fr = W == 16 ? (lane & 15) : col, fk = W == 16 ? (lane >> 4) : half;
                 const float* Gt = Gs + (64 * t + fk) * LDW + fr;
@@ -391,8 +399,7 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
                     if constexpr (W == 16) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Gt[KS * s2 * LDW], Yt[KS * s2 * LDW], acc, 0, 0, 0);
                     else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Gt[KS * s2 * LDW], Yt[KS * s2 * LDW], acc, 0, 0, 0);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+                WAVE_LDS_SYNC();
             }
         } else {
         // Software pipeline over the four sub-tiles: the substitution of sub-tile t + 1 (VALU, scalar loads) is issued in the
@@ -426,8 +433,7 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
                 for (int i = 0; i < DP; ++i)
                     if (i < D) Yw[lane * LDW + i] = e * yn[i];
                 Yw[lane * LDW + D] = e;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+                WAVE_LDS_SYNC();
                 // ---- region A: MFMAs of sub-tile t  ||  substitution of sub-tile t + 1 ---------------------------------------
                 // operand fragments: 32x32x2 -> lane (row/col = l % 32, k = l / 32), 32 steps of 2 samples;
                 //                    16x16x4 -> lane (row/col = l % 16, k = l / 16), 16 steps of 4 samples
@@ -457,8 +463,7 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
                     if constexpr (W == 16) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s2], yb[s2], acc, 0, 0, 0);
                     else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s2], yb[s2], acc, 0, 0, 0);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
+                WAVE_LDS_SYNC();
             }
         }
         float* out = part + ((size_t)k * n_tiles + tile) * (size_t)(D1 * D1);
