@@ -176,9 +176,11 @@ __global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, int ch
     }
 }
 
+// DPZ > 0: the partials are in z form (see stein_wc_kernel) and DPZ is the padded dimension of the packed blocks; 0: y form
+template <int DPZ>
 __global__ __launch_bounds__(1024) void stein_finalize_kernel(int D, int R, int N, int flags, const float* __restrict__ part,
                                                              const float* __restrict__ part_m, float* __restrict__ H_neg,
-                                                             float* __restrict__ g_neg) {
+                                                             float* __restrict__ g_neg, const float* __restrict__ packed_z) {
     extern __shared__ float A[];       // (D+1)^2, then R scale factors
     const int k = blockIdx.x;
     const int D1 = D + 1;
@@ -210,6 +212,34 @@ __global__ __launch_bounds__(1024) void stein_finalize_kernel(int D, int R, int 
         A[e] = a;
     }
     __syncthreads();
+    if constexpr (DPZ > 0) {
+        // the partials hold sum e g z^T with z = L^-1 (x - mu): y = L^-T z, so row i of sum e g y^T is (row i) L^-1, i.e.
+        // h L = b solved from the last column; L from the component's packed block (common.h Pack<DP>: 1/diag, columns)
+        // staged in LDS, the row in registers, loops unrolled for the padded dimension
+        using PK = Pack<DPZ>;
+        const float* Pk = packed_z + (size_t)k * PK::STRIDE;
+        float* Lc = Ag;                                // the group sums are consumed: reuse as [1/diag (DPZ) | columns (T)]
+        for (int e = threadIdx.x; e < DPZ + PK::T; e += blockDim.x)
+            Lc[e] = (e < DPZ) ? Pk[PK::RD + e] : Pk[PK::LCOL + (e - DPZ)];
+        __syncthreads();
+        if (threadIdx.x < D) {
+            float* row = A + threadIdx.x * D1;
+            float h[DPZ];
+#pragma unroll
+            for (int j = 0; j < DPZ; ++j) h[j] = (j < D) ? row[j] : 0.f;
+#pragma unroll
+            for (int j = DPZ - 1; j >= 0; --j) {
+                float t = h[j];
+#pragma unroll
+                for (int m = j + 1; m < DPZ; ++m) t = fmaf(-h[m], Lc[DPZ + PK::colofs(j) + (m - j - 1)], t);   // padding: L = 0
+                h[j] = t * Lc[j];
+            }
+#pragma unroll
+            for (int j = 0; j < DPZ; ++j)
+                if (j < D) row[j] = h[j];
+        }
+        __syncthreads();
+    }
     const bool snis = (flags & GMMVI_SELF_NORMALIZED) != 0;
     // A[i][j] = sum e g_i y_j, A[i][D] = sum e g_i, A[D][D] = sum e.
     // plain importance weights: 1/N * sum exp(ld - bg) v   (ng_estimator.py:146-152), Hessian not symmetrised
@@ -222,21 +252,37 @@ __global__ __launch_bounds__(1024) void stein_finalize_kernel(int D, int R, int 
     for (int i = threadIdx.x; i < D; i += blockDim.x) g_neg[(size_t)k * D + i] = -A[i * D1 + D] * scale;
 }
 
-static int launch_stein_finalize(gmmvi_ctx* ctx, int K, int D, int R, int N, int flags, const float* part,
-                                 const float* part_m, float* H_neg, float* g_neg) {
+template <int DPZ>
+static int launch_stein_finalize_t(gmmvi_ctx* ctx, int K, int D, int R, int N, int flags, const float* part,
+                                   const float* part_m, float* H_neg, float* g_neg, const float* packed_z) {
     const int D1 = D + 1;
-    const size_t shmem = ((size_t)5 * D1 * D1 + R) * sizeof(float);
+    size_t floats = (size_t)5 * D1 * D1 + R;
+    if (DPZ > 0 && (size_t)D1 * D1 + R + DPZ + Pack<(DPZ > 0 ? DPZ : 2)>::T > floats)
+        floats = (size_t)D1 * D1 + R + DPZ + Pack<(DPZ > 0 ? DPZ : 2)>::T;
+    const size_t shmem = floats * sizeof(float);
     static size_t attr = 64 * 1024;
     if (shmem > attr) {
-        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_finalize_kernel,
+        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_finalize_kernel<DPZ>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         attr = shmem;
     }
     GMMVI_PROF(ctx, "stein_finalize");
-    hipLaunchKernelGGL(stein_finalize_kernel, dim3(K), dim3(1024), shmem, ctx->stream, D, R, N, flags, part, part_m, H_neg,
-                       g_neg);
+    hipLaunchKernelGGL(stein_finalize_kernel<DPZ>, dim3(K), dim3(1024), shmem, ctx->stream, D, R, N, flags, part, part_m, H_neg,
+                       g_neg, packed_z);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
+}
+
+// packed_z != nullptr: partials in z form (wave-per-component kernel), L^-T applied here
+static int launch_stein_finalize(gmmvi_ctx* ctx, int K, int D, int R, int N, int flags, const float* part,
+                                 const float* part_m, float* H_neg, float* g_neg, const float* packed_z = nullptr) {
+    if (packed_z == nullptr) return launch_stein_finalize_t<0>(ctx, K, D, R, N, flags, part, part_m, H_neg, g_neg, nullptr);
+    switch (gmmvi_padded_dim(D)) {
+#define GMMVI_FIN(DPV) case DPV: return launch_stein_finalize_t<DPV>(ctx, K, D, R, N, flags, part, part_m, H_neg, g_neg, packed_z)
+        GMMVI_FIN(2); GMMVI_FIN(4); GMMVI_FIN(8); GMMVI_FIN(10); GMMVI_FIN(12); GMMVI_FIN(16); GMMVI_FIN(20); GMMVI_FIN(24);
+#undef GMMVI_FIN
+        default: return gmmvi_fail(ctx, GMMVI_ERR_ARG, "stein_finalize: z form needs D <= 24");
+    }
 }
 
 // Row tile [rows, D] (contiguous in memory) -> LDS image with row stride ld, all loads of a thread in flight at once:
@@ -283,7 +329,9 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ A, const fl
 // matrix in its MFMA registers with an online rescale of the running maximum.  Nothing is merged across waves and the
 // component loop has no block barrier: one partial per (component, tile) leaves straight from the accumulators.  A
 // component's block is read through the scalar cache four times in a row (once per sub-tile) instead of by four waves
-// in four different places.
+// in four different places.  The kernel accumulates  sum_n e [g;1] [z;1]^T  with the FORWARD-substituted z = L^-1 (x - mu) only:
+// y = L^-T z is linear in z with a per-component matrix, so L^-T is applied once per component to the finished sum
+// (stein_finalize, z_form) instead of once per sample -- half the per-sample vector work.
 // W = 32: v_mfma_f32_32x32x2 (D + 1 <= 32); W = 16: v_mfma_f32_16x16x4 for D + 1 <= 16 -- a quarter of the matrix-pipe time
 // and half the LDS, the 32-wide tile is 88 % padding at D = 10.  D[i][j] of the 16x16x4 form: i = 4 (l / 16) + r, j = l % 16
 // (probed: tools/probe/mfma_f32_16x16x4_layout.hip).
@@ -374,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
                 if ((t & 1) == 0) {
 #pragma unroll
                     for (int i = 0; i < DP; ++i) { yp[i].x = x[t][i]; yp[i].y = x[t + 1 < 4 ? t + 1 : 3][i]; }
-                    SubstAsmPk<DP>::run(P, yp);
+                    SubstAsmPk<DP>::forward(P, yp);             // z = L^-1 (x - mu); L^-T is applied once, in stein_finalize
                 }
                 const bool vt = 64 * t + lane < n_here;
                 const float a_t = !vt ? -3.0e38f : (own_only ? ((mp[t] == k) ? 0.f : -3.0e38f) : la[t] - bgv[t]);
@@ -412,11 +460,9 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
                 if constexpr (SubstAsm<DP>::available) {
 #pragma unroll
                     for (int i = 0; i < DP; ++i) yn[i] = x[0][i];
-                    SubstAsm<DP>::run(P, yn);                              // hand-scheduled: double-buffered scalar feed
+                    SubstAsm<DP>::forward(P, yn);                          // hand-scheduled: double-buffered scalar feed
                 } else {
-                    float z[DP];
-                    forward_subst_s<DP>(P, x[0], z);
-                    backward_subst_s<DP>(P, z, yn);
+                    forward_subst_s<DP>(P, x[0], yn);
                 }
             }
 #pragma unroll
@@ -451,11 +497,9 @@ __global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chun
                     if constexpr (SubstAsm<DP>::available) {
 #pragma unroll
                         for (int i = 0; i < DP; ++i) yn[i] = x[t + 1 < 4 ? t + 1 : 3][i];
-                        SubstAsm<DP>::run(P, yn);
+                        SubstAsm<DP>::forward(P, yn);
                     } else {
-                        float z[DP];
-                        forward_subst_s<DP>(P, x[t + 1 < 4 ? t + 1 : 3], z);
-                        backward_subst_s<DP>(P, z, yn);
+                        forward_subst_s<DP>(P, x[t + 1 < 4 ? t + 1 : 3], yn);
                     }
                 }
 #pragma unroll
@@ -512,7 +556,7 @@ static int launch_stein_wc(gmmvi_ctx* ctx, int K, int D, const float* packed, co
                            packed, X, tgrad, qgrad, N, ld, bg, mapping, map_offset, flags, part, part_m);
     }
     GMMVI_LAUNCH_CHECK(ctx);
-    return launch_stein_finalize(ctx, K, D, n_tiles, N, flags, part, part_m, H_neg, g_neg);
+    return launch_stein_finalize(ctx, K, D, n_tiles, N, flags, part, part_m, H_neg, g_neg, packed);   // z form
 }
 
 

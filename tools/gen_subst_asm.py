@@ -107,7 +107,7 @@ def gen(dp, part="both"):
 PK_CH = int(os.environ.get("PK_CH", "16")) if "os" in dir() else 16
 
 
-def gen_pk(dp):
+def gen_pk(dp, part="both"):
     """Two samples per lane (float2 operands, v_pk_fma_f32): every scalar of L feeds two FMAs in ONE instruction -- the only
     way to the packed fp32 rate of the vector unit.  fwd + bwd in place, same element order as gen()."""
     assert 2 <= dp <= 20
@@ -185,6 +185,8 @@ def gen_pk(dp):
         if j == i - 1:
             pk_mul(i, R0 + i)
     stream(T, LROW, False, fwd)
+    if part == "fwd":
+        return lines
     cols = [(i, j) for i in range(dp - 1) for j in range(i + 1, dp)]
     pk_mul(dp - 1, R0 + dp - 1)
     def bwd(idx, reg):
@@ -232,15 +234,16 @@ def main(out):
         w.append("")
         w.append(f"template <> struct SubstAsmPk<{dp}> {{")
         w.append("    static constexpr bool available = true;")
-        w.append("    // v[i] = (x_i of sample A, x_i of sample B)  ->  Sigma^-1 (x - mu) of both, one v_pk_fma_f32 per element of L")
-        w.append(f"    static __device__ __forceinline__ void run(const float* P, gmmvi_f32x2 (&v)[{dp}]) {{")
-        w.append("        asm volatile(")
-        for ln in gen_pk(dp):
-            w.append(f'            "{ln}\\n"')
-        w.append(f"            : {ops}")
-        w.append('            : "s"(P)')
-        w.append(f"            : {clob});")
-        w.append("    }")
+        for name, part, doc in (("run", "both", "Sigma^-1 (x - mu)"), ("forward", "fwd", "z = L^-1 (x - mu)")):
+            w.append(f"    // v[i] = (x_i of sample A, x_i of sample B)  ->  {doc} of both, one v_pk_fma_f32 per element of L")
+            w.append(f"    static __device__ __forceinline__ void {name}(const float* P, gmmvi_f32x2 (&v)[{dp}]) {{")
+            w.append("        asm volatile(")
+            for ln in gen_pk(dp, part):
+                w.append(f'            "{ln}\\n"')
+            w.append(f"            : {ops}")
+            w.append('            : "s"(P)')
+            w.append(f"            : {clob});")
+            w.append("    }")
         w.append("};")
     open(out, "w").write("\n".join(w) + "\n")
 
