@@ -119,12 +119,11 @@ __global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, int ch
         const float m_w = wave_max(a_log);
         const float e = (valid && a_log > -1.0e38f) ? __expf(a_log - m_w) : 0.f;
 
-        float z[DP], y[DP];
-        forward_subst_s<DP>(P, x, z);
-        backward_subst_s<DP>(P, z, y);
+        float z[DP];
+        forward_subst_s<DP>(P, x, z);                  // z form: L^-T is applied once per component in stein_finalize
 #pragma unroll
         for (int i = 0; i < DP; ++i)
-            if (i < D) Yw[lane * LDW + i] = e * y[i];
+            if (i < D) Yw[lane * LDW + i] = e * z[i];
         Yw[lane * LDW + D] = e;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -280,8 +279,9 @@ static int launch_stein_finalize(gmmvi_ctx* ctx, int K, int D, int R, int N, int
     switch (gmmvi_padded_dim(D)) {
 #define GMMVI_FIN(DPV) case DPV: return launch_stein_finalize_t<DPV>(ctx, K, D, R, N, flags, part, part_m, H_neg, g_neg, packed_z)
         GMMVI_FIN(2); GMMVI_FIN(4); GMMVI_FIN(8); GMMVI_FIN(10); GMMVI_FIN(12); GMMVI_FIN(16); GMMVI_FIN(20); GMMVI_FIN(24);
+        GMMVI_FIN(32); GMMVI_FIN(40); GMMVI_FIN(50); GMMVI_FIN(64);
 #undef GMMVI_FIN
-        default: return gmmvi_fail(ctx, GMMVI_ERR_ARG, "stein_finalize: z form needs D <= 24");
+        default: return gmmvi_fail(ctx, GMMVI_ERR_ARG, "stein_finalize: unsupported dimension");
     }
 }
 
@@ -591,7 +591,7 @@ static int launch_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
                            chunk, packed, X, tgrad, qgrad, N, ld, bg, mapping, map_offset, flags, part, part_m);
     }
     GMMVI_LAUNCH_CHECK(ctx);
-    return launch_stein_finalize(ctx, K, D, n_tiles, N, flags, part, part_m, H_neg, g_neg);
+    return launch_stein_finalize(ctx, K, D, n_tiles, N, flags, part, part_m, H_neg, g_neg, packed);   // z form
 }
 
 extern "C" int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* X_dev, int N,
