@@ -103,6 +103,34 @@ __device__ float weights_kl(float eta, float beta, const float* lw, const float*
     return wsum(kl);
 }
 
+// weights_kl for K <= 128 with the lane's two elements (i = lane, lane + 64) in registers: the same operations in the same
+// order as the LDS form (every lane reduces its strided elements first, then the wave), without the LDS round trips and
+// barriers of up to 50 probes.  v0 / v1 return the new log weights of the lane's elements.
+__device__ __forceinline__ float weights_kl_reg(float eta, float beta, float lw0, float lw1, float E0, float E1, bool h0,
+                                               bool h1, float& v0, float& v1) {
+    const float a = (eta + 1.f) / (beta + eta), b = 1.f / (beta + eta);
+    float n0 = a * lw0 + b * E0, n1 = a * lw1 + b * E1;                                   // :184-185
+    auto lse2 = [&](float x0, float x1) {
+        float m = -3.0e38f;
+        if (h0) m = fmaxf(m, x0);
+        if (h1) m = fmaxf(m, x1);
+        m = wmax(m);
+        float s = 0.f;
+        if (h0) s += __expf(x0 - m);
+        if (h1) s += __expf(x1 - m);
+        s = wsum(s);
+        return m + __logf(s);
+    };
+    float l = lse2(n0, n1);
+    n0 = fmaxf(n0 - l, -69.07f); n1 = fmaxf(n1 - l, -69.07f);                             // :186-187
+    l = lse2(n0, n1);
+    float kl = 0.f;
+    v0 = n0 - l; v1 = n1 - l;                                                             // :188
+    if (h0) kl = fmaf(__expf(v0), v0 - lw0, kl);                                          // :190
+    if (h1) kl = fmaf(__expf(v1), v1 - lw1, kl);
+    return wsum(kl);
+}
+
 // mode 0: trust region (:193-279); mode 1: direct (:123-141).  Single wavefront; lw/E/nl live in LDS.
 __global__ __launch_bounds__(64) void update_weights_kernel(int mode, int K, float* __restrict__ logw,
                                                             const float* __restrict__ E_in, const float* __restrict__ stepsize,
@@ -130,10 +158,15 @@ __global__ __launch_bounds__(64) void update_weights_kernel(int mode, int K, flo
         float lb = -45.f, ub = 45.f;                                                      // :276-277
         float log_eta = 0.5f * (ub + lb);
         bool ub_ok = false;
+        const bool in_regs = K <= 128;
+        const bool h0 = t < K, h1 = t + 64 < K;
+        const float lw0 = h0 ? lw[t] : 0.f, lw1 = h1 ? lw[t + 64] : 0.f, E0 = h0 ? E[t] : 0.f, E1 = h1 ? E[t + 64] : 0.f;
+        float v0 = lw0, v1 = lw1;                                                         // nl starts as the old weights
         for (int it = 0; it < 50; ++it) {                                                 // :232
             eta = expf(log_eta);
             if (fabsf(expf(ub) - expf(lb)) < 1e-1f) break;                                // :234-236
-            kl = weights_kl(eta, beta, lw, E, nl, K);                                     // :238
+            kl = in_regs ? weights_kl_reg(eta, beta, lw0, lw1, E0, E1, h0, h1, v0, v1)
+                         : weights_kl(eta, beta, lw, E, nl, K);                           // :238
             if (fabsf(bound - kl) < 1e-1f * bound) { lb = ub; break; }                    // :240-243
             if (bound > kl) { ub = log_eta; ub_ok = true; } else { lb = log_eta; }        // :245-249
             log_eta = 0.5f * (ub + lb);
@@ -142,10 +175,16 @@ __global__ __launch_bounds__(64) void update_weights_kernel(int mode, int K, flo
             // :252-253 keep the last evaluated weights
         } else if (ub_ok) {
             eta = expf(ub);
-            kl = weights_kl(eta, beta, lw, E, nl, K);                                     // :256-258
+            kl = in_regs ? weights_kl_reg(eta, beta, lw0, lw1, E0, E1, h0, h1, v0, v1)
+                         : weights_kl(eta, beta, lw, E, nl, K);                           // :256-258
         } else {
             updated = false;                                                              // :260
             kl = -1.f; eta = -1.f;
+        }
+        if (in_regs) {                                                                    // hand the result to the LDS image
+            if (h0) nl[t] = v0;
+            if (h1) nl[t + 64] = v1;
+            __syncthreads();
         }
     }
     if (!updated) {
