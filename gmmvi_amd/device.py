@@ -7,6 +7,8 @@ modules hand each other device-resident arrays and only ``.numpy()`` copies to t
 import ctypes as C
 import os
 
+import math
+
 import numpy as np
 
 from . import _lib
@@ -143,11 +145,11 @@ class DeviceArray:
     @classmethod
     def _alloc(cls, ctx, shape, dtype):
         self = object.__new__(cls)
-        shape = (int(shape),) if np.isscalar(shape) else tuple(int(s) for s in shape)
+        shape = (int(shape),) if isinstance(shape, (int, np.integer)) else tuple(int(s) for s in shape)
         dtype = np.dtype(dtype)
         if dtype not in (np.dtype(np.float32), np.dtype(np.int32)):
             raise TypeError(f"DeviceArray supports float32 and int32, not {dtype}")
-        nbytes = int(np.prod(shape, dtype=np.int64)) * 4
+        nbytes = math.prod(shape) * 4
         ptr, cap = ctx._alloc_bytes(nbytes)
         self.ctx, self.ptr, self.shape, self.dtype, self._owner, self._base = ctx, ptr, shape, dtype, True, None
         self._cap = cap
@@ -171,7 +173,7 @@ class DeviceArray:
     # ---- metadata -----------------------------------------------------------------------------------------
     @property
     def size(self):
-        return int(np.prod(self.shape, dtype=np.int64))
+        return math.prod(self.shape)
 
     @property
     def ndim(self):
@@ -226,16 +228,16 @@ class DeviceArray:
         stop = n if stop is None else stop
         if not (0 <= start <= stop <= n):
             raise IndexError(f"rows({start}, {stop}) out of range for {self.shape}")
-        inner = int(np.prod(self.shape[1:], dtype=np.int64))
+        inner = math.prod(self.shape[1:])
         return DeviceArray._view(self, self.ptr + start * inner * 4, (stop - start,) + self.shape[1:])
 
     def reshape(self, *shape):
-        shape = shape[0] if len(shape) == 1 and not np.isscalar(shape[0]) else shape
+        shape = shape[0] if len(shape) == 1 and not isinstance(shape[0], (int, np.integer)) else shape
         shape = tuple(int(s) for s in shape)
         if shape.count(-1) == 1:
-            known = int(np.prod([s for s in shape if s != -1], dtype=np.int64))
+            known = math.prod(s for s in shape if s != -1)
             shape = tuple(self.size // max(known, 1) if s == -1 else s for s in shape)
-        if int(np.prod(shape, dtype=np.int64)) != self.size:
+        if math.prod(shape) != self.size:
             raise ValueError("reshape: size mismatch")
         return DeviceArray._view(self, self.ptr, shape)
 

@@ -1,5 +1,7 @@
 """Shape-checked Python wrappers over the C ABI (include/gmmvi_hip.h).  Every wrapper validates operand shapes on
 the host before the launch, so a kernel never sees a grid/operand mismatch."""
+import math
+
 import numpy as np
 
 from . import _lib
@@ -258,7 +260,7 @@ def gather_rows(ctx, src, idx):
     n = idx.shape[0]
     _req(idx, (n,), I32, "idx")
     inner = src.shape[1:]
-    words = int(np.prod(inner, dtype=np.int64)) if inner else 1
+    words = math.prod(inner) if inner else 1
     dst = ctx.empty((n,) + tuple(inner), src.dtype)
     if n > 0:
         ctx.check(ctx.lib.gmmvi_gather_rows(ctx.handle, src.ptr, idx.ptr, n, words, dst.ptr))
