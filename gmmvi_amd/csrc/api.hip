@@ -1,5 +1,6 @@
 // Context, error, memory and event entry points of the C ABI (include/gmmvi_hip.h).
 #include "common.h"
+#include "blocked.h"
 
 std::string g_gmmvi_global_err;
 
@@ -342,6 +343,7 @@ int gmmvi_profile_report(gmmvi_ctx* ctx, char* buf, size_t buf_size) {
 }
 
 size_t gmmvi_packed_stride(int D) {
+    if (gmmvi_is_blocked_dim(D)) return gmmvi_blocked_stride(D);
     int dp = gmmvi_padded_dim(D);
     return dp < 0 ? 0 : gmmvi_packed_stride_dp(dp);
 }

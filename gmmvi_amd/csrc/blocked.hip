@@ -1,0 +1,975 @@
+// Blocked path for 64 < D <= 512 (blocked.h): densities, sampling, Stein estimate and the KL-constrained update with the
+// O(D^2)-per-pair work expressed as batched fp32 contractions on the matrix cores and the O(D^3)-per-component
+// factorisations as one-workgroup-per-component kernels on L2-resident matrices.
+//
+// Reference arithmetic: models/full_cov_gmm.py:56-62 (z = L^-1 (x - mu) -- here Z = (X - mu) L^-T with the explicit
+// inverse the reference also keeps for its sample database, optimization/sample_db.py:121), models/gmm.py:183-216,274-300,
+// :361-386, gmmvi_modules/ng_estimator.py:146-263, gmmvi_modules/ng_based_component_updater.py:244-524.
+#include "blocked.h"
+#include "wave_reduce.h"
+#include <cfloat>
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// batched contraction  C[b] (+)= alpha * opA(A[b]) * opB(B[b]) (+ bias)   on v_mfma_f32_32x32x2_f32
+// ---------------------------------------------------------------------------------------------------------------------------
+// Workgroup = 128 x 128 tile of C, 4 waves in 2 x 2, each wave 2 x 2 MFMA tiles (64 accumulator registers); the k dimension
+// advances 16 at a time through two LDS images per operand, stored k-major ([k][row], row stride 130 words: the lanes of a
+// ds_read_b32 walk consecutive rows, and the transposing writes of a k-contiguous source land on 32 distinct banks).
+// Global loads of step s+1 are in flight while step s is multiplied.  Operands may be k-contiguous or k-major in memory;
+// the A operand takes an element-wise prologue (subtract a vector along k, scale along k, scale along rows), which is how
+// "x - mu", the importance weights and the responsibilities enter without being materialised.
+struct BG {
+    const float* A; const float* B; float* C;
+    int M, N, Kd;
+    int lda, ldb, ldc;
+    long long sA, sB, sC;            // batch strides (floats)
+    int a_kmajor;                    // 0: A[m * lda + k]      1: A[k * lda + m]
+    int b_kmajor;                    // 0: B[n * ldb + k]      1: B[k * ldb + n]
+    const float* a_sub; long long s_asub;        // [Kd]  A(m, k) -= a_sub[k]
+    const float* a_kscale; long long s_aks;      // [Kd]  A(m, k) *= a_kscale[k]
+    const float* a_rscale; long long s_ars;      // [M]   A(m, k) *= a_rscale[m]
+    const float* c_bias; long long s_cb;         // [N]   C(m, n) += c_bias[n]
+    const int32_t* row_off;          // optional [batches + 1]: batch b owns rows [row_off[b], row_off[b+1]) of A and C (M = bound)
+    int inner;                       // > 0: this many consecutive batches are accumulated into ONE C (grid.z = 1)
+    int tri;                         // 1: opB(k, n) = 0 for k > n   2: opB(k, n) = 0 for k < n   (k range clipped per column tile)
+    int accumulate;                  // C += result
+    float alpha;
+};
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 130;
+
+__global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
+    __shared__ float As[2][BK * LDT];
+    __shared__ float Bs[2][BK * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int bz = blockIdx.z;
+    int Mb = g.M;
+    long long rowbase = 0;
+    if (g.row_off) { rowbase = g.row_off[bz]; Mb = g.row_off[bz + 1] - (int)rowbase; }
+    if (m0 >= Mb) return;
+    int kb = 0, ke = g.Kd;
+    if (g.tri == 1) ke = min(g.Kd, n0 + BN);
+    else if (g.tri == 2) kb = min(g.Kd, n0);
+    const int spb = (ke - kb + BK - 1) / BK;
+    const int nb = g.inner > 0 ? g.inner : 1;
+    const int total = nb * spb;
+
+    float ra[8], rb[8];
+    auto gload = [&](int step) {
+        const int bi = step / spb;
+        const long long b = (long long)bz * nb + bi;
+        const int k0 = kb + (step - bi * spb) * BK;
+        const float* Ab = g.A + b * g.sA + (g.a_kmajor ? rowbase : rowbase * g.lda);
+        const float* Bb = g.B + b * g.sB;
+        const float* sub = g.a_sub ? g.a_sub + b * g.s_asub : nullptr;
+        const float* ks = g.a_kscale ? g.a_kscale + b * g.s_aks : nullptr;
+        const float* rs = g.a_rscale ? g.a_rscale + b * g.s_ars : nullptr;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = tid + 256 * u;
+            int r, kk;
+            if (g.a_kmajor) { kk = idx >> 7; r = idx & 127; } else { r = idx >> 4; kk = idx & 15; }
+            const int gm = m0 + r, gk = k0 + kk;
+            float v = 0.f;
+            if (gm < Mb && gk < ke) {
+                v = g.a_kmajor ? Ab[(long long)gk * g.lda + gm] : Ab[(long long)gm * g.lda + gk];
+                if (sub) v -= sub[gk];
+                if (ks) v *= ks[gk];
+                if (rs) v *= rs[gm];
+            }
+            ra[u] = v;
+            int c, k2;
+            if (g.b_kmajor) { k2 = idx >> 7; c = idx & 127; } else { c = idx >> 4; k2 = idx & 15; }
+            const int gn = n0 + c, gk2 = k0 + k2;
+            float w = 0.f;
+            if (gn < g.N && gk2 < ke) w = g.b_kmajor ? Bb[(long long)gk2 * g.ldb + gn] : Bb[(long long)gn * g.ldb + gk2];
+            rb[u] = w;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = tid + 256 * u;
+            int r, kk;
+            if (g.a_kmajor) { kk = idx >> 7; r = idx & 127; } else { r = idx >> 4; kk = idx & 15; }
+            As[buf][kk * LDT + r] = ra[u];
+            int c, k2;
+            if (g.b_kmajor) { k2 = idx >> 7; c = idx & 127; } else { c = idx >> 4; k2 = idx & 15; }
+            Bs[buf][k2 * LDT + c] = rb[u];
+        }
+    };
+    f32x16 acc00, acc01, acc10, acc11;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+
+    if (total > 0) {
+        gload(0);
+        sstore(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int step = 0; step < total; ++step) {
+        if (step + 1 < total) gload(step + 1);
+        const float* a_ = As[buf] + half * LDT + wm * 64 + col;
+        const float* b_ = Bs[buf] + half * LDT + wn * 64 + col;
+#pragma unroll
+        for (int k2 = 0; k2 < BK / 2; ++k2) {
+            const float a0 = a_[2 * k2 * LDT], a1 = a_[2 * k2 * LDT + 32];
+            const float b0 = b_[2 * k2 * LDT], b1 = b_[2 * k2 * LDT + 32];
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        }
+        if (step + 1 < total) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* Cb = g.C + (g.inner > 0 ? 0 : (long long)bz * g.sC) + rowbase * g.ldc;
+    const float* bias = g.c_bias ? g.c_bias + (long long)bz * g.s_cb : nullptr;
+    auto emit = [&](const f32x16& acc, int ti, int tj) {
+        const int j = n0 + wn * 64 + tj * 32 + col;
+        if (j >= g.N) return;
+        const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = m0 + wm * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (i < Mb) {
+                float* p = Cb + (long long)i * g.ldc + j;
+                float v = fmaf(g.alpha, acc[r], bj);
+                if (g.accumulate) v += *p;
+                *p = v;
+            }
+        }
+    };
+    emit(acc00, 0, 0); emit(acc01, 0, 1); emit(acc10, 1, 0); emit(acc11, 1, 1);
+}
+
+BG bg_zero() {
+    BG g;
+    memset(&g, 0, sizeof(g));
+    g.alpha = 1.f;
+    return g;
+}
+
+int bgemm(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
+    if (g.M <= 0 || g.N <= 0 || batches_outer <= 0) return GMMVI_OK;
+    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batches_outer);
+    hipLaunchKernelGGL(bgemm_kernel, grid, dim3(256), 0, ctx->stream, g);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red) {          // red: >= 16 floats of LDS; result block-uniform
+    v = gmmvi_wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = gmmvi_wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = -3.0e38f;
+    for (int i = 0; i < nw; ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+
+// Forward substitution T x = r with a lower-triangular T (row-major, row stride D), one thread per right-hand side:
+// thread t solves for rhs(i, t), i = 0..D-1, knowing that its solution vanishes for i < i0.  The solution goes to
+// X[i * ldx + t] (coalesced over t; the thread re-reads its own column).  Row i of T is staged in LDS for every step.
+template <class RhsF>
+__device__ void blk_trsm(int D, const float* __restrict__ T, int nrhs, RhsF rhs, int i0, float* X, int ldx, float* Trow) {
+    const int t = threadIdx.x;
+    for (int i = 0; i < D; ++i) {
+        __syncthreads();
+        for (int c = t; c <= i; c += blockDim.x) Trow[c] = T[(size_t)i * D + c];
+        __syncthreads();
+        if (t < nrhs) {
+            float v = 0.f;
+            if (i >= i0) {
+                float s0 = rhs(i, t), s1 = 0.f, s2 = 0.f, s3 = 0.f;
+                int c = i0;
+                for (; c + 3 < i; c += 4) {
+                    s0 = fmaf(-Trow[c], X[(size_t)c * ldx + t], s0);
+                    s1 = fmaf(-Trow[c + 1], X[(size_t)(c + 1) * ldx + t], s1);
+                    s2 = fmaf(-Trow[c + 2], X[(size_t)(c + 2) * ldx + t], s2);
+                    s3 = fmaf(-Trow[c + 3], X[(size_t)(c + 3) * ldx + t], s3);
+                }
+                for (; c < i; ++c) s0 = fmaf(-Trow[c], X[(size_t)c * ldx + t], s0);
+                v = ((s0 + s1) + (s2 + s3)) / Trow[i];
+            }
+            X[(size_t)i * ldx + t] = v;
+        }
+    }
+    __syncthreads();
+}
+
+// Cholesky factorisation A = C C^T of the symmetric matrix a(i, j) (i >= j read), left-looking, one thread per row;
+// the factor is built column-major (W[c * D + i] = C[i][c]: thread i walks coalesced rows of W).  Returns false (block-uniform)
+// on a non-positive or non-finite pivot.
+template <class ElemF>
+__device__ bool blk_cholesky(int D, ElemF a, float* W, float* piv) {
+    const int i = threadIdx.x;
+    for (int j = 0; j < D; ++j) {
+        float s = 0.f;
+        if (i >= j && i < D) {
+            float s0 = a(i, j), s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int c = 0;
+            for (; c + 3 < j; c += 4) {
+                s0 = fmaf(-W[(size_t)c * D + i], W[(size_t)c * D + j], s0);
+                s1 = fmaf(-W[(size_t)(c + 1) * D + i], W[(size_t)(c + 1) * D + j], s1);
+                s2 = fmaf(-W[(size_t)(c + 2) * D + i], W[(size_t)(c + 2) * D + j], s2);
+                s3 = fmaf(-W[(size_t)(c + 3) * D + i], W[(size_t)(c + 3) * D + j], s3);
+            }
+            for (; c < j; ++c) s0 = fmaf(-W[(size_t)c * D + i], W[(size_t)c * D + j], s0);
+            s = (s0 + s1) + (s2 + s3);
+        }
+        if (i == j) *piv = s;
+        __syncthreads();
+        const float p = *piv;
+        if (!(p > 0.f) || !(p < FLT_MAX)) return false;
+        const float d = sqrtf(p);
+        if (i >= j && i < D) W[(size_t)j * D + i] = (i == j) ? d : s / d;
+        __syncthreads();
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// component blocks: [mu | const | pad | L^-1]
+// ---------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void blk_pack_kernel(int family, float nu, int D, const float* __restrict__ means,
+                                                       const float* __restrict__ chols, float* __restrict__ packed,
+                                                       size_t ps, int lo, float* __restrict__ inv_out) {
+    __shared__ float Trow[GMMVI_BLOCKED_MAX_DIM];
+    __shared__ float red[16];
+    const int k = blockIdx.x, t = threadIdx.x;
+    const float* L = chols + (size_t)k * D * D;
+    float* out = packed + (size_t)k * ps;
+    float* Linv = out + lo;
+    if (t < D) out[t] = means[(size_t)k * D + t];
+    const float s = block_sum(t < D ? logf(L[(size_t)t * D + t]) : 0.f, red);
+    if (t == 0) {
+        out[D] = (family == GMMVI_GAUSS)
+                     ? -s - 0.5f * D * 1.8378770664093453f
+                     : lgammaf(0.5f * (nu + D)) - lgammaf(0.5f * nu) - 0.5f * D * logf(nu * 3.14159265358979f) - s;
+        for (int i = D + 1; i < lo; ++i) out[i] = 0.f;
+    }
+    blk_trsm(D, L, D, [](int i, int tt) { return i == tt ? 1.f : 0.f; }, t, Linv, D, Trow);
+    if (inv_out != nullptr) {
+        float* o = inv_out + (size_t)k * D * D;
+        for (int e = t; e < D * D; e += blockDim.x) o[e] = Linv[e];
+    }
+}
+
+__global__ __launch_bounds__(512) void blk_cholesky_kernel(int D, const float* __restrict__ covs, float* __restrict__ W,
+                                                           float* __restrict__ chols, int32_t* __restrict__ ok) {
+    __shared__ float piv;
+    const int k = blockIdx.x, t = threadIdx.x;
+    const float* A = covs + (size_t)k * D * D;
+    float* Wk = W + (size_t)k * D * D;
+    const bool good = blk_cholesky(D, [A, D](int i, int j) { return A[(size_t)i * D + j]; }, Wk, &piv);
+    __syncthreads();
+    float* o = chols + (size_t)k * D * D;
+    for (int e = t; e < D * D; e += blockDim.x) {
+        const int i = e / D, j = e % D;
+        o[e] = good ? (j <= i ? Wk[(size_t)j * D + i] : 0.f) : __builtin_nanf("");
+    }
+    if (t == 0 && ok) ok[k] = good ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// densities
+// ---------------------------------------------------------------------------------------------------------------------------
+// q[row] = |z_row|^2 and the component log-density; 16 lanes per row of Z
+__global__ __launch_bounds__(256) void blk_rowsq_kernel(int family, float nu, int D, int N, long long rows,
+                                                        const float* __restrict__ Z, int ldz, const float* __restrict__ packed,
+                                                        size_t ps, float* __restrict__ q, float* __restrict__ ld) {
+    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    float s = 0.f;
+    if (row < rows) {
+        const float* z = Z + row * ldz;
+        if (((ldz | D) & 3) == 0) {
+            for (int i = sub; i < D / 4; i += 16) {
+                const float4 v = reinterpret_cast<const float4*>(z)[i];
+                s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
+            }
+        } else {
+            for (int i = sub; i < D; i += 16) s = fmaf(z[i], z[i], s);
+        }
+    }
+    s += gmmvi_dpp<0xB1>(s);
+    s += gmmvi_dpp<0x4E>(s);
+    s += gmmvi_dpp<0x141>(s);
+    s += gmmvi_dpp<0x140>(s);
+    if (row < rows && sub == 0) {
+        const int kb = (int)(row / N);
+        const float c = packed[(size_t)kb * ps + D];
+        if (q) q[row] = s;
+        if (ld) ld[row] = (family == GMMVI_GAUSS) ? fmaf(-0.5f, s, c) : c - 0.5f * (nu + D) * log1pf(s / nu);
+    }
+}
+
+__global__ __launch_bounds__(256) void blk_lse_kernel(int K, int N, const float* __restrict__ ld, const float* __restrict__ logw,
+                                                      const float* __restrict__ logw2, float* __restrict__ lp,
+                                                      float* __restrict__ lp2) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float m = -3.0e38f, s = 0.f, m2 = -3.0e38f, s2 = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float v = ld[(size_t)k * N + n];
+        const float a = v + logw[k];
+        const float mn = fmaxf(m, a);
+        s = fmaf(s, __expf(m - mn), __expf(a - mn));
+        m = mn;
+        if (logw2) {
+            const float a2 = v + logw2[k];
+            const float mn2 = fmaxf(m2, a2);
+            s2 = fmaf(s2, __expf(m2 - mn2), __expf(a2 - mn2));
+            m2 = mn2;
+        }
+    }
+    if (lp) lp[n] = m + __logf(s);
+    if (lp2 && logw2) lp2[n] = m2 + __logf(s2);
+}
+
+// responsibilities times the family's gradient coefficient: rw[kb][n] = exp(logw_k + ld[k][n] - lp[n]) * coef
+__global__ __launch_bounds__(256) void blk_resp_kernel(int family, float nu, int D, int N, int kn, const float* __restrict__ ld,
+                                                       const float* __restrict__ logw, const float* __restrict__ lp,
+                                                       const float* __restrict__ q, float* __restrict__ rw) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)kn * N) return;
+    const int kb = (int)(e / N), n = (int)(e % N);
+    const float r = __expf(logw[kb] + ld[e] - lp[n]);
+    const float coef = (family == GMMVI_GAUSS) ? -1.f : -(nu + (float)D) / (nu + q[e]);
+    rw[e] = r * coef;
+}
+
+__global__ void blk_mapping_kernel(int K, const int32_t* __restrict__ offsets, int32_t* __restrict__ mapping) {
+    const int k = blockIdx.x;
+    const int begin = offsets[k], end = offsets[k + 1];
+    for (int n = begin + blockIdx.y * blockDim.x + threadIdx.x; n < end; n += gridDim.y * blockDim.x) mapping[n] = k;
+}
+
+size_t z_budget_floats() {
+    // scratch budget for the whitened samples of a component chunk (default 4 GiB); read per call so tests can shrink it
+    const char* e = getenv("GMMVI_BLOCKED_ZBYTES");
+    return e ? (size_t)atoll(e) / 4 : ((size_t)4 << 30) / 4;
+}
+
+// Z[kb][n][0:D] = (x_n - mu_k) L_k^-T for the components k0 .. k0 + kn - 1 (row stride ldz)
+int blk_forward(gmmvi_ctx* ctx, int D, const float* packed, int k0, int kn, const float* X, int N, float* Z, int ldz) {
+    const size_t ps = gmmvi_blocked_stride(D);
+    BG g = bg_zero();
+    g.A = X; g.lda = D; g.sA = 0; g.a_kmajor = 0;
+    g.a_sub = packed + (size_t)k0 * ps; g.s_asub = (long long)ps;
+    g.B = packed + (size_t)k0 * ps + gmmvi_blocked_linv_ofs(D); g.ldb = D; g.sB = (long long)ps; g.b_kmajor = 0;
+    g.C = Z; g.ldc = ldz; g.sC = (long long)N * ldz;
+    g.M = N; g.N = D; g.Kd = D; g.tri = 1;
+    GMMVI_PROF(ctx, "blocked_forward");
+    return bgemm(ctx, g, kn);
+}
+
+}  // namespace
+
+#define BLK_TRY(call) do { int rc__ = (call); if (rc__ != GMMVI_OK) return rc__; } while (0)
+
+static int blk_threads(int D) { return ((D + 63) / 64) * 64; }
+
+int gmmvi_blocked_pack(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* means, const float* chols,
+                       float* packed, float* inv_chols) {
+    GMMVI_PROF(ctx, "blocked_pack");
+    hipLaunchKernelGGL(blk_pack_kernel, dim3(K), dim3(blk_threads(D)), 0, ctx->stream, family, nu, D, means, chols, packed,
+                       gmmvi_blocked_stride(D), gmmvi_blocked_linv_ofs(D), inv_chols);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+int gmmvi_blocked_cholesky(gmmvi_ctx* ctx, int K, int D, const float* covs, float* chols, int32_t* ok) {
+    BLK_TRY(gmmvi_ws_reserve(ctx, (size_t)K * D * D * sizeof(float)));
+    hipLaunchKernelGGL(blk_cholesky_kernel, dim3(K), dim3(blk_threads(D)), 0, ctx->stream, D, covs, (float*)ctx->ws, chols, ok);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed, const float* logw,
+                               const float* logw2, const float* X, int N, float* ld_out, float* lp, float* grad, float* lp2) {
+    const size_t ps = gmmvi_blocked_stride(D);
+    const bool need_lse = lp || grad || lp2;
+    const size_t zrow = (size_t)N * D;
+    size_t kc = z_budget_floats() / zrow;
+    const int Kc = (int)(kc < 1 ? 1 : (kc > (size_t)K ? (size_t)K : kc));
+    const int nchunks = (K + Kc - 1) / Kc;
+    const size_t f_z = (size_t)Kc * zrow, f_q = (size_t)Kc * N, f_rw = grad ? (size_t)Kc * N : 0;
+    const size_t f_ld = (!ld_out && need_lse) ? (size_t)K * N : 0, f_lp = (grad && !lp) ? (size_t)N : 0;
+    BLK_TRY(gmmvi_ws_reserve(ctx, (f_z + f_q + f_rw + f_ld + f_lp) * sizeof(float)));
+    float* Z = (float*)ctx->ws;
+    float* q = Z + f_z;
+    float* rw = q + f_q;
+    float* ldp = ld_out ? ld_out : (f_ld ? rw + f_rw : nullptr);
+    float* lpp = lp ? lp : (f_lp ? rw + f_rw + f_ld : nullptr);
+    auto rowsq = [&](int k0, int kn, bool write_ld) {
+        const long long rows = (long long)kn * N;
+        GMMVI_PROF(ctx, "blocked_rowsq");
+        hipLaunchKernelGGL(blk_rowsq_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, ctx->stream, family, nu, D,
+                           N, rows, Z, D, packed + (size_t)k0 * ps, ps, q, (write_ld && ldp) ? ldp + (size_t)k0 * N : nullptr);
+    };
+    for (int c = 0; c < nchunks; ++c) {
+        const int k0 = c * Kc, kn = (K - k0 < Kc) ? K - k0 : Kc;
+        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, D));
+        rowsq(k0, kn, true);
+        GMMVI_LAUNCH_CHECK(ctx);
+    }
+    if (need_lse) {
+        GMMVI_PROF(ctx, "blocked_lse");
+        hipLaunchKernelGGL(blk_lse_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, K, N, ldp, logw, logw2, lpp, lp2);
+        GMMVI_LAUNCH_CHECK(ctx);
+    }
+    if (grad) {
+        for (int c = 0; c < nchunks; ++c) {
+            const int k0 = c * Kc, kn = (K - k0 < Kc) ? K - k0 : Kc;
+            if (nchunks > 1) {
+                BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, D));
+                rowsq(k0, kn, false);
+                GMMVI_LAUNCH_CHECK(ctx);
+            }
+            const long long tot = (long long)kn * N;
+            hipLaunchKernelGGL(blk_resp_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, family, nu, D, N,
+                               kn, ldp + (size_t)k0 * N, logw + k0, lpp, q, rw);
+            GMMVI_LAUNCH_CHECK(ctx);
+            BG g = bg_zero();
+            g.A = Z; g.lda = D; g.sA = (long long)zrow; g.a_kmajor = 0;
+            g.a_rscale = rw; g.s_ars = N;
+            g.B = packed + (size_t)k0 * ps + gmmvi_blocked_linv_ofs(D); g.ldb = D; g.sB = (long long)ps; g.b_kmajor = 1;
+            g.C = grad; g.ldc = D;
+            g.M = N; g.N = D; g.Kd = D; g.tri = 2; g.inner = kn; g.accumulate = c > 0;
+            GMMVI_PROF(ctx, "blocked_grad");
+            BLK_TRY(bgemm(ctx, g, 1));
+        }
+    }
+    return GMMVI_OK;
+}
+
+int gmmvi_blocked_sample(gmmvi_ctx* ctx, int K, int D, const float* means, const float* chols, const int32_t* offsets, int N,
+                         int max_per_component, uint64_t seed, uint64_t first_index, int stream_id, const float* eps,
+                         float* X_out, int32_t* mapping_out) {
+    if (N == 0) return GMMVI_OK;
+    if (eps == nullptr) {
+        BLK_TRY(gmmvi_ws_reserve(ctx, (size_t)N * D * sizeof(float)));
+        BLK_TRY(gmmvi_philox_normals(ctx, seed, first_index, stream_id, N, D, (float*)ctx->ws));
+        eps = (const float*)ctx->ws;
+    }
+    const int bound = max_per_component < N ? max_per_component : N;
+    BG g = bg_zero();
+    g.A = eps; g.lda = D; g.sA = 0; g.a_kmajor = 0;
+    g.B = chols; g.ldb = D; g.sB = (long long)D * D; g.b_kmajor = 0;       // opB(k = m, n = i) = L[i][m]: zero for m > i
+    g.C = X_out; g.ldc = D; g.sC = 0;
+    g.c_bias = means; g.s_cb = D;
+    g.row_off = offsets;
+    g.M = bound; g.N = D; g.Kd = D; g.tri = 1;
+    {
+        GMMVI_PROF(ctx, "blocked_sample");
+        BLK_TRY(bgemm(ctx, g, K));
+    }
+    if (mapping_out) {
+        int by = (bound + 255) / 256;
+        if (by < 1) by = 1;
+        if (by > 64) by = 64;
+        hipLaunchKernelGGL(blk_mapping_kernel, dim3(K, by), dim3(256), 0, ctx->stream, K, offsets, mapping_out);
+        GMMVI_LAUNCH_CHECK(ctx);
+    }
+    return GMMVI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Stein estimate (gmmvi_modules/ng_estimator.py:146-263): A_k = sum_n e_kn [g_n; 1] [z_kn; 1]^T as one contraction over the
+// samples per component, then H = sym(A[:D,:D] L^-1) / sum e  (y = L^-T z applied once per component, as in stein.hip)
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void blk_stein_g_kernel(int N, int D, const float* __restrict__ tgrad,
+                                                          const float* __restrict__ qgrad, float* __restrict__ G1) {
+    const int D1 = D + 1;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)N * D1) return;
+    const int n = (int)(e / D1), i = (int)(e % D1);
+    G1[e] = (i < D) ? tgrad[(size_t)n * D + i] - qgrad[(size_t)n * D + i] : 1.f;
+}
+
+__global__ __launch_bounds__(256) void blk_fill_col_kernel(long long rows, int ld, int colidx, float value, float* __restrict__ Z) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r < rows) Z[r * ld + colidx] = value;
+}
+
+// importance weights of one component over all samples, referred to their maximum: e[kb][n] = exp(a_n - M), Mk[kb] = M
+__global__ __launch_bounds__(1024) void blk_stein_weights_kernel(int N, int k0, const float* __restrict__ ld,
+                                                                 const float* __restrict__ bg, const int32_t* __restrict__ mapping,
+                                                                 int map_offset, int flags, float* __restrict__ e,
+                                                                 float* __restrict__ Mk) {
+    __shared__ float red[16];
+    const int kb = blockIdx.x, k = k0 + kb;
+    const bool own_only = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
+    float m = -3.0e38f;
+    for (int n = threadIdx.x; n < N; n += 1024) {
+        const float a = own_only ? ((mapping[n] + map_offset == k) ? 0.f : -3.0e38f) : ld[(size_t)k * N + n] - bg[n];
+        m = fmaxf(m, a);
+    }
+    const float M = block_max(m, red);
+    for (int n = threadIdx.x; n < N; n += 1024) {
+        const float a = own_only ? ((mapping[n] + map_offset == k) ? 0.f : -3.0e38f) : ld[(size_t)k * N + n] - bg[n];
+        e[(size_t)kb * N + n] = (a > -1.0e38f) ? __expf(a - M) : 0.f;
+    }
+    if (threadIdx.x == 0) Mk[kb] = M;
+}
+
+__global__ __launch_bounds__(256) void blk_stein_finalize_kernel(int D, int N, int flags, const float* __restrict__ Araw,
+                                                                 const float* __restrict__ T, const float* __restrict__ Mk,
+                                                                 float* __restrict__ H_neg, float* __restrict__ g_neg) {
+    const int kb = blockIdx.x, D1 = D + 1;
+    const float* A = Araw + (size_t)kb * D1 * D1;
+    const float* Tk = T + (size_t)kb * D * D;
+    const bool snis = (flags & GMMVI_SELF_NORMALIZED) != 0;
+    const float scale = snis ? 1.f / A[(size_t)D * D1 + D] : __expf(Mk[kb]) / (float)N;
+    for (int e = threadIdx.x; e < D * D; e += 256) {
+        const int i = e / D, j = e % D;
+        const float v = snis ? 0.5f * (Tk[e] + Tk[(size_t)j * D + i]) : Tk[e];
+        H_neg[(size_t)kb * D * D + e] = -v * scale;
+    }
+    for (int i = threadIdx.x; i < D; i += 256) g_neg[(size_t)kb * D + i] = -A[(size_t)i * D1 + D] * scale;
+}
+
+}  // namespace
+
+int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
+                        const float* qgrad, const float* bg, const float* tgrad, const int32_t* mapping, int map_offset,
+                        int flags, float* H_neg, float* g_neg) {
+    const int D1 = D + 1;
+    const size_t ps = gmmvi_blocked_stride(D);
+    const size_t zrow = (size_t)N * D1;
+    size_t kc = z_budget_floats() / zrow;
+    const int Kc = (int)(kc < 1 ? 1 : (kc > (size_t)K ? (size_t)K : kc));
+    const size_t f_z = (size_t)Kc * zrow, f_g = zrow, f_e = (size_t)Kc * N, f_m = ((size_t)Kc + 3) / 4 * 4;
+    const size_t f_a = (size_t)Kc * D1 * D1, f_t = (size_t)Kc * D * D;
+    BLK_TRY(gmmvi_ws_reserve(ctx, (f_z + f_g + f_e + f_m + f_a + f_t) * sizeof(float)));
+    float* Z = (float*)ctx->ws;
+    float* G1 = Z + f_z;
+    float* e = G1 + f_g;
+    float* Mk = e + f_e;
+    float* Araw = Mk + f_m;
+    float* T = Araw + f_a;
+    hipLaunchKernelGGL(blk_stein_g_kernel, dim3((unsigned)((zrow + 255) / 256)), dim3(256), 0, ctx->stream, N, D, tgrad, qgrad, G1);
+    GMMVI_LAUNCH_CHECK(ctx);
+    for (int k0 = 0; k0 < K; k0 += Kc) {
+        const int kn = (K - k0 < Kc) ? K - k0 : Kc;
+        const long long rows = (long long)kn * N;
+        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, D1));
+        hipLaunchKernelGGL(blk_fill_col_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, rows, D1, D, 1.f, Z);
+        hipLaunchKernelGGL(blk_stein_weights_kernel, dim3(kn), dim3(1024), 0, ctx->stream, N, k0, ld, bg, mapping, map_offset,
+                           flags, e, Mk);
+        GMMVI_LAUNCH_CHECK(ctx);
+        {
+            BG g = bg_zero();
+            g.A = G1; g.lda = D1; g.sA = 0; g.a_kmajor = 1;             // opA(m = a, k = n) = G1[n][a]
+            g.a_kscale = e; g.s_aks = N;
+            g.B = Z; g.ldb = D1; g.sB = (long long)zrow; g.b_kmajor = 1;  // opB(k = n, n = b) = Z1[n][b]
+            g.C = Araw; g.ldc = D1; g.sC = (long long)D1 * D1;
+            g.M = D1; g.N = D1; g.Kd = N;
+            GMMVI_PROF(ctx, "blocked_stein_accumulate");
+            BLK_TRY(bgemm(ctx, g, kn));
+        }
+        {
+            BG g = bg_zero();
+            g.A = Araw; g.lda = D1; g.sA = (long long)D1 * D1; g.a_kmajor = 0;
+            g.B = packed + (size_t)k0 * ps + gmmvi_blocked_linv_ofs(D); g.ldb = D; g.sB = (long long)ps; g.b_kmajor = 1;
+            g.C = T; g.ldc = D; g.sC = (long long)D * D;
+            g.M = D; g.N = D; g.Kd = D; g.tri = 2;
+            GMMVI_PROF(ctx, "blocked_stein_unwhiten");
+            BLK_TRY(bgemm(ctx, g, kn));
+        }
+        hipLaunchKernelGGL(blk_stein_finalize_kernel, dim3(kn), dim3(256), 0, ctx->stream, D, N, flags, Araw, T, Mk,
+                           H_neg + (size_t)k0 * D * D, g_neg + (size_t)k0 * D);
+        GMMVI_LAUNCH_CHECK(ctx);
+    }
+    return GMMVI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// KL-constrained component update (ng_based_component_updater.py:431-524): the whitened / tridiagonal route of update_kl.hip
+// with the D x D matrices in global memory (L2-resident), one workgroup per component and step.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// R_sym (lower triangle mirrored, as tf.linalg.cholesky reads it) and g~ = g_neg + (R_sym - R) mu
+__global__ __launch_bounds__(256) void blk_upd_prep_kernel(int D, const float* __restrict__ H_neg, const float* __restrict__ g_neg,
+                                                           const float* __restrict__ means, float* __restrict__ Rs,
+                                                           float* __restrict__ gt) {
+    const int k = blockIdx.x;
+    const float* R = H_neg + (size_t)k * D * D;
+    const float* mu = means + (size_t)k * D;
+    float* o = Rs + (size_t)k * D * D;
+    for (int e = threadIdx.x; e < D * D; e += 256) {
+        const int i = e / D, j = e % D;
+        o[e] = (j <= i) ? R[e] : R[(size_t)j * D + i];
+    }
+    for (int t = threadIdx.x; t < D; t += 256) {
+        float g = g_neg[(size_t)k * D + t];
+        for (int j = t + 1; j < D; ++j) g = fmaf(R[(size_t)j * D + t] - R[(size_t)t * D + j], mu[j], g);
+        gt[(size_t)k * D + t] = g;
+    }
+}
+
+// M <- (M + M^T)/2, copy to Mc; w = L^T g~ (also the vector the reflectors act on)
+__global__ __launch_bounds__(256) void blk_upd_sym_kernel(int D, const float* __restrict__ chols, const float* __restrict__ gt,
+                                                          float* __restrict__ M, float* __restrict__ Mc, float* __restrict__ w,
+                                                          float* __restrict__ wt) {
+    const int k = blockIdx.x;
+    float* Mk = M + (size_t)k * D * D;
+    float* Ck = Mc + (size_t)k * D * D;
+    const float* L = chols + (size_t)k * D * D;
+    for (int e = threadIdx.x; e < D * D; e += 256) {
+        const int i = e / D, j = e % D;
+        if (j < i) {
+            const float m = 0.5f * (Mk[e] + Mk[(size_t)j * D + i]);
+            Mk[e] = m; Mk[(size_t)j * D + i] = m;
+            Ck[e] = m; Ck[(size_t)j * D + i] = m;
+        } else if (j == i) {
+            Ck[e] = Mk[e];
+        }
+    }
+    for (int t = threadIdx.x; t < D; t += 256) {
+        float a = 0.f;
+        for (int c = t; c < D; ++c) a = fmaf(L[(size_t)c * D + t], gt[(size_t)k * D + c], a);
+        w[(size_t)k * D + t] = a;
+        wt[(size_t)k * D + t] = a;
+    }
+}
+
+// Householder tridiagonalisation of the symmetric M (in place) with the reflectors applied to wt.  Thread (i, grp): column
+// i of the trailing block, rows j = c+1+grp, +G, ... (coalesced over i); partial products meet in LDS.
+__global__ __launch_bounds__(1024) void blk_tridiag_kernel(int D, int DT, int G, float* __restrict__ Mall,
+                                                           float* __restrict__ wt_all, float* __restrict__ td_all,
+                                                           float* __restrict__ te_all) {
+    extern __shared__ float sm[];
+    float* v = sm;
+    float* q = sm + D;
+    float* part = q + D;
+    float* red = part + (size_t)G * DT;
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const int i = tid % DT, grp = tid / DT;
+    float* M = Mall + (size_t)k * D * D;
+    float* te = te_all + (size_t)k * D;
+    float wti = (grp == 0 && i < D) ? wt_all[(size_t)k * D + i] : 0.f;
+    for (int c = 0; c + 2 < D; ++c) {
+        const float x1 = M[(size_t)c * D + c + 1];
+        const bool mine = grp == 0 && i > c && i < D;
+        const float xi = mine ? M[(size_t)c * D + i] : 0.f;
+        const float tail = block_sum((mine && i > c + 1) ? xi * xi : 0.f, red);
+        if (!(tail > 0.f)) {                       // column already tridiagonal (NaN lands here too: handled by the search)
+            if (tid == 0) te[c] = x1;
+            continue;
+        }
+        const float nrm = sqrtf(tail + x1 * x1);
+        const float alpha = (x1 > 0.f) ? -nrm : nrm;
+        const float beta = 1.f / (nrm * nrm - alpha * x1);
+        const float vi = mine ? (i == c + 1 ? x1 - alpha : xi) : 0.f;
+        if (grp == 0 && i < D) v[i] = vi;
+        __syncthreads();
+        float a0 = 0.f, a1 = 0.f;
+        if (i > c && i < D) {
+            int j = c + 1 + grp;
+            for (; j + G < D; j += 2 * G) {
+                a0 = fmaf(M[(size_t)j * D + i], v[j], a0);
+                a1 = fmaf(M[(size_t)(j + G) * D + i], v[j + G], a1);
+            }
+            if (j < D) a0 = fmaf(M[(size_t)j * D + i], v[j], a0);
+        }
+        part[grp * DT + i] = a0 + a1;
+        __syncthreads();
+        float p = 0.f;
+        if (mine) {
+            for (int gi = 0; gi < G; ++gi) p += part[gi * DT + i];
+            p *= beta;
+        }
+        const float kk = 0.5f * beta * block_sum(vi * p, red);
+        const float wdot = beta * block_sum(vi * wti, red);
+        if (grp == 0 && i < D) q[i] = mine ? p - kk * vi : 0.f;
+        wti -= wdot * vi;
+        __syncthreads();
+        if (i > c && i < D) {
+            const float vi2 = v[i], qi2 = q[i];
+            for (int j = c + 1 + grp; j < D; j += G)
+                M[(size_t)j * D + i] -= __fadd_rn(__fmul_rn(v[j], qi2), __fmul_rn(q[j], vi2));
+        }
+        if (tid == 0) te[c] = alpha;
+        __syncthreads();
+    }
+    if (grp == 0 && i < D) {
+        td_all[(size_t)k * D + i] = M[(size_t)i * D + i];
+        wt_all[(size_t)k * D + i] = wti;
+        if (i == D - 1 && D >= 2) te[D - 2] = M[(size_t)(D - 1) * D + D - 2];
+    }
+}
+
+// KL(eta) from the tridiagonal form (update_kl.hip kl_tridiag), pivots kept in a global scratch column per lane
+__device__ __forceinline__ float blk_kl_tridiag(int D, const float* td, const float* te, const float* wt, float* scratch,
+                                                float eta) {
+    const int lane = threadIdx.x;
+    const float inv = 1.f / eta;
+    float* dcol = scratch + lane;
+    float dprev = 1.f, cprev = 0.f, logdet = 0.f;
+    bool ok = true;
+    for (int i = 0; i < D; ++i) {
+        const float a = fmaf(td[i], inv, 1.f);
+        float d = a, c = wt[i];
+        if (i > 0) {
+            const float b = te[i - 1] * inv;
+            const float r = b / dprev;
+            d = fmaf(-b, r, a);
+            c = fmaf(-r, cprev, c);
+        }
+        ok = ok && (d > 0.f);
+        logdet += __logf(d);
+        dcol[(size_t)i * 64] = d;
+        dcol[(size_t)(D + i) * 64] = c;
+        dprev = d; cprev = c;
+    }
+    float dnext = 1.f, ynext = 0.f, tr = 0.f, yy = 0.f;
+    for (int i = D - 1; i >= 0; --i) {
+        const float a = fmaf(td[i], inv, 1.f);
+        const float d = dcol[(size_t)i * 64], c = dcol[(size_t)(D + i) * 64];
+        float delta = a, y = c / d;
+        if (i < D - 1) {
+            const float b = te[i] * inv;
+            delta = fmaf(-b, b / dnext, a);
+            y = (c - b * ynext) / d;
+        }
+        tr += 1.f / (d + delta - a);
+        yy = fmaf(y, y, yy);
+        dnext = delta; ynext = y;
+    }
+    float kl = 0.5f * (logdet - (float)D + tr + yy * inv * inv);
+    if (!ok || !(kl == kl)) kl = FLT_MAX;
+    return kl;
+}
+
+// bracketing search (:335-429) on the tridiagonal form, 63 nodes of the bisection tree per round (update_kl.hip);
+// state[k] = (eta*, success, KL(eta*), probes)
+__global__ __launch_bounds__(64) void blk_search_kernel(int D, const float* __restrict__ td_all, const float* __restrict__ te_all,
+                                                        const float* __restrict__ wt_all, const float* __restrict__ stepsizes,
+                                                        const float* __restrict__ last_eta, float temperature,
+                                                        float* __restrict__ scratch_all, float* __restrict__ state) {
+    extern __shared__ float sm[];
+    float* td = sm;
+    float* te = sm + D;
+    float* wt = sm + 2 * D;
+    const int k = blockIdx.x, t = threadIdx.x;
+    for (int i = t; i < D; i += 64) {
+        td[i] = td_all[(size_t)k * D + i];
+        te[i] = te_all[(size_t)k * D + i];
+        wt[i] = wt_all[(size_t)k * D + i];
+    }
+    __syncthreads();
+    float* scratch = scratch_all + (size_t)k * 2 * D * 64;
+    const float eps = stepsizes[k];
+    const float last = last_eta[k];
+    float lb, ub;
+    if (last < 0.f) { lb = -20.f; ub = 80.f; }
+    else { lb = fmaxf(0.f, __logf(last) - 3.f); ub = __logf(last) + 3.f; }
+    bool ub_ok = false, done = false;
+    int probes = 0, iters = 0;
+    float kl_ub = -1.f;
+    while (!done && iters < 1000) {
+        float nlb = lb, nub = ub;
+        if (t >= 2) {
+            const int depth = 31 - __clz(t);
+            for (int b = depth - 1; b >= 0; --b) {
+                const float mid = 0.5f * (nub + nlb);
+                if ((t >> b) & 1) nlb = mid; else nub = mid;
+            }
+        }
+        const float neta = 0.5f * (nub + nlb);
+        const float e_eta = expf(neta);
+        const float ndiff = fminf(expf(nub) - e_eta, e_eta - expf(nlb));
+        const float nkl = (t >= 1) ? blk_kl_tridiag(D, td, te, wt, scratch, e_eta) : 0.f;
+        int n = 1;
+        for (int level = 0; level < 6 && !done && iters < 1000; ++level, ++iters) {
+            const float diff = __shfl(ndiff, n), klv = __shfl(nkl, n), eta = __shfl(neta, n);
+            if (diff < 1e-1f) { done = true; break; }
+            ++probes;
+            if (fabsf(eps - klv) < 1e-1f * eps) { lb = ub = eta; kl_ub = klv; done = true; break; }
+            if (eps > klv) { ub = eta; ub_ok = true; kl_ub = klv; n = 2 * n; }
+            else { lb = eta; n = 2 * n + 1; }
+        }
+    }
+    if (ub_ok) lb = ub;
+    const float lo = expf(lb), hi = expf(ub);
+    const float eta_star = fmaxf(lo, temperature);
+    bool success = (lo == hi);
+    float kl_val = -1.f;
+    if (success) {
+        kl_val = (eta_star == lo && kl_ub >= 0.f) ? kl_ub : __shfl(blk_kl_tridiag(D, td, te, wt, scratch, eta_star), 0);
+        success = kl_val < FLT_MAX;
+    }
+    if (t == 0) {
+        state[4 * k] = eta_star;
+        state[4 * k + 1] = success ? 1.f : 0.f;
+        state[4 * k + 2] = kl_val;
+        state[4 * k + 3] = (float)probes;
+    }
+}
+
+// B = I + Mc/eta* = U U^T through the Cholesky factor C of the index-reversed matrix (U = J C J); L' = L U^-T and
+// z = U^-1 w by forward substitution with C on the reversed rows of L (one thread per row, thread D: w);
+// mu' = mu - L' z / eta*.  Commits means / chols on success and does the bookkeeping of :518-524.
+__global__ __launch_bounds__(576) void blk_upd_final_kernel(int D, const float* __restrict__ Mc_all, const float* __restrict__ w_all,
+                                                            float* __restrict__ W_all, float* __restrict__ Cr_all,
+                                                            float* __restrict__ X_all, const float* __restrict__ state,
+                                                            float* __restrict__ means, float* __restrict__ chols,
+                                                            float l2_init, float* __restrict__ last_eta, float* __restrict__ l2,
+                                                            float* __restrict__ num_updates, int32_t* __restrict__ success_out,
+                                                            float* __restrict__ kl_out, int32_t* __restrict__ nprobes_out) {
+    __shared__ float Trow[GMMVI_BLOCKED_MAX_DIM];
+    __shared__ float piv;
+    __shared__ int anybad;
+    const int k = blockIdx.x, t = threadIdx.x;
+    const float eta_star = state[4 * k];
+    bool success = state[4 * k + 1] != 0.f;
+    const float kl_val = state[4 * k + 2];
+    const float inv = 1.f / eta_star;
+    float* L = chols + (size_t)k * D * D;
+    float* mu = means + (size_t)k * D;
+    if (success) {
+        const float* Mc = Mc_all + (size_t)k * D * D;
+        float* W = W_all + (size_t)k * D * D;
+        success = blk_cholesky(D, [Mc, D, inv](int i, int j) {
+            return (i == j ? 1.f : 0.f) + Mc[(size_t)(D - 1 - i) * D + (D - 1 - j)] * inv; }, W, &piv);
+        __syncthreads();
+        if (success) {
+            float* Cr = Cr_all + (size_t)k * D * D;
+            for (int e = t; e < D * D; e += blockDim.x) {
+                const int c = e / D, i = e % D;                     // W[c][i] = C[i][c]
+                if (c <= i) Cr[(size_t)i * D + c] = W[e];
+            }
+            __syncthreads();
+            const float* w = w_all + (size_t)k * D;
+            float* X = X_all + (size_t)k * D * (D + 1);
+            const int ldx = D + 1;
+            blk_trsm(D, Cr, D + 1,
+                     [L, w, D](int i, int tt) { return tt < D ? L[(size_t)tt * D + (D - 1 - i)] : w[D - 1 - i]; },
+                     t < D ? D - 1 - t : 0, X, ldx, Trow);
+            if (t == 0) anybad = 0;
+            __syncthreads();
+            float new_mu = 0.f;
+            if (t < D) {
+                float acc = 0.f;
+                bool bad = false;
+                for (int i = 0; i < D; ++i) {
+                    const float x = X[(size_t)i * ldx + t];
+                    acc = fmaf(x, X[(size_t)i * ldx + D], acc);
+                    bad |= !(x == x);
+                }
+                bad |= !(X[(size_t)(D - 1 - t) * ldx + t] > 0.f);          // diagonal of L'
+                new_mu = mu[t] - acc * inv;
+                bad |= !(new_mu == new_mu);
+                if (bad) anybad = 1;
+            }
+            __syncthreads();
+            success = anybad == 0;                                                         // :493 is_nan(new_chol)
+            if (success) {
+                for (int e = t; e < D * D; e += blockDim.x) {
+                    const int r = e / D, c = e % D;
+                    L[e] = (c <= r) ? X[(size_t)(D - 1 - c) * ldx + r] : 0.f;
+                }
+                if (t < D) mu[t] = new_mu;
+            }
+        }
+    }
+    if (t == 0) {
+        last_eta[k] = success ? eta_star : -1.f;
+        if (kl_out) kl_out[k] = success ? kl_val : -1.f;
+        if (nprobes_out) nprobes_out[k] = (int32_t)state[4 * k + 3];
+        const float old = l2[k];
+        l2[k] = success ? fmaxf(0.5f * old, l2_init) : fminf(1e-6f, 10.f * old);
+        num_updates[k] += 1.f;
+        if (success_out) success_out[k] = success ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* chols, const float* H_neg, const float* g_neg,
+                            const float* stepsizes, float temperature, float l2_init, float* last_eta, float* l2,
+                            float* num_updates, int32_t* success_out, float* kl_out, int32_t* nprobes_out, float* packed_out) {
+    const size_t DD = (size_t)D * D;
+    const size_t f_mat = (size_t)K * DD;
+    const size_t f_x = (size_t)K * D * (D + 1), f_vec = (size_t)K * D, f_scr = (size_t)K * 2 * D * 64, f_state = (size_t)K * 4;
+    BLK_TRY(gmmvi_ws_reserve(ctx, (4 * f_mat + f_x + 5 * f_vec + f_scr + f_state) * sizeof(float)));
+    float* Rs = (float*)ctx->ws;          // R_sym, later the row-major Cholesky factor
+    float* T1 = Rs + f_mat;               // R_sym L, later the column-major Cholesky factor
+    float* M = T1 + f_mat;                // L^T R L, tridiagonalised in place
+    float* Mc = M + f_mat;                // copy of M for the final factorisation
+    float* Xs = Mc + f_mat;
+    float* gt = Xs + f_x;
+    float* w = gt + f_vec;
+    float* wt = w + f_vec;
+    float* td = wt + f_vec;
+    float* te = td + f_vec;
+    float* scratch = te + f_vec;
+    float* state = scratch + f_scr;
+    GMMVI_PROF(ctx, "blocked_update_kl");
+    hipLaunchKernelGGL(blk_upd_prep_kernel, dim3(K), dim3(256), 0, ctx->stream, D, H_neg, g_neg, means, Rs, gt);
+    GMMVI_LAUNCH_CHECK(ctx);
+    {
+        BG g = bg_zero();
+        g.A = Rs; g.lda = D; g.sA = (long long)DD; g.a_kmajor = 0;
+        g.B = chols; g.ldb = D; g.sB = (long long)DD; g.b_kmajor = 1; g.tri = 2;      // opB(k = c, n = j) = L[c][j], zero for c < j
+        g.C = T1; g.ldc = D; g.sC = (long long)DD;
+        g.M = D; g.N = D; g.Kd = D;
+        BLK_TRY(bgemm(ctx, g, K));
+    }
+    {
+        BG g = bg_zero();
+        g.A = chols; g.lda = D; g.sA = (long long)DD; g.a_kmajor = 1;                 // opA(m = i, k = c) = L[c][i]
+        g.B = T1; g.ldb = D; g.sB = (long long)DD; g.b_kmajor = 1;
+        g.C = M; g.ldc = D; g.sC = (long long)DD;
+        g.M = D; g.N = D; g.Kd = D;
+        BLK_TRY(bgemm(ctx, g, K));
+    }
+    hipLaunchKernelGGL(blk_upd_sym_kernel, dim3(K), dim3(256), 0, ctx->stream, D, chols, gt, M, Mc, w, wt);
+    GMMVI_LAUNCH_CHECK(ctx);
+    {
+        const int DT = blk_threads(D);
+        int G = 1024 / DT;
+        if (G < 1) G = 1;
+        const size_t shmem = ((size_t)2 * D + (size_t)G * DT + 32) * sizeof(float);
+        hipLaunchKernelGGL(blk_tridiag_kernel, dim3(K), dim3(G * DT), shmem, ctx->stream, D, DT, G, M, wt, td, te);
+        GMMVI_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(blk_search_kernel, dim3(K), dim3(64), (size_t)3 * D * sizeof(float), ctx->stream, D, td, te, wt, stepsizes,
+                       last_eta, temperature, scratch, state);
+    GMMVI_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(blk_upd_final_kernel, dim3(K), dim3(blk_threads(D + 1)), 0, ctx->stream, D, Mc, w, T1, Rs, Xs, state, means,
+                       chols, l2_init, last_eta, l2, num_updates, success_out, kl_out, nprobes_out);
+    GMMVI_LAUNCH_CHECK(ctx);
+    if (packed_out) BLK_TRY(gmmvi_blocked_pack(ctx, GMMVI_GAUSS, 0.f, K, D, means, chols, packed_out, nullptr));
+    return GMMVI_OK;
+}

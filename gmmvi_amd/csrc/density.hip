@@ -8,6 +8,7 @@
 // through LDS.
 #include "common.h"
 #include "subst.h"
+#include "blocked.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -333,10 +334,11 @@ extern "C" {
 
 int gmmvi_pack_components(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* means_dev,
                           const float* chols_dev, float* packed_dev, float* inv_chols_dev) {
-    GMMVI_ARG_CHECK(ctx, K >= 0 && D >= 1 && D <= GMMVI_MAX_DIM);
+    GMMVI_ARG_CHECK(ctx, K >= 0 && D >= 1 && D <= GMMVI_BLOCKED_MAX_DIM);
     GMMVI_ARG_CHECK(ctx, family == GMMVI_GAUSS || family == GMMVI_STUDENT_T);
     if (K == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && packed_dev);
+    if (gmmvi_is_blocked_dim(D)) return gmmvi_blocked_pack(ctx, family, nu, K, D, means_dev, chols_dev, packed_dev, inv_chols_dev);
     int dp = gmmvi_padded_dim(D);
     GMMVI_PROF(ctx, "pack_components");
     GMMVI_DISPATCH_DP(dp, hipLaunchKernelGGL((pack_kernel<DP>), dim3(K), dim3(64), 0, ctx->stream, family, nu, K, D,
@@ -346,9 +348,10 @@ int gmmvi_pack_components(gmmvi_ctx* ctx, int family, float nu, int K, int D, co
 }
 
 int gmmvi_cholesky(gmmvi_ctx* ctx, int K, int D, const float* covs_dev, float* chols_dev, int32_t* ok_dev) {
-    GMMVI_ARG_CHECK(ctx, K >= 0 && D >= 1 && D <= GMMVI_MAX_DIM);
+    GMMVI_ARG_CHECK(ctx, K >= 0 && D >= 1 && D <= GMMVI_BLOCKED_MAX_DIM);
     if (K == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, covs_dev && chols_dev);
+    if (gmmvi_is_blocked_dim(D)) return gmmvi_blocked_cholesky(ctx, K, D, covs_dev, chols_dev, ok_dev);
     hipLaunchKernelGGL(cholesky_kernel, dim3(K), dim3(64), (size_t)D * (D + 1) * 4, ctx->stream, D, covs_dev,
                        chols_dev, ok_dev);
     GMMVI_LAUNCH_CHECK(ctx);
@@ -358,11 +361,14 @@ int gmmvi_cholesky(gmmvi_ctx* ctx, int K, int D, const float* covs_dev, float* c
 int gmmvi_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed_dev,
                        const float* logw_dev, const float* X_dev, int N, float* ld_out_dev, float* lp_out_dev,
                        float* grad_out_dev) {
-    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM && N >= 0);
+    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_BLOCKED_MAX_DIM && N >= 0);
     GMMVI_ARG_CHECK(ctx, family == GMMVI_GAUSS || family == GMMVI_STUDENT_T);
     if (N == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, packed_dev && logw_dev && X_dev);
     GMMVI_ARG_CHECK(ctx, ld_out_dev || lp_out_dev || grad_out_dev);
+    if (gmmvi_is_blocked_dim(D))
+        return gmmvi_blocked_mixture_eval(ctx, family, nu, K, D, packed_dev, logw_dev, nullptr, X_dev, N, ld_out_dev, lp_out_dev,
+                                          grad_out_dev, nullptr);
     int dp = gmmvi_padded_dim(D);
     GMMVI_DISPATCH_DP(dp, return launch_mixture_eval<DP>(ctx, family, nu, K, D, packed_dev, logw_dev, X_dev, N,
                                                          ld_out_dev, lp_out_dev, grad_out_dev));
@@ -372,10 +378,13 @@ int gmmvi_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const
 int gmmvi_mixture_eval_dual(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed_dev,
                             const float* logw_dev, const float* logw2_dev, const float* X_dev, int N, float* ld_out_dev,
                             float* lp_out_dev, float* grad_out_dev, float* lp2_out_dev) {
-    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM && N >= 0);
+    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_BLOCKED_MAX_DIM && N >= 0);
     GMMVI_ARG_CHECK(ctx, family == GMMVI_GAUSS || family == GMMVI_STUDENT_T);
     if (N == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, packed_dev && logw_dev && logw2_dev && X_dev && lp_out_dev && lp2_out_dev);
+    if (gmmvi_is_blocked_dim(D))
+        return gmmvi_blocked_mixture_eval(ctx, family, nu, K, D, packed_dev, logw_dev, logw2_dev, X_dev, N, ld_out_dev,
+                                          lp_out_dev, grad_out_dev, lp2_out_dev);
     int dp = gmmvi_padded_dim(D);
     GMMVI_DISPATCH_DP(dp, return launch_mixture_eval<DP>(ctx, family, nu, K, D, packed_dev, logw_dev, X_dev, N,
                                                          ld_out_dev, lp_out_dev, grad_out_dev, logw2_dev, lp2_out_dev));

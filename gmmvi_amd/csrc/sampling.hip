@@ -5,6 +5,7 @@
 #include "common.h"
 #include "philox.h"
 #include "iter_prep.h"
+#include "blocked.h"
 
 // grid = (component, 256-sample chunk of that component); (mu_k, L_k) staged in LDS and read as broadcasts, eps and x in
 // registers (DP = padded dimension, loops unrolled), the output tile leaves through LDS with coalesced stores.
@@ -98,9 +99,14 @@ static int launch_sample(gmmvi_ctx* ctx, int K, int D, const float* means_dev, c
                          const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed, uint64_t first_index,
                          int stream_id, const float* eps_dev, float* X_out_dev, int32_t* mapping_out_dev, int32_t mapping_base,
                          const PrepArgs* prep) {
-    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM && N >= 0 && max_per_component >= 0);
+    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_BLOCKED_MAX_DIM && N >= 0 && max_per_component >= 0);
     if (N == 0 && !prep) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && offsets_dev && X_out_dev);
+    if (gmmvi_is_blocked_dim(D)) {
+        GMMVI_ARG_CHECK(ctx, prep == nullptr && mapping_base == 0);
+        return gmmvi_blocked_sample(ctx, K, D, means_dev, chols_dev, offsets_dev, N, max_per_component, seed, first_index,
+                                    stream_id, eps_dev, X_out_dev, mapping_out_dev);
+    }
     GMMVI_PROF(ctx, "sample_components");
     const int bound = max_per_component < N ? max_per_component : N;
     const int chunks = (bound + 255) / 256 > 0 ? (bound + 255) / 256 : 1;

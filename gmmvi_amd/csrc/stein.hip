@@ -17,6 +17,7 @@
 //     the four waves merged through LDS per component (own maximum per wave, fixed summation order).
 // stein_finalize sums the slab in fixed order (bitwise reproducible), normalises, symmetrises and negates.
 #include "common.h"
+#include "blocked.h"
 #include "wave_reduce.h"
 #include "subst_asm_gen.h"
 #include <cstdlib>
@@ -598,10 +599,13 @@ extern "C" int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev
                            const float* ld_dev, const float* qgrad_dev, const float* bg_dev, const float* tgrad_dev,
                            const int32_t* mapping_dev, int map_offset, int flags, float* H_neg_out_dev,
                            float* g_neg_out_dev) {
-    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D < GMMVI_MAX_DIM && N >= 1);
+    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && (D < GMMVI_MAX_DIM || gmmvi_is_blocked_dim(D)) && N >= 1);
     GMMVI_ARG_CHECK(ctx, packed_dev && X_dev && qgrad_dev && tgrad_dev && H_neg_out_dev && g_neg_out_dev);
     if (flags & GMMVI_OWN_SAMPLES_ONLY) GMMVI_ARG_CHECK(ctx, mapping_dev != nullptr);
     else GMMVI_ARG_CHECK(ctx, ld_dev && bg_dev);
+    if (gmmvi_is_blocked_dim(D))
+        return gmmvi_blocked_stein(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev, mapping_dev,
+                                   map_offset, flags, H_neg_out_dev, g_neg_out_dev);
     const int dp = gmmvi_padded_dim(D);
     const bool two = (D + 1) > 32;
     // D <= 24: wave-per-component kernel (GMMVI_STEIN_TILED=1 selects the tiled kernel with its cross-wave merge)

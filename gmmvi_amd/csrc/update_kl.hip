@@ -13,6 +13,7 @@
 // "Cholesky failed" (non-positive pivot / NaN) maps to KL = float32.max and to the reject branch (:320-324, :493).
 // One wavefront per component, matrices in LDS (row stride D+1), lane = row (D <= 64).
 #include "common.h"
+#include "blocked.h"
 #include "wave_reduce.h"
 #include <cfloat>
 
@@ -552,9 +553,13 @@ extern "C" int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* m
                                           float temperature, float l2_init, float* last_eta_dev, float* l2_dev,
                                           float* num_received_updates_dev, int32_t* success_out_dev, float* kl_out_dev,
                                           int32_t* n_probes_out_dev, float* packed_out_dev) {
-    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM);
+    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_BLOCKED_MAX_DIM);
     GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && H_neg_dev && g_neg_dev && stepsizes_dev && last_eta_dev && l2_dev &&
                              num_received_updates_dev);
+    if (gmmvi_is_blocked_dim(D))
+        return gmmvi_blocked_update_kl(ctx, K, D, means_dev, chols_dev, H_neg_dev, g_neg_dev, stepsizes_dev, temperature, l2_init,
+                                       last_eta_dev, l2_dev, num_received_updates_dev, success_out_dev, kl_out_dev,
+                                       n_probes_out_dev, packed_out_dev);
     size_t shmem = lds_bytes(D);
     GMMVI_PROF(ctx, "update_kl");
 #define GMMVI_UKL(DCV)                                                                                             \

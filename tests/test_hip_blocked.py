@@ -1,0 +1,202 @@
+"""GPU parity of the blocked path (64 < D <= 512: config C5, D = 300) against the fp64 oracle: same entry points, the
+per-pair work on the matrix cores (csrc/blocked.hip).  Tolerances as in test_hip_kernels.py; the quadratic forms sum D
+terms in fp32, so absolute errors of log-densities scale with D (stated per assertion)."""
+import os
+
+import numpy as np
+import pytest
+from scipy.special import logsumexp
+
+from oracle import philox, gmm as ogmm, targets as otargets, stein as ostein, updaters as oupd
+from test_hip_kernels import random_gmm, upload_model, _stein_inputs, _update_inputs, ops
+from test_hip_train_iter import run_pair
+from helpers import samtron_config
+
+pytestmark = pytest.mark.gpu
+
+DIMS = [(3, 72, 300), (2, 130, 257), (4, 300, 200), (1, 65, 10), (2, 512, 140)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from gmmvi_amd.device import get_context
+    return get_context()
+
+
+@pytest.mark.parametrize("k,d,n", DIMS)
+def test_blocked_pack_cholesky(ctx, rng, k, d, n):
+    m = random_gmm(rng, k, d)
+    _, means, chols = upload_model(ctx, m)
+    packed, inv = ops().pack_components(ctx, means, chols, want_inverse=True)
+    ref = np.linalg.inv(m.chol_cov)
+    np.testing.assert_allclose(inv.numpy(), ref, rtol=2e-4, atol=2e-5 * np.abs(ref).max())
+    p = packed.numpy()
+    np.testing.assert_allclose(p[:, :d], m.means, rtol=1e-6)
+    const = -np.log(np.diagonal(m.chol_cov, axis1=1, axis2=2)).sum(axis=1) - 0.5 * d * np.log(2 * np.pi)
+    np.testing.assert_allclose(p[:, d], const, rtol=1e-5)
+    ch, ok = ops().cholesky(ctx, ctx.asarray(m.covs))
+    assert ok.numpy().all()
+    np.testing.assert_allclose(ch.numpy(), m.chol_cov, rtol=2e-4, atol=2e-5)
+    bad = m.covs.copy(); bad[0] = -np.eye(d)
+    ch, ok = ops().cholesky(ctx, ctx.asarray(bad))
+    assert ok.numpy()[0] == 0 and np.isnan(ch.numpy()[0]).all() and ok.numpy()[1:].all()
+
+
+@pytest.mark.parametrize("k,d,n", DIMS)
+def test_blocked_mixture_eval(ctx, rng, k, d, n):
+    m = random_gmm(rng, k, d)
+    x = m.means[rng.integers(0, k, n)] + rng.normal(size=(n, d)) * 1.5
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    xd = ctx.asarray(x)
+    ld, lp, grad = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_lp=True, want_grad=True)
+    lq, g, cld = m.log_density_and_grad(x.astype(np.float32).astype(np.float64))
+    # |z|^2 is O(D..100 D) here and carries fp32 relative error ~1e-6 per term: atol scales with the magnitude
+    atol = 2e-6 * np.abs(cld).max() + 2e-4
+    np.testing.assert_allclose(ld.numpy(), cld, rtol=1e-4, atol=atol)
+    np.testing.assert_allclose(lp.numpy(), lq, rtol=1e-4, atol=atol)
+    np.testing.assert_allclose(grad.numpy(), g, rtol=1e-3, atol=1e-3 * np.abs(g).max())
+    _, lp2, _ = ops().mixture_eval(ctx, packed, logw, xd, d)
+    np.testing.assert_allclose(lp2.numpy(), lp.numpy(), rtol=1e-6, atol=1e-6)
+    # dual sweep
+    counts = rng.integers(1, 50, k).astype(np.float64)
+    logc = ctx.asarray(np.log(counts / counts.sum()))
+    ld3, lp3, grad3, bg = ops().mixture_eval_dual(ctx, packed, logw, logc, xd, d)
+    np.testing.assert_allclose(ld3.numpy(), ld.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(grad3.numpy(), grad.numpy(), rtol=1e-5, atol=1e-5)
+    ref = logsumexp(cld + np.log(counts / counts.sum())[:, None], axis=0)
+    np.testing.assert_allclose(bg.numpy(), ref, rtol=1e-4, atol=atol)
+
+
+def test_blocked_mixture_eval_component_chunks(ctx, rng):
+    """The component-chunked route (Z of all components does not fit the scratch budget) gives the same results."""
+    k, d, n = 5, 96, 150
+    m = random_gmm(rng, k, d)
+    x = m.means[rng.integers(0, k, n)] + rng.normal(size=(n, d)) * 1.5
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    xd = ctx.asarray(x)
+    ld, lp, grad = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_lp=True, want_grad=True)
+    os.environ["GMMVI_BLOCKED_ZBYTES"] = str(2 * n * d * 4)          # two components per chunk
+    try:
+        ld2, lp2, grad2 = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_lp=True, want_grad=True)
+        _, lp3, grad3 = ops().mixture_eval(ctx, packed, logw, xd, d, want_grad=True)
+    finally:
+        del os.environ["GMMVI_BLOCKED_ZBYTES"]
+    np.testing.assert_array_equal(ld2.numpy(), ld.numpy())
+    np.testing.assert_array_equal(lp2.numpy(), lp.numpy())
+    np.testing.assert_allclose(grad2.numpy(), grad.numpy(), rtol=1e-5, atol=1e-5 * np.abs(grad.numpy()).max())
+    np.testing.assert_array_equal(lp3.numpy(), lp.numpy())
+    np.testing.assert_allclose(grad3.numpy(), grad.numpy(), rtol=1e-5, atol=1e-5 * np.abs(grad.numpy()).max())
+
+
+def test_blocked_student_t_target(ctx, rng):
+    d, n = 80, 300
+    t = otargets.make_stm_target(d, rng)
+    x = t.means[rng.integers(0, t.means.shape[0], n)] + rng.normal(size=(n, d)) * 2
+    from gmmvi_amd import _lib
+    packed, _ = ops().pack_components(ctx, ctx.asarray(t.means), ctx.asarray(t.chols), family=_lib.STUDENT_T, nu=2.0)
+    _, lp, grad = ops().mixture_eval(ctx, packed, ctx.asarray(t.log_weights), ctx.asarray(x), d, family=_lib.STUDENT_T,
+                                     nu=2.0, want_grad=True)
+    rlp, rg = t.log_density_and_grad(x.astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(lp.numpy(), rlp, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(grad.numpy(), rg, rtol=2e-3, atol=2e-3 * np.abs(rg).max())
+
+
+@pytest.mark.parametrize("k,d,n", DIMS[:4])
+def test_blocked_sample_components(ctx, rng, k, d, n):
+    m = random_gmm(rng, k, d)
+    n_k = rng.multinomial(n, np.ones(k) / k)
+    offs = np.concatenate([[0], np.cumsum(n_k)]).astype(np.int32)
+    _, means, chols = upload_model(ctx, m)
+    eps = philox.normals(3, 100, n, d)
+    x, mp = ops().sample_components(ctx, means, chols, ctx.asarray(offs, np.int32), n, eps=ctx.asarray(eps))
+    rx, rmp = m.sample_from_components_no_shuffle(n_k, eps.astype(np.float32).astype(np.float64))
+    np.testing.assert_array_equal(mp.numpy(), rmp)
+    np.testing.assert_allclose(x.numpy(), rx, rtol=1e-5, atol=2e-5)
+    x2, _ = ops().sample_components(ctx, means, chols, ctx.asarray(offs, np.int32), n, seed=3, first_index=100)
+    np.testing.assert_allclose(x2.numpy(), rx, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k,d,n", [(3, 72, 600), (2, 300, 900), (4, 130, 257)])
+@pytest.mark.parametrize("snis", [True, False])
+def test_blocked_stein(ctx, rng, k, d, n, snis):
+    m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    xd = ctx.asarray(x)
+    ld, lp, qg = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_grad=True)
+    h, g = ops().stein(ctx, packed, xd, ld, qg, ctx.asarray(bg), ctx.asarray(tg), d, self_normalized=snis)
+    rh, rg = ostein.get_expected_hessian_and_grad(m, x, mapping, bg, tlp, tg, False, snis)
+    scale_h = np.abs(rh).max(axis=(1, 2), keepdims=True)
+    scale_g = np.abs(rg).max(axis=1, keepdims=True)
+    # the weights exp(ld - bg) amplify the fp32 error of ld, which grows with D (see test_blocked_mixture_eval)
+    assert np.all(np.abs(h.numpy() - rh) <= 1e-2 * scale_h + 1e-6)
+    assert np.all(np.abs(g.numpy() - rg) <= 1e-2 * scale_g + 1e-6)
+
+
+def test_blocked_stein_own_samples(ctx, rng):
+    k, d, n = 3, 70, 500
+    m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    xd = ctx.asarray(x)
+    ld, lp, qg = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_grad=True)
+    mp = mapping + 7
+    h, g = ops().stein(ctx, packed, xd, ld, qg, ctx.asarray(bg), ctx.asarray(tg), d,
+                       mapping=ctx.asarray(mp, np.int32), map_offset=k - 1 - int(mp.max()), own_samples_only=True)
+    rh, rg = ostein.get_expected_hessian_and_grad(m, x, mp, bg, tlp, tg, True, True)
+    np.testing.assert_allclose(h.numpy(), rh, rtol=2e-3, atol=2e-3 * np.abs(rh).max())
+    np.testing.assert_allclose(g.numpy(), rg, rtol=2e-3, atol=2e-3 * np.abs(rg).max())
+
+
+@pytest.mark.parametrize("k,d", [(3, 72), (2, 300), (3, 129)])
+def test_blocked_update_components_kl(ctx, rng, k, d):
+    m, hs, gs = _update_inputs(rng, k, d)
+    m32 = ogmm.FullCovGMM(m.weights, m.means.astype(np.float32), m.covs.astype(np.float32))
+    w = ogmm.GmmWrapper(m32, 0.1, 1e-12, 4)
+    w.stepsizes = np.linspace(0.05, 0.5, k)
+    logw, means, chols = upload_model(ctx, m32)
+    last_eta = ctx.asarray(w.last_log_etas); l2 = ctx.asarray(w.l2_regularizers)
+    nupd = ctx.asarray(w.num_received_updates); steps = ctx.asarray(w.stepsizes)
+    for round_ in range(2):
+        succ, kl, probes, packed = ops().update_components_kl(ctx, means, chols, ctx.asarray(hs), ctx.asarray(gs), steps,
+                                                              1.0, 1e-12, last_eta, l2, nupd, want_info=True,
+                                                              want_packed=True)
+        rs, retas, rkls, rprobes = oupd.apply_ng_update_kl(w, hs, gs, w.stepsizes, 1.0, traces=[])
+        np.testing.assert_array_equal(succ.numpy().astype(bool), rs)
+        np.testing.assert_array_equal(probes.numpy(), rprobes)
+        np.testing.assert_allclose(last_eta.numpy(), retas, rtol=1e-5)
+        np.testing.assert_allclose(kl.numpy(), rkls, rtol=1e-2, atol=1e-5)
+        np.testing.assert_allclose(means.numpy(), m32.means, rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(chols.numpy(), m32.chol_cov, rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(l2.numpy(), w.l2_regularizers, rtol=1e-6)
+        np.testing.assert_allclose(nupd.numpy(), w.num_received_updates)
+        ref, _ = ops().pack_components(ctx, means, chols)
+        np.testing.assert_allclose(packed.numpy(), ref.numpy(), rtol=2e-6, atol=1e-6)
+
+
+def test_blocked_update_components_kl_failure(ctx, rng):
+    k, d = 3, 80
+    m, hs, gs = _update_inputs(rng, k, d)
+    hs[0] = np.nan
+    w = ogmm.GmmWrapper(m, 0.1, 1e-12, 4)
+    logw, means, chols = upload_model(ctx, m)
+    old_means, old_chols = means.numpy(), chols.numpy()
+    last_eta = ctx.asarray(w.last_log_etas); l2 = ctx.asarray(w.l2_regularizers); nupd = ctx.asarray(w.num_received_updates)
+    succ, kl, probes = ops().update_components_kl(ctx, means, chols, ctx.asarray(hs), ctx.asarray(gs),
+                                                  ctx.asarray(w.stepsizes), 1.0, 1e-12, last_eta, l2, nupd, want_info=True)
+    rs, retas, _, _ = oupd.apply_ng_update_kl(w, hs, gs, w.stepsizes, 1.0, traces=[])
+    np.testing.assert_array_equal(succ.numpy().astype(bool), rs)
+    assert not rs[0]
+    np.testing.assert_array_equal(means.numpy()[0], old_means[0])
+    np.testing.assert_array_equal(chols.numpy()[0], old_chols[0])
+    np.testing.assert_allclose(last_eta.numpy(), retas, rtol=1e-4)
+    np.testing.assert_allclose(l2.numpy(), w.l2_regularizers, rtol=1e-6)
+
+
+@pytest.mark.parametrize("kind,d,k,s", [("gmm", 72, 3, 60), ("gauss", 300, 2, 64)])
+def test_blocked_trajectory_matches_oracle(kind, d, k, s):
+    """GMMVI.train_iter() at D > 64 (modular plug-in path over the blocked kernels) against the oracle, same draws."""
+    cfg = samtron_config(s)
+    run_pair(kind, d, k, s, seed=11, iters=4, cfg=cfg, tol_scale=2.0)
