@@ -35,6 +35,10 @@ WORKLOADS = {
     "c3": ("gmm", 50, 100, 100),       # BASELINE configs[2]: GMM target D=50, K=100, N=10k
     "c4": ("planar", 10, 200, 100),    # BASELINE configs[3] on one GPU: planar-4, K=200, N=20k
     "ns_more": ("stm", 20, 100, 100, "MORE"),   # north-star shape with the MORE estimator ("ZAMTRON") instead of Stein
+    # BASELINE configs[4] per GPU: D=300 single-Gaussian target (make_target_with_scale, gmm.py:148-162), K=512 over 8 GPUs
+    # = 64 components per GPU, N = 20k samples/iter; blocked path (csrc/blocked.hip).  No CPU baseline: the oracle's
+    # [K,N,D] fp64 temporaries make one iteration take minutes ("C5 infeasible on CPU")
+    "c5": ("gauss300", 300, 64, 312),
     "tiny": ("stm", 4, 4, 16),         # host-overhead probe (kernels are empty; time = launch path)
 }
 
@@ -48,6 +52,10 @@ def kernel_flops(name, n, k, d):
         "stein_partial": p * (4 * d * d + 6 * d),         # recompute y (2D^2) + rank-1 accumulate (2D^2)
         # MORE: lower triangle of the (F+1)x(F+1) Gram matrix of [phi; reward], F = D(D+1)/2 + D + 1 (2 flop per MAC)
         "more_gram": p * ((d * (d + 1) // 2 + d + 2) * (d * (d + 1) // 2 + d + 3) + d * d),
+        # blocked path (D > 64): triangular whitening Z = (X - mu) L^-T, gradient sum_k r Z L^-1, Stein sum e [g;1][z;1]^T
+        "blocked_forward": p * (d * d + 2 * d),
+        "blocked_grad": p * (d * d + d),
+        "blocked_stein_accumulate": p * 2 * (d + 1) * (d + 1),
     }.get(name)
 
 
@@ -74,6 +82,10 @@ def build(workload, n_gpus, rank, seed=0):
         ot = otargets.make_gmm_target(d, rng)
         tgt = GMM_LNPDF(ot.weights, ot.means, ot.covs)
         prior_scale, initial_cov = 31.63, 1000.0                   # gmm20.yml:7-12
+    elif kind == "gauss300":
+        ot = otargets.make_gmm_target_with_scale(d, 1, 1.0, rng)
+        tgt = GMM_LNPDF(ot.weights, ot.means, ot.covs)
+        prior_scale, initial_cov = 100.0, 300.0                    # stm300.yml:9-14
     else:
         ot = otargets.PlanarRobotTarget(d, 4)
         tgt = PlanarRobot(d, 4)
@@ -208,7 +220,12 @@ def main():
     }
 
     # ---- CPU baseline + matched-ELBO check (rank 0, 1 GPU only) -------------------------------------------------
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and w["d"] > 64:
+        result["cpu_baseline"] = None
+        result["cpu_baseline_note"] = ("not timed: one fp64 NumPy iteration of this workload materialises several [K,N,D] "
+                                       "arrays (3 GB each) and takes minutes; parity at D = 300 is covered by "
+                                       "tests/test_hip_blocked.py on smaller K, N")
+    elif rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         try:
             from threadpoolctl import threadpool_info
             threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
