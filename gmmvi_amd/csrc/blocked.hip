@@ -17,12 +17,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------------------------------------------------------
 // batched contraction  C[b] (+)= alpha * opA(A[b]) * opB(B[b]) (+ bias)   on v_mfma_f32_32x32x2_f32
 // ---------------------------------------------------------------------------------------------------------------------------
-// Workgroup = 128 x 128 tile of C, 4 waves in 2 x 2, each wave 2 x 2 MFMA tiles (64 accumulator registers); the k dimension
-// advances 16 at a time through two LDS images per operand, stored k-major ([k][row], row stride 130 words: the lanes of a
-// ds_read_b32 walk consecutive rows, and the transposing writes of a k-contiguous source land on 32 distinct banks).
-// Global loads of step s+1 are in flight while step s is multiplied.  Operands may be k-contiguous or k-major in memory;
-// the A operand takes an element-wise prologue (subtract a vector along k, scale along k, scale along rows), which is how
-// "x - mu", the importance weights and the responsibilities enter without being materialised.
+// Workgroup = 128 x (32 NT) tile of C, 4 waves stacked along M: wave w owns rows 32 w .. 32 w + 31 and NT 32 x 32 MFMA
+// tiles (16 NT accumulator registers); NT in {2..5} is chosen per launch so that the padded width wastes the least
+// (D = 300: NT = 5, 320 columns).  The k dimension advances 16 at a time through two LDS images per operand, stored
+// k-major ([k][row]; row strides of 132 / 32 NT + 4 words keep 16-byte alignment for ds_write_b128 and let the lanes of a
+// ds_read_b32 walk consecutive rows).  Every thread moves 4 consecutive elements along the contiguous direction of its
+// operand (one 16-byte load when the operand is aligned), global loads of step s+1 are in flight while step s is
+// multiplied.  The f32 MFMA shares the vector ALU on gfx950 (it does not co-execute), so the staging code is kept to a
+// few vector instructions per 16-byte load: uniform base pointers + per-thread offsets fixed for the whole launch.
+// The A operand takes an element-wise prologue (subtract a vector along k, scale along k, scale along rows), which is how
+// "x - mu", the importance weights and the responsibilities enter without being materialised.  A triangular opB skips
+// the 32-column sub-tiles whose k range is structurally zero.
 struct BG {
     const float* A; const float* B; float* C;
     int M, N, Kd;
@@ -36,19 +41,38 @@ struct BG {
     const float* c_bias; long long s_cb;         // [N]   C(m, n) += c_bias[n]
     const int32_t* row_off;          // optional [batches + 1]: batch b owns rows [row_off[b], row_off[b+1]) of A and C (M = bound)
     int inner;                       // > 0: this many consecutive batches are accumulated into ONE C (grid.z = 1)
-    int tri;                         // 1: opB(k, n) = 0 for k > n   2: opB(k, n) = 0 for k < n   (k range clipped per column tile)
+    int tri;                         // 1: opB(k, n) = 0 for k > n   2: opB(k, n) = 0 for k < n
     int accumulate;                  // C += result
     float alpha;
 };
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 130;
+constexpr int BM = 128, BK = 16, LDA_S = BM + 4;
 
+// 4 consecutive floats, the first nvalid of them in range (others 0); one 16-byte load when allowed
+__device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
+    if (vec && nvalid >= 4) return *reinterpret_cast<const float4*>(p);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nvalid > 0) r.x = p[0];
+    if (nvalid > 1) r.y = p[1];
+    if (nvalid > 2) r.z = p[2];
+    if (nvalid > 3) r.w = p[3];
+    return r;
+}
+__device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// NT: 32-column MFMA tiles per wave; AK / BKM: operand is k-major in memory; PRO: prologue on A (0 none, 1 subtract a
+// vector along k, 2 scale rows, 3 scale along k).  Every step takes one of two routes, chosen uniformly: the fast route
+// (aligned operands, a full 16-wide k step, every 16-byte piece entirely valid or entirely void -- decided once per thread)
+// issues all loads back to back without a branch; the edge route handles ragged ends element by element.
+template <int NT, int AK, int BKM, int PRO>
 __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
-    __shared__ float As[2][BK * LDT];
-    __shared__ float Bs[2][BK * LDT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int BN = 32 * NT, LDB_S = BN + 4;
+    constexpr int NVB = (BN * BK / 4 + 255) / 256;          // 16-byte pieces of the B tile per thread
+    __shared__ __align__(16) float As[2][BK * LDA_S];
+    __shared__ __align__(16) float Bs[2][BK * LDB_S];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int bz = blockIdx.z;
     int Mb = g.M;
@@ -57,58 +81,145 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
     if (m0 >= Mb) return;
     int kb = 0, ke = g.Kd;
     if (g.tri == 1) ke = min(g.Kd, n0 + BN);
-    else if (g.tri == 2) kb = min(g.Kd, n0);
+    else if (g.tri == 2) kb = min(g.Kd, n0) & ~3;
     const int spb = (ke - kb + BK - 1) / BK;
     const int nb = g.inner > 0 ? g.inner : 1;
     const int total = nb * spb;
+    const float* A0 = g.A + (AK ? rowbase : rowbase * g.lda);
+    const float* pro = PRO == 1 ? g.a_sub : (PRO == 2 ? g.a_rscale : (PRO == 3 ? g.a_kscale : nullptr));
+    const long long s_pro = PRO == 1 ? g.s_asub : (PRO == 2 ? g.s_ars : (PRO == 3 ? g.s_aks : 0));
+    const bool vecA = al16(A0) && ((g.lda | g.sA) & 3) == 0;
+    const bool vecB = al16(g.B) && ((g.ldb | g.sB) & 3) == 0;
+    const bool vecP = PRO == 0 || (al16(pro) && (s_pro & 3) == 0);
+    // fast route: no 16-byte piece may straddle the end of its operand
+    const bool fast_ok = vecA && vecB && (PRO != 1 || vecP) && (!AK || (Mb & 3) == 0 || m0 + BM <= Mb) &&
+                         (!BKM || (g.N & 3) == 0 || n0 + BN <= g.N);
 
-    float ra[8], rb[8];
+    // per-thread pieces: A tile = 512 pieces (2 per thread), B tile = 4 BN pieces
+    // k-contiguous operand: piece = (row r, 4 consecutive k); k-major operand: piece = (k row, 4 consecutive rows)
+    int a_r[2], a_k[2], a_off[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = tid + 256 * u;
+        if (AK) { a_k[u] = idx >> 5; a_r[u] = 4 * (idx & 31); } else { a_r[u] = idx >> 2; a_k[u] = 4 * (idx & 3); }
+        a_ok[u] = m0 + a_r[u] < Mb;
+        a_off[u] = a_ok[u] ? (AK ? a_k[u] * g.lda + m0 + a_r[u] : (m0 + a_r[u]) * g.lda + a_k[u]) : 0;
+    }
+    int b_c[NVB], b_k[NVB], b_off[NVB];
+    bool b_ok[NVB];
+#pragma unroll
+    for (int u = 0; u < NVB; ++u) {
+        const int idx = tid + 256 * u;
+        if (BKM) { b_k[u] = idx / (BN / 4); b_c[u] = 4 * (idx % (BN / 4)); } else { b_c[u] = idx >> 2; b_k[u] = 4 * (idx & 3); }
+        if (idx >= BN * BK / 4) { b_c[u] = BN; b_k[u] = 0; }            // no piece
+        b_ok[u] = b_c[u] < BN && n0 + b_c[u] < g.N;
+        b_off[u] = b_ok[u] ? (BKM ? b_k[u] * g.ldb + n0 + b_c[u] : (n0 + b_c[u]) * g.ldb + b_k[u]) : 0;
+    }
+
+    float4 ra[2], rb[NVB];
     auto gload = [&](int step) {
         const int bi = step / spb;
         const long long b = (long long)bz * nb + bi;
         const int k0 = kb + (step - bi * spb) * BK;
-        const float* Ab = g.A + b * g.sA + (g.a_kmajor ? rowbase : rowbase * g.lda);
+        const float* Ab = A0 + b * g.sA;
         const float* Bb = g.B + b * g.sB;
-        const float* sub = g.a_sub ? g.a_sub + b * g.s_asub : nullptr;
-        const float* ks = g.a_kscale ? g.a_kscale + b * g.s_aks : nullptr;
-        const float* rs = g.a_rscale ? g.a_rscale + b * g.s_ars : nullptr;
+        const float* pb = PRO ? pro + b * s_pro : nullptr;
+        if (fast_ok && k0 + BK <= ke) {
+            const float* Ak = Ab + (AK ? (long long)k0 * g.lda : (long long)k0);
+            const float* Bk = Bb + (BKM ? (long long)k0 * g.ldb : (long long)k0);
+            float4 pv[2];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = tid + 256 * u;
-            int r, kk;
-            if (g.a_kmajor) { kk = idx >> 7; r = idx & 127; } else { r = idx >> 4; kk = idx & 15; }
-            const int gm = m0 + r, gk = k0 + kk;
-            float v = 0.f;
-            if (gm < Mb && gk < ke) {
-                v = g.a_kmajor ? Ab[(long long)gk * g.lda + gm] : Ab[(long long)gm * g.lda + gk];
-                if (sub) v -= sub[gk];
-                if (ks) v *= ks[gk];
-                if (rs) v *= rs[gm];
+            for (int u = 0; u < 2; ++u) ra[u] = *reinterpret_cast<const float4*>(Ak + a_off[u]);
+#pragma unroll
+            for (int u = 0; u < NVB; ++u) rb[u] = *reinterpret_cast<const float4*>(Bk + b_off[u]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (PRO == 1) {
+                    if (AK) { const float s = pb[k0 + a_k[u]]; pv[u] = make_float4(s, s, s, s); }
+                    else pv[u] = *reinterpret_cast<const float4*>(pb + k0 + a_k[u]);
+                } else if (PRO == 2) {
+                    if (AK) pv[u] = a_ok[u] ? *reinterpret_cast<const float4*>(pb + m0 + a_r[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    else { const float s = a_ok[u] ? pb[m0 + a_r[u]] : 0.f; pv[u] = make_float4(s, s, s, s); }
+                } else if (PRO == 3) {
+                    if (AK) { const float s = pb[k0 + a_k[u]]; pv[u] = make_float4(s, s, s, s); }
+                    else pv[u] = ld4(pb + k0 + a_k[u], 4, vecP);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float4 v = ra[u];
+                if (PRO == 1) { v.x -= pv[u].x; v.y -= pv[u].y; v.z -= pv[u].z; v.w -= pv[u].w; }
+                if (PRO >= 2) { v.x *= pv[u].x; v.y *= pv[u].y; v.z *= pv[u].z; v.w *= pv[u].w; }
+                ra[u] = a_ok[u] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < NVB; ++u) rb[u] = b_ok[u] ? rb[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int gm = m0 + a_r[u], gk = k0 + a_k[u];
+            float4 v;
+            if (AK) {                                           // 4 consecutive rows of one k
+                const int nv = (gk < ke) ? Mb - gm : 0;
+                v = ld4(Ab + (long long)gk * g.lda + gm, nv, vecA);
+                if (nv > 0) {
+                    if (PRO == 1) { const float s = pb[gk]; v.x -= s; v.y -= s; v.z -= s; v.w -= s; }
+                    if (PRO == 3) { const float s = pb[gk]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+                    if (PRO == 2) { const float4 s = ld4(pb + gm, nv, vecP); v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
+                    if (nv < 4) { if (nv < 2) v.y = 0.f; if (nv < 3) v.z = 0.f; v.w = 0.f; }
+                }
+            } else {                                            // 4 consecutive k of one row
+                const int nv = (gm < Mb) ? ke - gk : 0;
+                v = ld4(Ab + (long long)gm * g.lda + gk, nv, vecA);
+                if (nv > 0) {
+                    if (PRO == 1) { const float4 s = ld4(pb + gk, nv, vecP); v.x -= s.x; v.y -= s.y; v.z -= s.z; v.w -= s.w; }
+                    if (PRO == 3) { const float4 s = ld4(pb + gk, nv, vecP); v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
+                    if (PRO == 2) { const float s = pb[gm]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+                    if (nv < 4) { if (nv < 2) v.y = 0.f; if (nv < 3) v.z = 0.f; v.w = 0.f; }
+                }
             }
             ra[u] = v;
-            int c, k2;
-            if (g.b_kmajor) { k2 = idx >> 7; c = idx & 127; } else { c = idx >> 4; k2 = idx & 15; }
-            const int gn = n0 + c, gk2 = k0 + k2;
-            float w = 0.f;
-            if (gn < g.N && gk2 < ke) w = g.b_kmajor ? Bb[(long long)gk2 * g.ldb + gn] : Bb[(long long)gn * g.ldb + gk2];
-            rb[u] = w;
+        }
+#pragma unroll
+        for (int u = 0; u < NVB; ++u) {
+            const int gn = n0 + b_c[u], gk = k0 + b_k[u];
+            if (BKM) {
+                const int nv = (gk < ke && b_c[u] < BN) ? g.N - gn : 0;
+                rb[u] = ld4(Bb + (long long)gk * g.ldb + gn, nv, vecB);
+            } else {
+                const int nv = (gn < g.N && b_c[u] < BN) ? ke - gk : 0;
+                rb[u] = ld4(Bb + (long long)gn * g.ldb + gk, nv, vecB);
+            }
         }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int idx = tid + 256 * u;
-            int r, kk;
-            if (g.a_kmajor) { kk = idx >> 7; r = idx & 127; } else { r = idx >> 4; kk = idx & 15; }
-            As[buf][kk * LDT + r] = ra[u];
-            int c, k2;
-            if (g.b_kmajor) { k2 = idx >> 7; c = idx & 127; } else { c = idx >> 4; k2 = idx & 15; }
-            Bs[buf][k2 * LDT + c] = rb[u];
+        for (int u = 0; u < 2; ++u) {
+            if (AK) {
+                *reinterpret_cast<float4*>(&As[buf][a_k[u] * LDA_S + a_r[u]]) = ra[u];
+            } else {
+                float* d = &As[buf][a_k[u] * LDA_S + a_r[u]];
+                d[0] = ra[u].x; d[LDA_S] = ra[u].y; d[2 * LDA_S] = ra[u].z; d[3 * LDA_S] = ra[u].w;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NVB; ++u) {
+            if (b_c[u] >= BN) continue;
+            if (BKM) {
+                *reinterpret_cast<float4*>(&Bs[buf][b_k[u] * LDB_S + b_c[u]]) = rb[u];
+            } else {
+                float* d = &Bs[buf][b_k[u] * LDB_S + b_c[u]];
+                d[0] = rb[u].x; d[LDB_S] = rb[u].y; d[2 * LDB_S] = rb[u].z; d[3 * LDB_S] = rb[u].w;
+            }
         }
     };
-    f32x16 acc00, acc01, acc10, acc11;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     if (total > 0) {
         gload(0);
@@ -118,16 +229,23 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
     int buf = 0;
     for (int step = 0; step < total; ++step) {
         if (step + 1 < total) gload(step + 1);
-        const float* a_ = As[buf] + half * LDT + wm * 64 + col;
-        const float* b_ = Bs[buf] + half * LDT + wn * 64 + col;
+        const int k0 = kb + (step % spb) * BK;
+        const float* a_ = As[buf] + half * LDA_S + wave * 32 + col;
+        const float* b_ = Bs[buf] + half * LDB_S + col;
+        float av[BK / 2];
 #pragma unroll
-        for (int k2 = 0; k2 < BK / 2; ++k2) {
-            const float a0 = a_[2 * k2 * LDT], a1 = a_[2 * k2 * LDT + 32];
-            const float b0 = b_[2 * k2 * LDT], b1 = b_[2 * k2 * LDT + 32];
-            acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc00, 0, 0, 0);
-            acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc01, 0, 0, 0);
-            acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc10, 0, 0, 0);
-            acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc11, 0, 0, 0);
+        for (int k2 = 0; k2 < BK / 2; ++k2) av[k2] = a_[2 * k2 * LDA_S];
+        // sub-tile t (columns n0 + 32 t ..) is skipped for this k range when opB vanishes there or the columns do not exist.
+        // (One uniform branch per sub-tile: straight-line variants per live range were measured -- the accumulator copies
+        // between the variants double the register count and halve the occupancy, 1.6x slower.)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c0 = n0 + 32 * t;
+            if (c0 < g.N && !(g.tri == 1 && k0 >= c0 + 32) && !(g.tri == 2 && k0 + BK <= c0)) {
+#pragma unroll
+                for (int k2 = 0; k2 < BK / 2; ++k2)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k2], b_[2 * k2 * LDB_S + 32 * t], acc[t], 0, 0, 0);
+            }
         }
         if (step + 1 < total) sstore(buf ^ 1);
         __syncthreads();
@@ -135,22 +253,22 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
     }
     float* Cb = g.C + (g.inner > 0 ? 0 : (long long)bz * g.sC) + rowbase * g.ldc;
     const float* bias = g.c_bias ? g.c_bias + (long long)bz * g.s_cb : nullptr;
-    auto emit = [&](const f32x16& acc, int ti, int tj) {
-        const int j = n0 + wn * 64 + tj * 32 + col;
-        if (j >= g.N) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int j = n0 + 32 * t + col;
+        if (j >= g.N) continue;
         const float bj = bias ? bias[j] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int i = m0 + wm * 64 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int i = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (i < Mb) {
                 float* p = Cb + (long long)i * g.ldc + j;
-                float v = fmaf(g.alpha, acc[r], bj);
+                float v = fmaf(g.alpha, acc[t][r], bj);
                 if (g.accumulate) v += *p;
                 *p = v;
             }
         }
-    };
-    emit(acc00, 0, 0); emit(acc01, 0, 1); emit(acc10, 1, 0); emit(acc11, 1, 1);
+    }
 }
 
 BG bg_zero() {
@@ -160,12 +278,37 @@ BG bg_zero() {
     return g;
 }
 
-int bgemm(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
-    if (g.M <= 0 || g.N <= 0 || batches_outer <= 0) return GMMVI_OK;
-    dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batches_outer);
-    hipLaunchKernelGGL(bgemm_kernel, grid, dim3(256), 0, ctx->stream, g);
+template <int AK, int BKM, int PRO>
+int bgemm_launch(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
+    int nt = 4, best = 1 << 30;
+    for (int c = 5; c >= 3; --c) {                       // least padded width; ties go to the wider tile
+        const int w = (g.N + 32 * c - 1) / (32 * c) * 32 * c;
+        if (w < best) { best = w; nt = c; }
+    }
+    dim3 grid(best / (32 * nt), (g.M + BM - 1) / BM, batches_outer);
+    switch (nt) {
+        case 3: hipLaunchKernelGGL((bgemm_kernel<3, AK, BKM, PRO>), grid, dim3(256), 0, ctx->stream, g); break;
+        case 4: hipLaunchKernelGGL((bgemm_kernel<4, AK, BKM, PRO>), grid, dim3(256), 0, ctx->stream, g); break;
+        default: hipLaunchKernelGGL((bgemm_kernel<5, AK, BKM, PRO>), grid, dim3(256), 0, ctx->stream, g); break;
+    }
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
+}
+
+// the operand layouts / prologues the callers below use
+int bgemm(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
+    if (g.M <= 0 || g.N <= 0 || batches_outer <= 0) return GMMVI_OK;
+    const int pro = g.a_sub ? 1 : (g.a_rscale ? 2 : (g.a_kscale ? 3 : 0));
+    const int key = g.a_kmajor * 100 + g.b_kmajor * 10 + pro;
+    switch (key) {
+        case 1: return bgemm_launch<0, 0, 1>(ctx, g, batches_outer);      // whitening: (X - mu) L^-T
+        case 0: return bgemm_launch<0, 0, 0>(ctx, g, batches_outer);      // sampling: eps L^T
+        case 12: return bgemm_launch<0, 1, 2>(ctx, g, batches_outer);     // gradient: (r Z) L^-1
+        case 10: return bgemm_launch<0, 1, 0>(ctx, g, batches_outer);     // A L^-1, R L
+        case 113: return bgemm_launch<1, 1, 3>(ctx, g, batches_outer);    // Stein: G1^T diag(e) Z1
+        case 110: return bgemm_launch<1, 1, 0>(ctx, g, batches_outer);    // L^T (R L)
+        default: return gmmvi_fail(ctx, GMMVI_ERR_ARG, "bgemm: operand layout not instantiated");
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -192,64 +335,150 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return s;
 }
 
-// Forward substitution T x = r with a lower-triangular T (row-major, row stride D), one thread per right-hand side:
-// thread t solves for rhs(i, t), i = 0..D-1, knowing that its solution vanishes for i < i0.  The solution goes to
-// X[i * ldx + t] (coalesced over t; the thread re-reads its own column).  Row i of T is staged in LDS for every step.
-template <class RhsF>
-__device__ void blk_trsm(int D, const float* __restrict__ T, int nrhs, RhsF rhs, int i0, float* X, int ldx, float* Trow) {
+// Forward substitution T x = r with a lower-triangular T, one thread per right-hand side, 32 rows at a time:
+// thread t solves for rhs(i, t), i = 0..D-1, knowing that its solution vanishes for i < i0; X[i * ldx + t] receives it
+// (coalesced over t).  Per block of 32 rows the rows of T are staged in LDS (Ts: 32 x (D + 4) floats) and the thread keeps
+// its 32 partial sums in registers: every solved x is read back from memory once per block (not once per row), the
+// multiplies run on broadcast 16-byte LDS reads.  TCM: T is given column-major (T[i][c] at Tm[c * D + i]).
+constexpr int TRB = 32;
+inline size_t blk_trsm_lds_floats(int D) { return (size_t)TRB * (((D + 3) / 4) * 4 + 4); }
+
+template <bool TCM, class RhsF>
+__device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs, int i0, float* X, int ldx, float* Ts) {
     const int t = threadIdx.x;
-    for (int i = 0; i < D; ++i) {
+    const int ld = ((D + 3) / 4) * 4 + 4;
+    for (int I = 0; I < D; I += TRB) {
+        const int nbk = min(TRB, D - I), w = I + nbk;
         __syncthreads();
-        for (int c = t; c <= i; c += blockDim.x) Trow[c] = T[(size_t)i * D + c];
-        __syncthreads();
-        if (t < nrhs) {
-            float v = 0.f;
-            if (i >= i0) {
-                float s0 = rhs(i, t), s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                int c = i0;
-                for (; c + 3 < i; c += 4) {
-                    s0 = fmaf(-Trow[c], X[(size_t)c * ldx + t], s0);
-                    s1 = fmaf(-Trow[c + 1], X[(size_t)(c + 1) * ldx + t], s1);
-                    s2 = fmaf(-Trow[c + 2], X[(size_t)(c + 2) * ldx + t], s2);
-                    s3 = fmaf(-Trow[c + 3], X[(size_t)(c + 3) * ldx + t], s3);
-                }
-                for (; c < i; ++c) s0 = fmaf(-Trow[c], X[(size_t)c * ldx + t], s0);
-                v = ((s0 + s1) + (s2 + s3)) / Trow[i];
+        if (TCM) {
+            for (int e = t; e < w * TRB; e += blockDim.x) {
+                const int c = e / TRB, r = e % TRB;
+                if (r < nbk) Ts[r * ld + c] = (c <= I + r) ? Tm[(size_t)c * D + I + r] : 0.f;
             }
-            X[(size_t)i * ldx + t] = v;
+        } else {
+            for (int e = t; e < nbk * w; e += blockDim.x) {
+                const int r = e / w, c = e % w;
+                Ts[r * ld + c] = Tm[(size_t)(I + r) * D + c];
+            }
+        }
+        __syncthreads();
+        if (t >= nrhs) continue;
+        float acc[TRB];
+        if (I + TRB <= i0) {                                   // structurally zero rows
+#pragma unroll
+            for (int r = 0; r < TRB; ++r)
+                if (r < nbk) X[(size_t)(I + r) * ldx + t] = 0.f;
+            continue;
+        }
+#pragma unroll
+        for (int r = 0; r < TRB; ++r) acc[r] = (r < nbk) ? rhs(I + r, t) : 0.f;
+        for (int c = i0 & ~3; c < I; c += 4) {                 // x_c = 0 below i0 (stored as such)
+            const float x0 = X[(size_t)c * ldx + t], x1 = X[(size_t)(c + 1) * ldx + t];
+            const float x2 = X[(size_t)(c + 2) * ldx + t], x3 = X[(size_t)(c + 3) * ldx + t];
+#pragma unroll
+            for (int r = 0; r < TRB; ++r) {
+                const float4 tv = *reinterpret_cast<const float4*>(Ts + r * ld + c);
+                acc[r] = fmaf(-tv.x, x0, fmaf(-tv.y, x1, fmaf(-tv.z, x2, fmaf(-tv.w, x3, acc[r]))));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < TRB; ++r) {
+            if (r < nbk) {
+                float sv = acc[r];
+#pragma unroll
+                for (int q = 0; q < r; ++q) sv = fmaf(-Ts[r * ld + I + q], acc[q], sv);
+                acc[r] = sv / Ts[r * ld + I + r];
+                X[(size_t)(I + r) * ldx + t] = acc[r];
+            }
         }
     }
     __syncthreads();
 }
 
-// Cholesky factorisation A = C C^T of the symmetric matrix a(i, j) (i >= j read), left-looking, one thread per row;
-// the factor is built column-major (W[c * D + i] = C[i][c]: thread i walks coalesced rows of W).  Returns false (block-uniform)
-// on a non-positive or non-finite pivot.
+// Cholesky factorisation A = C C^T of the symmetric matrix a(i, j) (i >= j read), left-looking over blocks of 32 columns,
+// one thread per row; the factor is built column-major (W[c * D + i] = C[i][c]: thread i walks coalesced rows of W).
+// Per column block the finished columns' entries of the block rows are staged in LDS (Wb: J x 32), every thread forms its
+// 32 partial sums in registers, one wave factorises the 32 x 32 diagonal block in LDS (Dg), the other rows solve
+// against it.  LDS: blk_chol_lds_floats(D).  Returns false (block-uniform) on a non-positive or non-finite pivot.
+inline size_t blk_chol_lds_floats(int D) { return (size_t)D * TRB + TRB * (TRB + 1) + 4; }
+
 template <class ElemF>
-__device__ bool blk_cholesky(int D, ElemF a, float* W, float* piv) {
+__device__ bool blk_cholesky(int D, ElemF a, float* W, float* lds) {
+    float* Wb = lds;                                   // [c][32], c < J
+    float* Dg = lds + (size_t)D * TRB;                 // [32][33]
+    int* fail = reinterpret_cast<int*>(Dg + TRB * (TRB + 1));
     const int i = threadIdx.x;
-    for (int j = 0; j < D; ++j) {
-        float s = 0.f;
-        if (i >= j && i < D) {
-            float s0 = a(i, j), s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int c = 0;
-            for (; c + 3 < j; c += 4) {
-                s0 = fmaf(-W[(size_t)c * D + i], W[(size_t)c * D + j], s0);
-                s1 = fmaf(-W[(size_t)(c + 1) * D + i], W[(size_t)(c + 1) * D + j], s1);
-                s2 = fmaf(-W[(size_t)(c + 2) * D + i], W[(size_t)(c + 2) * D + j], s2);
-                s3 = fmaf(-W[(size_t)(c + 3) * D + i], W[(size_t)(c + 3) * D + j], s3);
-            }
-            for (; c < j; ++c) s0 = fmaf(-W[(size_t)c * D + i], W[(size_t)c * D + j], s0);
-            s = (s0 + s1) + (s2 + s3);
+    if (i == 0) *fail = 0;
+    for (int J = 0; J < D; J += TRB) {
+        const int nbk = min(TRB, D - J);
+        __syncthreads();
+        for (int e = i; e < J * TRB; e += blockDim.x) {
+            const int c = e / TRB, r = e % TRB;
+            Wb[e] = (r < nbk) ? W[(size_t)c * D + J + r] : 0.f;
         }
-        if (i == j) *piv = s;
         __syncthreads();
-        const float p = *piv;
-        if (!(p > 0.f) || !(p < FLT_MAX)) return false;
-        const float d = sqrtf(p);
-        if (i >= j && i < D) W[(size_t)j * D + i] = (i == j) ? d : s / d;
+        float acc[TRB];
+        const bool mine = i >= J && i < D;
+        if (mine) {
+#pragma unroll
+            for (int r = 0; r < TRB; ++r) acc[r] = (r < nbk && J + r <= i) ? a(i, J + r) : 0.f;
+            for (int c = 0; c < J; ++c) {
+                const float wv = W[(size_t)c * D + i];
+#pragma unroll
+                for (int r4 = 0; r4 < TRB / 4; ++r4) {
+                    const float4 bv = *reinterpret_cast<const float4*>(Wb + c * TRB + 4 * r4);
+                    acc[4 * r4] = fmaf(-wv, bv.x, acc[4 * r4]);
+                    acc[4 * r4 + 1] = fmaf(-wv, bv.y, acc[4 * r4 + 1]);
+                    acc[4 * r4 + 2] = fmaf(-wv, bv.z, acc[4 * r4 + 2]);
+                    acc[4 * r4 + 3] = fmaf(-wv, bv.w, acc[4 * r4 + 3]);
+                }
+            }
+            if (i < J + nbk) {
+#pragma unroll
+                for (int r = 0; r < TRB; ++r) Dg[(i - J) * (TRB + 1) + r] = acc[r];
+            }
+        }
         __syncthreads();
+        if (i < 32) {                                  // half of wave 0: 32 x 32 Cholesky in LDS, lane = row
+            const int l = i;
+            for (int r = 0; r < nbk; ++r) {
+                float sv = 0.f;
+                if (l >= r && l < nbk) {
+                    sv = Dg[l * (TRB + 1) + r];
+                    for (int q = 0; q < r; ++q) sv = fmaf(-Dg[l * (TRB + 1) + q], Dg[r * (TRB + 1) + q], sv);
+                }
+                const float pv = __shfl(sv, r);
+                if (!(pv > 0.f) || !(pv < FLT_MAX)) { if (i == 0) *fail = 1; break; }
+                const float d = sqrtf(pv);
+                if (l >= r && l < nbk) Dg[l * (TRB + 1) + r] = (l == r) ? d : sv / d;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+        }
+        __syncthreads();
+        if (*fail) return false;
+        if (mine) {
+            if (i < J + nbk) {
+                const int l = i - J;
+#pragma unroll
+                for (int r = 0; r < TRB; ++r)
+                    if (r <= l) W[(size_t)(J + r) * D + i] = Dg[l * (TRB + 1) + r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < TRB; ++r) {
+                    if (r < nbk) {
+                        float sv = acc[r];
+#pragma unroll
+                        for (int q = 0; q < r; ++q) sv = fmaf(-acc[q], Dg[r * (TRB + 1) + q], sv);
+                        acc[r] = sv / Dg[r * (TRB + 1) + r];
+                        W[(size_t)(J + r) * D + i] = acc[r];
+                    }
+                }
+            }
+        }
     }
+    __syncthreads();
     return true;
 }
 
@@ -259,7 +488,7 @@ __device__ bool blk_cholesky(int D, ElemF a, float* W, float* piv) {
 __global__ __launch_bounds__(512) void blk_pack_kernel(int family, float nu, int D, const float* __restrict__ means,
                                                        const float* __restrict__ chols, float* __restrict__ packed,
                                                        size_t ps, int lo, float* __restrict__ inv_out) {
-    __shared__ float Trow[GMMVI_BLOCKED_MAX_DIM];
+    extern __shared__ __align__(16) float dyn[];
     __shared__ float red[16];
     const int k = blockIdx.x, t = threadIdx.x;
     const float* L = chols + (size_t)k * D * D;
@@ -273,7 +502,7 @@ __global__ __launch_bounds__(512) void blk_pack_kernel(int family, float nu, int
                      : lgammaf(0.5f * (nu + D)) - lgammaf(0.5f * nu) - 0.5f * D * logf(nu * 3.14159265358979f) - s;
         for (int i = D + 1; i < lo; ++i) out[i] = 0.f;
     }
-    blk_trsm(D, L, D, [](int i, int tt) { return i == tt ? 1.f : 0.f; }, t, Linv, D, Trow);
+    blk_trsm<false>(D, L, D, [](int i, int tt) { return i == tt ? 1.f : 0.f; }, t, Linv, D, dyn);
     if (inv_out != nullptr) {
         float* o = inv_out + (size_t)k * D * D;
         for (int e = t; e < D * D; e += blockDim.x) o[e] = Linv[e];
@@ -282,11 +511,11 @@ __global__ __launch_bounds__(512) void blk_pack_kernel(int family, float nu, int
 
 __global__ __launch_bounds__(512) void blk_cholesky_kernel(int D, const float* __restrict__ covs, float* __restrict__ W,
                                                            float* __restrict__ chols, int32_t* __restrict__ ok) {
-    __shared__ float piv;
+    extern __shared__ __align__(16) float dyn[];
     const int k = blockIdx.x, t = threadIdx.x;
     const float* A = covs + (size_t)k * D * D;
     float* Wk = W + (size_t)k * D * D;
-    const bool good = blk_cholesky(D, [A, D](int i, int j) { return A[(size_t)i * D + j]; }, Wk, &piv);
+    const bool good = blk_cholesky(D, [A, D](int i, int j) { return A[(size_t)i * D + j]; }, Wk, dyn);
     __syncthreads();
     float* o = chols + (size_t)k * D * D;
     for (int e = t; e < D * D; e += blockDim.x) {
@@ -395,18 +624,32 @@ int blk_forward(gmmvi_ctx* ctx, int D, const float* packed, int k0, int kn, cons
 
 static int blk_threads(int D) { return ((D + 63) / 64) * 64; }
 
+// the factorisation kernels stage up to ~70 KB of LDS at D = 512: raise the dynamic limit once
+static int blk_lds_attr(gmmvi_ctx* ctx) {
+    static bool done = false;
+    if (done) return GMMVI_OK;
+    const int lim = 96 * 1024;
+    GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_cholesky_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    done = true;
+    return GMMVI_OK;
+}
+
 int gmmvi_blocked_pack(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* means, const float* chols,
                        float* packed, float* inv_chols) {
     GMMVI_PROF(ctx, "blocked_pack");
-    hipLaunchKernelGGL(blk_pack_kernel, dim3(K), dim3(blk_threads(D)), 0, ctx->stream, family, nu, D, means, chols, packed,
-                       gmmvi_blocked_stride(D), gmmvi_blocked_linv_ofs(D), inv_chols);
+    BLK_TRY(blk_lds_attr(ctx));
+    hipLaunchKernelGGL(blk_pack_kernel, dim3(K), dim3(blk_threads(D)), blk_trsm_lds_floats(D) * sizeof(float), ctx->stream, family,
+                       nu, D, means, chols, packed, gmmvi_blocked_stride(D), gmmvi_blocked_linv_ofs(D), inv_chols);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }
 
 int gmmvi_blocked_cholesky(gmmvi_ctx* ctx, int K, int D, const float* covs, float* chols, int32_t* ok) {
     BLK_TRY(gmmvi_ws_reserve(ctx, (size_t)K * D * D * sizeof(float)));
-    hipLaunchKernelGGL(blk_cholesky_kernel, dim3(K), dim3(blk_threads(D)), 0, ctx->stream, D, covs, (float*)ctx->ws, chols, ok);
+    BLK_TRY(blk_lds_attr(ctx));
+    hipLaunchKernelGGL(blk_cholesky_kernel, dim3(K), dim3(blk_threads(D)), blk_chol_lds_floats(D) * sizeof(float), ctx->stream, D,
+                       covs, (float*)ctx->ws, chols, ok);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }
@@ -506,18 +749,20 @@ int gmmvi_blocked_sample(gmmvi_ctx* ctx, int K, int D, const float* means, const
 // ---------------------------------------------------------------------------------------------------------------------------
 namespace {
 
-__global__ __launch_bounds__(256) void blk_stein_g_kernel(int N, int D, const float* __restrict__ tgrad,
+// rows [g_n; 1; 0..] with the row stride LP = D + 1 rounded up to a multiple of 4 (16-byte aligned rows)
+__global__ __launch_bounds__(256) void blk_stein_g_kernel(int N, int D, int LP, const float* __restrict__ tgrad,
                                                           const float* __restrict__ qgrad, float* __restrict__ G1) {
-    const int D1 = D + 1;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)N * D1) return;
-    const int n = (int)(e / D1), i = (int)(e % D1);
-    G1[e] = (i < D) ? tgrad[(size_t)n * D + i] - qgrad[(size_t)n * D + i] : 1.f;
+    if (e >= (long long)N * LP) return;
+    const int n = (int)(e / LP), i = (int)(e % LP);
+    G1[e] = (i < D) ? tgrad[(size_t)n * D + i] - qgrad[(size_t)n * D + i] : (i == D ? 1.f : 0.f);
 }
 
-__global__ __launch_bounds__(256) void blk_fill_col_kernel(long long rows, int ld, int colidx, float value, float* __restrict__ Z) {
+// columns D .. LP-1 of the whitened rows: [.; 1; 0..]
+__global__ __launch_bounds__(256) void blk_fill_col_kernel(long long rows, int D, int LP, float* __restrict__ Z) {
     const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (r < rows) Z[r * ld + colidx] = value;
+    if (r >= rows) return;
+    for (int c = D; c < LP; ++c) Z[r * LP + c] = (c == D) ? 1.f : 0.f;
 }
 
 // importance weights of one component over all samples, referred to their maximum: e[kb][n] = exp(a_n - M), Mk[kb] = M
@@ -544,7 +789,7 @@ __global__ __launch_bounds__(1024) void blk_stein_weights_kernel(int N, int k0, 
 __global__ __launch_bounds__(256) void blk_stein_finalize_kernel(int D, int N, int flags, const float* __restrict__ Araw,
                                                                  const float* __restrict__ T, const float* __restrict__ Mk,
                                                                  float* __restrict__ H_neg, float* __restrict__ g_neg) {
-    const int kb = blockIdx.x, D1 = D + 1;
+    const int kb = blockIdx.x, D1 = ((D + 1 + 3) / 4) * 4;          // row stride of the augmented matrix
     const float* A = Araw + (size_t)kb * D1 * D1;
     const float* Tk = T + (size_t)kb * D * D;
     const bool snis = (flags & GMMVI_SELF_NORMALIZED) != 0;
@@ -562,13 +807,13 @@ __global__ __launch_bounds__(256) void blk_stein_finalize_kernel(int D, int N, i
 int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
                         const float* qgrad, const float* bg, const float* tgrad, const int32_t* mapping, int map_offset,
                         int flags, float* H_neg, float* g_neg) {
-    const int D1 = D + 1;
+    const int LP = ((D + 1 + 3) / 4) * 4;                  // augmented width D + 1, padded to 16-byte rows (pad columns zero)
     const size_t ps = gmmvi_blocked_stride(D);
-    const size_t zrow = (size_t)N * D1;
+    const size_t zrow = (size_t)N * LP;
     size_t kc = z_budget_floats() / zrow;
     const int Kc = (int)(kc < 1 ? 1 : (kc > (size_t)K ? (size_t)K : kc));
     const size_t f_z = (size_t)Kc * zrow, f_g = zrow, f_e = (size_t)Kc * N, f_m = ((size_t)Kc + 3) / 4 * 4;
-    const size_t f_a = (size_t)Kc * D1 * D1, f_t = (size_t)Kc * D * D;
+    const size_t f_a = (size_t)Kc * LP * LP, f_t = (size_t)Kc * D * D;
     BLK_TRY(gmmvi_ws_reserve(ctx, (f_z + f_g + f_e + f_m + f_a + f_t) * sizeof(float)));
     float* Z = (float*)ctx->ws;
     float* G1 = Z + f_z;
@@ -576,29 +821,30 @@ int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
     float* Mk = e + f_e;
     float* Araw = Mk + f_m;
     float* T = Araw + f_a;
-    hipLaunchKernelGGL(blk_stein_g_kernel, dim3((unsigned)((zrow + 255) / 256)), dim3(256), 0, ctx->stream, N, D, tgrad, qgrad, G1);
+    hipLaunchKernelGGL(blk_stein_g_kernel, dim3((unsigned)((zrow + 255) / 256)), dim3(256), 0, ctx->stream, N, D, LP, tgrad, qgrad,
+                       G1);
     GMMVI_LAUNCH_CHECK(ctx);
     for (int k0 = 0; k0 < K; k0 += Kc) {
         const int kn = (K - k0 < Kc) ? K - k0 : Kc;
         const long long rows = (long long)kn * N;
-        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, D1));
-        hipLaunchKernelGGL(blk_fill_col_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, rows, D1, D, 1.f, Z);
+        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP));
+        hipLaunchKernelGGL(blk_fill_col_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, rows, D, LP, Z);
         hipLaunchKernelGGL(blk_stein_weights_kernel, dim3(kn), dim3(1024), 0, ctx->stream, N, k0, ld, bg, mapping, map_offset,
                            flags, e, Mk);
         GMMVI_LAUNCH_CHECK(ctx);
         {
             BG g = bg_zero();
-            g.A = G1; g.lda = D1; g.sA = 0; g.a_kmajor = 1;             // opA(m = a, k = n) = G1[n][a]
+            g.A = G1; g.lda = LP; g.sA = 0; g.a_kmajor = 1;             // opA(m = a, k = n) = G1[n][a]
             g.a_kscale = e; g.s_aks = N;
-            g.B = Z; g.ldb = D1; g.sB = (long long)zrow; g.b_kmajor = 1;  // opB(k = n, n = b) = Z1[n][b]
-            g.C = Araw; g.ldc = D1; g.sC = (long long)D1 * D1;
-            g.M = D1; g.N = D1; g.Kd = N;
+            g.B = Z; g.ldb = LP; g.sB = (long long)zrow; g.b_kmajor = 1;  // opB(k = n, n = b) = Z1[n][b]
+            g.C = Araw; g.ldc = LP; g.sC = (long long)LP * LP;
+            g.M = LP; g.N = LP; g.Kd = N;
             GMMVI_PROF(ctx, "blocked_stein_accumulate");
             BLK_TRY(bgemm(ctx, g, kn));
         }
         {
             BG g = bg_zero();
-            g.A = Araw; g.lda = D1; g.sA = (long long)D1 * D1; g.a_kmajor = 0;
+            g.A = Araw; g.lda = LP; g.sA = (long long)LP * LP; g.a_kmajor = 0;
             g.B = packed + (size_t)k0 * ps + gmmvi_blocked_linv_ofs(D); g.ldb = D; g.sB = (long long)ps; g.b_kmajor = 1;
             g.C = T; g.ldc = D; g.sC = (long long)D * D;
             g.M = D; g.N = D; g.Kd = D; g.tri = 2;
@@ -693,16 +939,18 @@ __global__ __launch_bounds__(1024) void blk_tridiag_kernel(int D, int DT, int G,
         const float vi = mine ? (i == c + 1 ? x1 - alpha : xi) : 0.f;
         if (grp == 0 && i < D) v[i] = vi;
         __syncthreads();
-        float a0 = 0.f, a1 = 0.f;
+        float a0 = 0.f;
         if (i > c && i < D) {
+            float av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};         // eight loads in flight per thread
             int j = c + 1 + grp;
-            for (; j + G < D; j += 2 * G) {
-                a0 = fmaf(M[(size_t)j * D + i], v[j], a0);
-                a1 = fmaf(M[(size_t)(j + G) * D + i], v[j + G], a1);
+            for (; j + 7 * G < D; j += 8 * G) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) av[u] = fmaf(M[(size_t)(j + u * G) * D + i], v[j + u * G], av[u]);
             }
-            if (j < D) a0 = fmaf(M[(size_t)j * D + i], v[j], a0);
+            for (; j < D; j += G) a0 = fmaf(M[(size_t)j * D + i], v[j], a0);
+            a0 += ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
         }
-        part[grp * DT + i] = a0 + a1;
+        part[grp * DT + i] = a0;
         __syncthreads();
         float p = 0.f;
         if (mine) {
@@ -716,8 +964,16 @@ __global__ __launch_bounds__(1024) void blk_tridiag_kernel(int D, int DT, int G,
         __syncthreads();
         if (i > c && i < D) {
             const float vi2 = v[i], qi2 = q[i];
-            for (int j = c + 1 + grp; j < D; j += G)
-                M[(size_t)j * D + i] -= __fadd_rn(__fmul_rn(v[j], qi2), __fmul_rn(q[j], vi2));
+            int j = c + 1 + grp;
+            for (; j + 7 * G < D; j += 8 * G) {
+                float mv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mv[u] = M[(size_t)(j + u * G) * D + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    M[(size_t)(j + u * G) * D + i] = mv[u] - __fadd_rn(__fmul_rn(v[j + u * G], qi2), __fmul_rn(q[j + u * G], vi2));
+            }
+            for (; j < D; j += G) M[(size_t)j * D + i] -= __fadd_rn(__fmul_rn(v[j], qi2), __fmul_rn(q[j], vi2));
         }
         if (tid == 0) te[c] = alpha;
         __syncthreads();
@@ -841,14 +1097,12 @@ __global__ __launch_bounds__(64) void blk_search_kernel(int D, const float* __re
 // z = U^-1 w by forward substitution with C on the reversed rows of L (one thread per row, thread D: w);
 // mu' = mu - L' z / eta*.  Commits means / chols on success and does the bookkeeping of :518-524.
 __global__ __launch_bounds__(576) void blk_upd_final_kernel(int D, const float* __restrict__ Mc_all, const float* __restrict__ w_all,
-                                                            float* __restrict__ W_all, float* __restrict__ Cr_all,
-                                                            float* __restrict__ X_all, const float* __restrict__ state,
+                                                            float* __restrict__ W_all, float* __restrict__ X_all, const float* __restrict__ state,
                                                             float* __restrict__ means, float* __restrict__ chols,
                                                             float l2_init, float* __restrict__ last_eta, float* __restrict__ l2,
                                                             float* __restrict__ num_updates, int32_t* __restrict__ success_out,
                                                             float* __restrict__ kl_out, int32_t* __restrict__ nprobes_out) {
-    __shared__ float Trow[GMMVI_BLOCKED_MAX_DIM];
-    __shared__ float piv;
+    extern __shared__ __align__(16) float dyn[];
     __shared__ int anybad;
     const int k = blockIdx.x, t = threadIdx.x;
     const float eta_star = state[4 * k];
@@ -861,21 +1115,14 @@ __global__ __launch_bounds__(576) void blk_upd_final_kernel(int D, const float* 
         const float* Mc = Mc_all + (size_t)k * D * D;
         float* W = W_all + (size_t)k * D * D;
         success = blk_cholesky(D, [Mc, D, inv](int i, int j) {
-            return (i == j ? 1.f : 0.f) + Mc[(size_t)(D - 1 - i) * D + (D - 1 - j)] * inv; }, W, &piv);
-        __syncthreads();
+            return (i == j ? 1.f : 0.f) + Mc[(size_t)(D - 1 - i) * D + (D - 1 - j)] * inv; }, W, dyn);
         if (success) {
-            float* Cr = Cr_all + (size_t)k * D * D;
-            for (int e = t; e < D * D; e += blockDim.x) {
-                const int c = e / D, i = e % D;                     // W[c][i] = C[i][c]
-                if (c <= i) Cr[(size_t)i * D + c] = W[e];
-            }
-            __syncthreads();
             const float* w = w_all + (size_t)k * D;
             float* X = X_all + (size_t)k * D * (D + 1);
             const int ldx = D + 1;
-            blk_trsm(D, Cr, D + 1,
-                     [L, w, D](int i, int tt) { return tt < D ? L[(size_t)tt * D + (D - 1 - i)] : w[D - 1 - i]; },
-                     t < D ? D - 1 - t : 0, X, ldx, Trow);
+            blk_trsm<true>(D, W, D + 1,
+                           [L, w, D](int i, int tt) { return tt < D ? L[(size_t)tt * D + (D - 1 - i)] : w[D - 1 - i]; },
+                           t < D ? D - 1 - t : 0, X, ldx, dyn);
             if (t == 0) anybad = 0;
             __syncthreads();
             float new_mu = 0.f;
@@ -967,8 +1214,18 @@ int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* c
     hipLaunchKernelGGL(blk_search_kernel, dim3(K), dim3(64), (size_t)3 * D * sizeof(float), ctx->stream, D, td, te, wt, stepsizes,
                        last_eta, temperature, scratch, state);
     GMMVI_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(blk_upd_final_kernel, dim3(K), dim3(blk_threads(D + 1)), 0, ctx->stream, D, Mc, w, T1, Rs, Xs, state, means,
-                       chols, l2_init, last_eta, l2, num_updates, success_out, kl_out, nprobes_out);
+    {
+        static bool attr_done = false;
+        if (!attr_done) {
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_upd_final_kernel,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_done = true;
+        }
+        const size_t a = blk_trsm_lds_floats(D), b = blk_chol_lds_floats(D);
+        hipLaunchKernelGGL(blk_upd_final_kernel, dim3(K), dim3(blk_threads(D + 1)), (a > b ? a : b) * sizeof(float), ctx->stream, D,
+                           Mc, w, T1, Xs, state, means, chols, l2_init, last_eta, l2, num_updates, success_out, kl_out,
+                           nprobes_out);
+    }
     GMMVI_LAUNCH_CHECK(ctx);
     if (packed_out) BLK_TRY(gmmvi_blocked_pack(ctx, GMMVI_GAUSS, 0.f, K, D, means, chols, packed_out, nullptr));
     return GMMVI_OK;
