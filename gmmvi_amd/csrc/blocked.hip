@@ -117,8 +117,10 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
         b_off[u] = b_ok[u] ? (BKM ? b_k[u] * g.ldb + n0 + b_c[u] : (n0 + b_c[u]) * g.ldb + b_k[u]) : 0;
     }
 
-    float4 ra[2], rb[NVB];
+    float4 ra[2], rb[NVB], pv[2];
+    bool pending = false;                   // fast route: prologue / masking of the staged pieces still to be applied
     auto gload = [&](int step) {
+        pending = false;
         const int bi = step / spb;
         const long long b = (long long)bz * nb + bi;
         const int k0 = kb + (step - bi * spb) * BK;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
         if (fast_ok && k0 + BK <= ke) {
             const float* Ak = Ab + (AK ? (long long)k0 * g.lda : (long long)k0);
             const float* Bk = Bb + (BKM ? (long long)k0 * g.ldb : (long long)k0);
-            float4 pv[2];
+            // loads only: the prologue and the masking wait for the data, so they run in sstore, after this step's MFMAs
 #pragma unroll
             for (int u = 0; u < 2; ++u) ra[u] = *reinterpret_cast<const float4*>(Ak + a_off[u]);
 #pragma unroll
@@ -139,22 +141,15 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
                     if (AK) { const float s = pb[k0 + a_k[u]]; pv[u] = make_float4(s, s, s, s); }
                     else pv[u] = *reinterpret_cast<const float4*>(pb + k0 + a_k[u]);
                 } else if (PRO == 2) {
-                    if (AK) pv[u] = a_ok[u] ? *reinterpret_cast<const float4*>(pb + m0 + a_r[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    else { const float s = a_ok[u] ? pb[m0 + a_r[u]] : 0.f; pv[u] = make_float4(s, s, s, s); }
+                    // rows that do not exist read element 0 (masked in sstore): no branch around the load
+                    if (AK) pv[u] = *reinterpret_cast<const float4*>(pb + (a_ok[u] ? m0 + a_r[u] : 0));
+                    else { const float s = pb[a_ok[u] ? m0 + a_r[u] : 0]; pv[u] = make_float4(s, s, s, s); }
                 } else if (PRO == 3) {
                     if (AK) { const float s = pb[k0 + a_k[u]]; pv[u] = make_float4(s, s, s, s); }
                     else pv[u] = ld4(pb + k0 + a_k[u], 4, vecP);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float4 v = ra[u];
-                if (PRO == 1) { v.x -= pv[u].x; v.y -= pv[u].y; v.z -= pv[u].z; v.w -= pv[u].w; }
-                if (PRO >= 2) { v.x *= pv[u].x; v.y *= pv[u].y; v.z *= pv[u].z; v.w *= pv[u].w; }
-                ra[u] = a_ok[u] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int u = 0; u < NVB; ++u) rb[u] = b_ok[u] ? rb[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            pending = true;
             return;
         }
 #pragma unroll
@@ -195,6 +190,17 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
         }
     };
     auto sstore = [&](int buf) {
+        if (pending) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float4 v = ra[u];
+                if (PRO == 1) { v.x -= pv[u].x; v.y -= pv[u].y; v.z -= pv[u].z; v.w -= pv[u].w; }
+                if (PRO >= 2) { v.x *= pv[u].x; v.y *= pv[u].y; v.z *= pv[u].z; v.w *= pv[u].w; }
+                ra[u] = a_ok[u] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < NVB; ++u) rb[u] = b_ok[u] ? rb[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (AK) {
@@ -238,19 +244,32 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
         // sub-tile t (columns n0 + 32 t ..) is skipped for this k range when opB vanishes there or the columns do not exist.
         // (One uniform branch per sub-tile: straight-line variants per live range were measured -- the accumulator copies
         // between the variants double the register count and halve the occupancy, 1.6x slower.)
+        // the B operands of sub-tile t + 1 are read (unconditionally) before the MFMAs of sub-tile t are issued, so the LDS
+        // latency of a block hides behind the previous block's eight MFMAs.  The MFMAs are issued through inline asm with
+        // the accumulators pinned to AGPRs: with the builtin the compiler kept acc[] in VGPRs across the (uniform) branches
+        // and copied 16 registers into and out of one AGPR tuple around every block (400 v_accvgpr moves per k step).
+        float bv[2][BK / 2];
+#pragma unroll
+        for (int k2 = 0; k2 < BK / 2; ++k2) bv[0][k2] = b_[2 * k2 * LDB_S];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) {
+#pragma unroll
+                for (int k2 = 0; k2 < BK / 2; ++k2) bv[(t + 1) & 1][k2] = b_[2 * k2 * LDB_S + 32 * (t + 1)];
+            }
             const int c0 = n0 + 32 * t;
             if (c0 < g.N && !(g.tri == 1 && k0 >= c0 + 32) && !(g.tri == 2 && k0 + BK <= c0)) {
 #pragma unroll
                 for (int k2 = 0; k2 < BK / 2; ++k2)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k2], b_[2 * k2 * LDB_S + 32 * t], acc[t], 0, 0, 0);
+                    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(av[k2]), "v"(bv[t & 1][k2]));
             }
         }
         if (step + 1 < total) sstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
+    // the last MFMA (16 passes) must have retired before its accumulators are read (inline asm: no automatic hazard nops)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float* Cb = g.C + (g.inner > 0 ? 0 : (long long)bz * g.sC) + rowbase * g.ldc;
     const float* bias = g.c_bias ? g.c_bias + (long long)bz * g.s_cb : nullptr;
 #pragma unroll
