@@ -43,6 +43,7 @@ struct BG {
     int inner;                       // > 0: this many consecutive batches are accumulated into ONE C (grid.z = 1)
     int tri;                         // 1: opB(k, n) = 0 for k > n   2: opB(k, n) = 0 for k < n
     int accumulate;                  // C += result
+    int ksplit;                      // > 1: grid.z = batches * ksplit, slab z of C receives the partial sum over its k range
     float alpha;
 };
 
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int bz = blockIdx.z;
+    const int nsplit = g.ksplit > 1 ? g.ksplit : 1;
+    const int bz = blockIdx.z / nsplit, kz = blockIdx.z - bz * nsplit;
     int Mb = g.M;
     long long rowbase = 0;
     if (g.row_off) { rowbase = g.row_off[bz]; Mb = g.row_off[bz + 1] - (int)rowbase; }
@@ -82,6 +84,11 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
     int kb = 0, ke = g.Kd;
     if (g.tri == 1) ke = min(g.Kd, n0 + BN);
     else if (g.tri == 2) kb = min(g.Kd, n0) & ~3;
+    if (nsplit > 1) {
+        const int chunk = ((g.Kd + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+        kb = min(g.Kd, kz * chunk);
+        ke = min(g.Kd, kb + chunk);
+    }
     const int spb = (ke - kb + BK - 1) / BK;
     const int nb = g.inner > 0 ? g.inner : 1;
     const int total = nb * spb;
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
     }
     // the last MFMA (16 passes) must have retired before its accumulators are read (inline asm: no automatic hazard nops)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    float* Cb = g.C + (g.inner > 0 ? 0 : (long long)bz * g.sC) + rowbase * g.ldc;
+    float* Cb = g.C + (g.inner > 0 ? 0 : (long long)blockIdx.z * g.sC) + rowbase * g.ldc;
     const float* bias = g.c_bias ? g.c_bias + (long long)bz * g.s_cb : nullptr;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -304,7 +311,7 @@ int bgemm_launch(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
         const int w = (g.N + 32 * c - 1) / (32 * c) * 32 * c;
         if (w < best) { best = w; nt = c; }
     }
-    dim3 grid(best / (32 * nt), (g.M + BM - 1) / BM, batches_outer);
+    dim3 grid(best / (32 * nt), (g.M + BM - 1) / BM, batches_outer * (g.ksplit > 1 ? g.ksplit : 1));
     switch (nt) {
         case 3: hipLaunchKernelGGL((bgemm_kernel<3, AK, BKM, PRO>), grid, dim3(256), 0, ctx->stream, g); break;
         case 4: hipLaunchKernelGGL((bgemm_kernel<4, AK, BKM, PRO>), grid, dim3(256), 0, ctx->stream, g); break;
@@ -391,13 +398,16 @@ __device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs
         }
 #pragma unroll
         for (int r = 0; r < TRB; ++r) acc[r] = (r < nbk) ? rhs(I + r, t) : 0.f;
-        for (int c = i0 & ~3; c < I; c += 4) {                 // x_c = 0 below i0 (stored as such)
-            const float x0 = X[(size_t)c * ldx + t], x1 = X[(size_t)(c + 1) * ldx + t];
-            const float x2 = X[(size_t)(c + 2) * ldx + t], x3 = X[(size_t)(c + 3) * ldx + t];
+        for (int c = i0 & ~7; c < I; c += 8) {                 // x_c = 0 below i0 (stored as such); I is a multiple of 32
+            float xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = X[(size_t)(c + u) * ldx + t];
 #pragma unroll
             for (int r = 0; r < TRB; ++r) {
-                const float4 tv = *reinterpret_cast<const float4*>(Ts + r * ld + c);
-                acc[r] = fmaf(-tv.x, x0, fmaf(-tv.y, x1, fmaf(-tv.z, x2, fmaf(-tv.w, x3, acc[r]))));
+                const float4 ta = *reinterpret_cast<const float4*>(Ts + r * ld + c);
+                const float4 tb = *reinterpret_cast<const float4*>(Ts + r * ld + c + 4);
+                float sv = fmaf(-ta.x, xv[0], fmaf(-ta.y, xv[1], fmaf(-ta.z, xv[2], fmaf(-ta.w, xv[3], acc[r]))));
+                acc[r] = fmaf(-tb.x, xv[4], fmaf(-tb.y, xv[5], fmaf(-tb.z, xv[6], fmaf(-tb.w, xv[7], sv))));
             }
         }
 #pragma unroll
@@ -441,15 +451,20 @@ __device__ bool blk_cholesky(int D, ElemF a, float* W, float* lds) {
         if (mine) {
 #pragma unroll
             for (int r = 0; r < TRB; ++r) acc[r] = (r < nbk && J + r <= i) ? a(i, J + r) : 0.f;
-            for (int c = 0; c < J; ++c) {
-                const float wv = W[(size_t)c * D + i];
+            for (int c = 0; c < J; c += 8) {                   // J is a multiple of 32; eight loads in flight
+                float wv[8];
 #pragma unroll
-                for (int r4 = 0; r4 < TRB / 4; ++r4) {
-                    const float4 bv = *reinterpret_cast<const float4*>(Wb + c * TRB + 4 * r4);
-                    acc[4 * r4] = fmaf(-wv, bv.x, acc[4 * r4]);
-                    acc[4 * r4 + 1] = fmaf(-wv, bv.y, acc[4 * r4 + 1]);
-                    acc[4 * r4 + 2] = fmaf(-wv, bv.z, acc[4 * r4 + 2]);
-                    acc[4 * r4 + 3] = fmaf(-wv, bv.w, acc[4 * r4 + 3]);
+                for (int u = 0; u < 8; ++u) wv[u] = W[(size_t)(c + u) * D + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                    for (int r4 = 0; r4 < TRB / 4; ++r4) {
+                        const float4 bv = *reinterpret_cast<const float4*>(Wb + (c + u) * TRB + 4 * r4);
+                        acc[4 * r4] = fmaf(-wv[u], bv.x, acc[4 * r4]);
+                        acc[4 * r4 + 1] = fmaf(-wv[u], bv.y, acc[4 * r4 + 1]);
+                        acc[4 * r4 + 2] = fmaf(-wv[u], bv.z, acc[4 * r4 + 2]);
+                        acc[4 * r4 + 3] = fmaf(-wv[u], bv.w, acc[4 * r4 + 3]);
+                    }
                 }
             }
             if (i < J + nbk) {
@@ -805,6 +820,17 @@ __global__ __launch_bounds__(1024) void blk_stein_weights_kernel(int N, int k0, 
     if (threadIdx.x == 0) Mk[kb] = M;
 }
 
+// dst[b][e] = sum_s src[b * S + s][e]: partial augmented matrices of the sample ranges, fixed order
+__global__ __launch_bounds__(256) void blk_sum_slabs_kernel(int S, size_t slab, const float* __restrict__ src,
+                                                            float* __restrict__ dst) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= slab) return;
+    const float* p = src + (size_t)blockIdx.y * S * slab + e;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += p[(size_t)s * slab];
+    dst[(size_t)blockIdx.y * slab + e] = a;
+}
+
 __global__ __launch_bounds__(256) void blk_stein_finalize_kernel(int D, int N, int flags, const float* __restrict__ Araw,
                                                                  const float* __restrict__ T, const float* __restrict__ Mk,
                                                                  float* __restrict__ H_neg, float* __restrict__ g_neg) {
@@ -833,13 +859,22 @@ int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
     const int Kc = (int)(kc < 1 ? 1 : (kc > (size_t)K ? (size_t)K : kc));
     const size_t f_z = (size_t)Kc * zrow, f_g = zrow, f_e = (size_t)Kc * N, f_m = ((size_t)Kc + 3) / 4 * 4;
     const size_t f_a = (size_t)Kc * LP * LP, f_t = (size_t)Kc * D * D;
-    BLK_TRY(gmmvi_ws_reserve(ctx, (f_z + f_g + f_e + f_m + f_a + f_t) * sizeof(float)));
+    // the contraction over the samples is split into S ranges per component so that the launch has ~8 workgroups per CU
+    // (a component alone has only ceil(LP/128) * ceil(LP/160) output tiles); the partial matrices are summed in fixed order
+    const int tiles = ((LP + 127) / 128) * ((LP + 159) / 160);
+    int S = (8 * ctx->num_cus + tiles * Kc - 1) / (tiles * Kc);
+    if (S > N / 256) S = N / 256;
+    if (S > 16) S = 16;
+    if (S < 1) S = 1;
+    const size_t f_p = S > 1 ? (size_t)Kc * S * LP * LP : 0;
+    BLK_TRY(gmmvi_ws_reserve(ctx, (f_z + f_g + f_e + f_m + f_a + f_t + f_p) * sizeof(float)));
     float* Z = (float*)ctx->ws;
     float* G1 = Z + f_z;
     float* e = G1 + f_g;
     float* Mk = e + f_e;
     float* Araw = Mk + f_m;
     float* T = Araw + f_a;
+    float* Apart = T + f_t;
     hipLaunchKernelGGL(blk_stein_g_kernel, dim3((unsigned)((zrow + 255) / 256)), dim3(256), 0, ctx->stream, N, D, LP, tgrad, qgrad,
                        G1);
     GMMVI_LAUNCH_CHECK(ctx);
@@ -856,10 +891,16 @@ int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
             g.A = G1; g.lda = LP; g.sA = 0; g.a_kmajor = 1;             // opA(m = a, k = n) = G1[n][a]
             g.a_kscale = e; g.s_aks = N;
             g.B = Z; g.ldb = LP; g.sB = (long long)zrow; g.b_kmajor = 1;  // opB(k = n, n = b) = Z1[n][b]
-            g.C = Araw; g.ldc = LP; g.sC = (long long)LP * LP;
-            g.M = LP; g.N = LP; g.Kd = N;
+            g.C = S > 1 ? Apart : Araw; g.ldc = LP; g.sC = (long long)LP * LP;
+            g.M = LP; g.N = LP; g.Kd = N; g.ksplit = S;
             GMMVI_PROF(ctx, "blocked_stein_accumulate");
             BLK_TRY(bgemm(ctx, g, kn));
+            if (S > 1) {
+                const size_t slab = (size_t)LP * LP;
+                hipLaunchKernelGGL(blk_sum_slabs_kernel, dim3((unsigned)((slab + 255) / 256), kn), dim3(256), 0, ctx->stream, S,
+                                   slab, Apart, Araw);
+                GMMVI_LAUNCH_CHECK(ctx);
+            }
         }
         {
             BG g = bg_zero();
