@@ -5,7 +5,7 @@
 #pragma once
 #include "common.h"
 
-#define GMMVI_BLOCKED_MAX_DIM 512
+#define GMMVI_BLOCKED_MAX_DIM GMMVI_MAX_DIM_BLOCKED
 
 inline bool gmmvi_is_blocked_dim(int D) { return D > GMMVI_MAX_DIM && D <= GMMVI_BLOCKED_MAX_DIM; }
 inline int gmmvi_blocked_linv_ofs(int D) { return ((D + 1 + 3) / 4) * 4; }

@@ -51,7 +51,10 @@ enum gmmvi_stein_flags {
 };
 
 #define GMMVI_MORE_MAX_DIM 21  /* gmmvi_more: the F x F ridge system (F = D(D+1)/2 + D + 1) is factorised in LDS */
-#define GMMVI_MAX_DIM 64       /* register-resident kernels: D <= 64 (D = 300 needs the blocked path) */
+#define GMMVI_MAX_DIM 64       /* register-resident kernels: D <= 64 */
+#define GMMVI_MAX_DIM_BLOCKED 512   /* 64 < D <= 512: blocked kernels (dense L^-1 blocks, fp32 MFMA contractions)
+                                     * behind gmmvi_packed_stride / pack_components / cholesky / mixture_eval(_dual) /
+                                     * sample_components / stein / update_components_kl */
 
 /* ---- context, errors, memory ------------------------------------------------------------------------ */
 int gmmvi_device_count(void);
@@ -101,8 +104,9 @@ int gmmvi_profile_enable(gmmvi_ctx* ctx, int on);
 int gmmvi_profile_report(gmmvi_ctx* ctx, char* buf, size_t buf_size);
 
 /* ---- component parameter blocks ---------------------------------------------------------------------- */
-/* Number of floats of one packed component block for dimension D (padded dimension, reciprocal diagonal,
- * row- and column-packed strict lower triangle of L, log-normaliser). */
+/* Number of floats of one packed component block for dimension D (D <= 64: padded dimension, reciprocal diagonal,
+ * row- and column-packed strict lower triangle of L, log-normaliser; 64 < D <= 512: mu, log-normaliser, dense L^-1).
+ * 0 for an unsupported dimension. */
 size_t gmmvi_packed_stride(int D);
 /* Pack K components (means[K,D], chols[K,D,D] lower-triangular dense) for the density kernels.
  * family/nu select the log-normaliser (Gaussian: full_cov_gmm.py:60-61; Student-t: student_t_mixture.py:40-44).
