@@ -66,7 +66,9 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert not extra, f"bound but not declared in the header: {sorted(extra)}"
     # argument-free query works without a GPU
     assert built_lib.gmmvi_packed_stride(20) == ((2 * 20 + 20 * 19 + 1 + 3) // 4) * 4
-    assert built_lib.gmmvi_packed_stride(65) == 0
+    assert built_lib.gmmvi_packed_stride(65) == 68 + 65 * 65          # blocked path: [mu, const, pad to 4 | L^-1]
+    assert built_lib.gmmvi_packed_stride(300) == 304 + 300 * 300
+    assert built_lib.gmmvi_packed_stride(513) == 0
     assert built_lib.gmmvi_device_count() >= 0
 
 
