@@ -970,75 +970,136 @@ __global__ __launch_bounds__(256) void blk_upd_sym_kernel(int D, const float* __
 }
 
 // Householder tridiagonalisation of the symmetric M (in place) with the reflectors applied to wt.  Thread (i, grp): column
-// i of the trailing block, rows j = c+1+grp, +G, ... (coalesced over i); partial products meet in LDS.
+// i of the trailing block, rows j = c+1+grp, +G, ... (coalesced over i, eight loads in flight); partial products meet in
+// LDS.  ONE sweep over the trailing block per step: the rank-2 update of step c (M -= v q^T + q v^T, exactly symmetric)
+// and the product M' v' for the reflector of step c+1 share it -- the next reflector only needs row c+1 of the updated
+// matrix, which is formed first (one element per thread).
 __global__ __launch_bounds__(1024) void blk_tridiag_kernel(int D, int DT, int G, float* __restrict__ Mall,
                                                            float* __restrict__ wt_all, float* __restrict__ td_all,
                                                            float* __restrict__ te_all) {
     extern __shared__ float sm[];
-    float* v = sm;
-    float* q = sm + D;
-    float* part = q + D;
+    float* va = sm;                       // reflector of the current step
+    float* vb = sm + D;                   // reflector of the next step
+    float* q = sm + 2 * D;
+    float* xn = sm + 3 * D;               // row c+1 of the updated matrix
+    float* part = sm + 4 * D;
     float* red = part + (size_t)G * DT;
     const int k = blockIdx.x, tid = threadIdx.x;
     const int i = tid % DT, grp = tid / DT;
     float* M = Mall + (size_t)k * D * D;
     float* te = te_all + (size_t)k * D;
-    float wti = (grp == 0 && i < D) ? wt_all[(size_t)k * D + i] : 0.f;
-    for (int c = 0; c + 2 < D; ++c) {
-        const float x1 = M[(size_t)c * D + c + 1];
-        const bool mine = grp == 0 && i > c && i < D;
-        const float xi = mine ? M[(size_t)c * D + i] : 0.f;
+    const bool g0 = grp == 0 && i < D;
+    float wti = g0 ? wt_all[(size_t)k * D + i] : 0.f;
+
+    // reflector for column c from its sub-diagonal part x (x_i = value of thread i, group 0): v_i, beta; alpha or the
+    // untouched sub-diagonal entry goes to te[c].  All results block-uniform except vi.
+    float beta = 0.f, vi = 0.f, p = 0.f;
+    auto make_reflector = [&](int c, float xi, float x1, float* vdst) {
+        const bool mine = g0 && i > c;
         const float tail = block_sum((mine && i > c + 1) ? xi * xi : 0.f, red);
+        float v_here = 0.f;
         if (!(tail > 0.f)) {                       // column already tridiagonal (NaN lands here too: handled by the search)
+            beta = 0.f;
             if (tid == 0) te[c] = x1;
-            continue;
+        } else {
+            const float nrm = sqrtf(tail + x1 * x1);
+            const float alpha = (x1 > 0.f) ? -nrm : nrm;
+            beta = 1.f / (nrm * nrm - alpha * x1);
+            v_here = mine ? (i == c + 1 ? x1 - alpha : xi) : 0.f;
+            if (tid == 0) te[c] = alpha;
         }
-        const float nrm = sqrtf(tail + x1 * x1);
-        const float alpha = (x1 > 0.f) ? -nrm : nrm;
-        const float beta = 1.f / (nrm * nrm - alpha * x1);
-        const float vi = mine ? (i == c + 1 ? x1 - alpha : xi) : 0.f;
-        if (grp == 0 && i < D) v[i] = vi;
+        if (g0) vdst[i] = v_here;
+        return v_here;
+    };
+
+    if (D >= 3) {
+        // step 0: reflector of column 0, p = beta M v by a plain sweep
+        const float x1 = M[1];
+        const float xi = (g0 && i > 0) ? M[i] : 0.f;
+        vi = make_reflector(0, xi, x1, va);
         __syncthreads();
         float a0 = 0.f;
-        if (i > c && i < D) {
-            float av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};         // eight loads in flight per thread
-            int j = c + 1 + grp;
+        if (i > 0 && i < D) {
+            float av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int j = 1 + grp;
             for (; j + 7 * G < D; j += 8 * G) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) av[u] = fmaf(M[(size_t)(j + u * G) * D + i], v[j + u * G], av[u]);
+                for (int u = 0; u < 8; ++u) av[u] = fmaf(M[(size_t)(j + u * G) * D + i], va[j + u * G], av[u]);
             }
-            for (; j < D; j += G) a0 = fmaf(M[(size_t)j * D + i], v[j], a0);
+            for (; j < D; j += G) a0 = fmaf(M[(size_t)j * D + i], va[j], a0);
             a0 += ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
         }
         part[grp * DT + i] = a0;
         __syncthreads();
-        float p = 0.f;
-        if (mine) {
+        p = 0.f;
+        if (g0 && i > 0) {
             for (int gi = 0; gi < G; ++gi) p += part[gi * DT + i];
             p *= beta;
         }
+    }
+    float* v = va;
+    float* v2 = vb;
+    for (int c = 0; c + 2 < D; ++c) {
         const float kk = 0.5f * beta * block_sum(vi * p, red);
         const float wdot = beta * block_sum(vi * wti, red);
-        if (grp == 0 && i < D) q[i] = mine ? p - kk * vi : 0.f;
+        if (g0) q[i] = (i > c) ? p - kk * vi : 0.f;
         wti -= wdot * vi;
         __syncthreads();
+        const bool more = c + 3 < D;                   // another reflector follows
+        float beta_n = 0.f, vi_n = 0.f;
+        if (more) {
+            // row c+1 of the updated matrix: its entries right of the diagonal are the next column
+            float xv = 0.f;
+            if (g0 && i > c) {
+                xv = M[(size_t)(c + 1) * D + i] - __fadd_rn(__fmul_rn(v[c + 1], q[i]), __fmul_rn(q[c + 1], v[i]));
+                xn[i] = xv;
+            }
+            __syncthreads();
+            const float x1n = xn[c + 2];
+            const float beta_keep = beta;
+            vi_n = make_reflector(c + 1, (g0 && i > c + 1) ? xv : 0.f, x1n, v2);
+            beta_n = beta;
+            beta = beta_keep;
+            __syncthreads();
+        }
+        // one sweep: M[j][i] -= v_j q_i + q_j v_i, and the partial product with the next reflector
+        float a0 = 0.f;
         if (i > c && i < D) {
             const float vi2 = v[i], qi2 = q[i];
+            float av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             int j = c + 1 + grp;
             for (; j + 7 * G < D; j += 8 * G) {
                 float mv[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) mv[u] = M[(size_t)(j + u * G) * D + i];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    M[(size_t)(j + u * G) * D + i] = mv[u] - __fadd_rn(__fmul_rn(v[j + u * G], qi2), __fmul_rn(q[j + u * G], vi2));
+                for (int u = 0; u < 8; ++u) {
+                    const int jj = j + u * G;
+                    const float m = mv[u] - __fadd_rn(__fmul_rn(v[jj], qi2), __fmul_rn(q[jj], vi2));
+                    M[(size_t)jj * D + i] = m;
+                    if (more) av[u] = fmaf(m, v2[jj], av[u]);
+                }
             }
-            for (; j < D; j += G) M[(size_t)j * D + i] -= __fadd_rn(__fmul_rn(v[j], qi2), __fmul_rn(q[j], vi2));
+            for (; j < D; j += G) {
+                const float m = M[(size_t)j * D + i] - __fadd_rn(__fmul_rn(v[j], qi2), __fmul_rn(q[j], vi2));
+                M[(size_t)j * D + i] = m;
+                if (more) a0 = fmaf(m, v2[j], a0);
+            }
+            a0 += ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
         }
-        if (tid == 0) te[c] = alpha;
+        part[grp * DT + i] = a0;
         __syncthreads();
+        p = 0.f;
+        if (more && g0 && i > c + 1) {
+            for (int gi = 0; gi < G; ++gi) p += part[gi * DT + i];
+            p *= beta_n;
+        }
+        beta = beta_n;
+        vi = vi_n;
+        float* tsw = v; v = v2; v2 = tsw;
     }
-    if (grp == 0 && i < D) {
+    __syncthreads();
+    if (g0) {
         td_all[(size_t)k * D + i] = M[(size_t)i * D + i];
         wt_all[(size_t)k * D + i] = wti;
         if (i == D - 1 && D >= 2) te[D - 2] = M[(size_t)(D - 1) * D + D - 2];
@@ -1267,7 +1328,7 @@ int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* c
         const int DT = blk_threads(D);
         int G = 1024 / DT;
         if (G < 1) G = 1;
-        const size_t shmem = ((size_t)2 * D + (size_t)G * DT + 32) * sizeof(float);
+        const size_t shmem = ((size_t)4 * D + (size_t)G * DT + 32) * sizeof(float);
         hipLaunchKernelGGL(blk_tridiag_kernel, dim3(K), dim3(G * DT), shmem, ctx->stream, D, DT, G, M, wt, td, te);
         GMMVI_LAUNCH_CHECK(ctx);
     }

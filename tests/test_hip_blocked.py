@@ -200,3 +200,21 @@ def test_blocked_trajectory_matches_oracle(kind, d, k, s):
     """GMMVI.train_iter() at D > 64 (modular plug-in path over the blocked kernels) against the oracle, same draws."""
     cfg = samtron_config(s)
     run_pair(kind, d, k, s, seed=11, iters=4, cfg=cfg, tol_scale=2.0)
+
+
+def test_blocked_runner_flow_stm300():
+    """The shipped 300-dimensional Student-t experiment (stm300.yml) through GmmviRunner with the SAMTRON defaults:
+    sample reuse, adaptive number of components, Student-t target -- every module on the blocked kernels."""
+    from gmmvi.gmmvi_runner import GmmviRunner
+    from gmmvi.configs import update_config, get_default_experiment_config, get_default_algorithm_config
+    config = update_config(update_config(get_default_experiment_config("stm300"), {"start_seed": 0}),
+                           update_config(get_default_algorithm_config("SAMTRON"),
+                                         {"gmmvi_runner_config": {"log_metrics_interval": 5}}))
+    runner = GmmviRunner.build_from_config(config=config)
+    elbos = []
+    for n in range(16):
+        m = runner.iterate_and_log(n)
+        if "-elbo" in m:
+            elbos.append(-m["-elbo"])
+    assert len(elbos) >= 3 and all(np.isfinite(elbos)) and elbos[-1] > elbos[0]
+    assert runner.gmmvi.model.num_dimensions == 300

@@ -85,12 +85,13 @@ class _ThreadExchange:
         return v
 
 
-def test_two_virtual_ranks_match_single_rank():
+@pytest.mark.parametrize("kind,d,k,s,iters", [("stm", 6, 8, 40, 5), ("gmm", 72, 4, 48, 3)])     # D = 72: blocked kernels
+def test_two_virtual_ranks_match_single_rank(kind, d, k, s, iters):
     import threading
     from gmmvi_amd.device import get_context
     from gmmvi_amd.sharded import ShardedGMMVI, HipOps, LocalExchange
     from gmmvi_amd import hip_ops
-    kind, d, k, s, seed, iters = "stm", 6, 8, 40, 23, 5
+    seed = 23
     cfg = samtron_config(s)
     o = make_oracle(kind, d, k, s, seed, cfg)
     g = make_device(kind, d, k, s, seed, cfg, o)

@@ -1,6 +1,8 @@
 """Runs the flows of the reference's examples/5_samtron_20D_student-T.py and examples/6_samtron_planar4.py through the
 drop-in `gmmvi` alias (same config calls, same GmmviRunner loop), with an iteration cap instead of 1501 iterations /
-30 minutes.  Usage: python tools/run_example_flows.py [stm|planar] [iterations]"""
+30 minutes; `stm300` is the shipped 300-dimensional Student-t experiment (configs/experiment_configs/stm300.yml) with the
+SAMTRON defaults (sample reuse, adaptive number of components) on the blocked path.
+Usage: python tools/run_example_flows.py [stm|planar|stm300] [iterations]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gmmvi.gmmvi_runner import GmmviRunner
@@ -17,6 +19,9 @@ if which == "stm":
             "weight_stepsize_adapter_config": {"initial_stepsize": 1},
             "model_initialization": {"num_initial_components": 45},
             "gmmvi_runner_config": {"log_metrics_interval": 100}}
+elif which == "stm300":
+    environment_config = update_config(get_default_experiment_config("stm300"), {"start_seed": 0})
+    used = {"gmmvi_runner_config": {"log_metrics_interval": 10}}
 else:
     environment_config = update_config(get_default_experiment_config("planar_robot_4"), {"start_seed": 0})
     used = {"num_component_adapter_config": {"del_iters": 10, "add_iters": 1},
