@@ -40,7 +40,8 @@ struct BG {
     const float* a_rscale; long long s_ars;      // [M]   A(m, k) *= a_rscale[m]
     const float* c_bias; long long s_cb;         // [N]   C(m, n) += c_bias[n]
     const int32_t* row_off;          // optional [batches + 1]: batch b owns rows [row_off[b], row_off[b+1]) of A and C (M = bound)
-    int inner;                       // > 0: this many consecutive batches are accumulated into ONE C (grid.z = 1)
+    int inner;                       // > 0: workgroup z accumulates the batches [z * inner, min((z+1) * inner, inner_total)) into slab z of C
+    int inner_total;
     int tri;                         // 1: opB(k, n) = 0 for k > n   2: opB(k, n) = 0 for k < n
     int accumulate;                  // C += result
     int ksplit;                      // > 1: grid.z = batches * ksplit, slab z of C receives the partial sum over its k range
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
         ke = min(g.Kd, kb + chunk);
     }
     const int spb = (ke - kb + BK - 1) / BK;
-    const int nb = g.inner > 0 ? g.inner : 1;
+    const int nb = g.inner > 0 ? min(g.inner, g.inner_total - bz * g.inner) : 1;
     const int total = nb * spb;
     const float* A0 = g.A + (AK ? rowbase : rowbase * g.lda);
     const float* pro = PRO == 1 ? g.a_sub : (PRO == 2 ? g.a_rscale : (PRO == 3 ? g.a_kscale : nullptr));
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
     auto gload = [&](int step) {
         pending = false;
         const int bi = step / spb;
-        const long long b = (long long)bz * nb + bi;
+        const long long b = (long long)bz * (g.inner > 0 ? g.inner : 1) + bi;
         const int k0 = kb + (step - bi * spb) * BK;
         const float* Ab = A0 + b * g.sA;
         const float* Bb = g.B + b * g.sB;
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
     }
     // the last MFMA (16 passes) must have retired before its accumulators are read (inline asm: no automatic hazard nops)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    float* Cb = g.C + (g.inner > 0 ? 0 : (long long)blockIdx.z * g.sC) + rowbase * g.ldc;
+    float* Cb = g.C + (long long)blockIdx.z * g.sC + rowbase * g.ldc;
     const float* bias = g.c_bias ? g.c_bias + (long long)bz * g.s_cb : nullptr;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -627,6 +628,17 @@ __global__ __launch_bounds__(256) void blk_resp_kernel(int family, float nu, int
     rw[e] = r * coef;
 }
 
+// dst[b][e] (+)= sum_s src[b * S + s][e]: partial results of a split contraction, summed in fixed order
+__global__ __launch_bounds__(256) void blk_sum_slabs_kernel(int S, size_t slab, const float* __restrict__ src,
+                                                            float* __restrict__ dst, int accumulate) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= slab) return;
+    const float* p = src + (size_t)blockIdx.y * S * slab + e;
+    float a = accumulate ? dst[(size_t)blockIdx.y * slab + e] : 0.f;
+    for (int s = 0; s < S; ++s) a += p[(size_t)s * slab];
+    dst[(size_t)blockIdx.y * slab + e] = a;
+}
+
 __global__ void blk_mapping_kernel(int K, const int32_t* __restrict__ offsets, int32_t* __restrict__ mapping) {
     const int k = blockIdx.x;
     const int begin = offsets[k], end = offsets[k + 1];
@@ -698,12 +710,24 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     const int nchunks = (K + Kc - 1) / Kc;
     const size_t f_z = (size_t)Kc * zrow, f_q = (size_t)Kc * N, f_rw = grad ? (size_t)Kc * N : 0;
     const size_t f_ld = (!ld_out && need_lse) ? (size_t)K * N : 0, f_lp = (grad && !lp) ? (size_t)N : 0;
-    BLK_TRY(gmmvi_ws_reserve(ctx, (f_z + f_q + f_rw + f_ld + f_lp) * sizeof(float)));
+    // gradient: the component loop runs inside the workgroups of one [N, D] tile grid; with few tiles it is split into S
+    // component ranges (≈8 workgroups per CU), each writing a partial gradient
+    int S = 1;
+    if (grad) {
+        const int tiles = ((N + 127) / 128) * ((D + 159) / 160);
+        S = (8 * ctx->num_cus + tiles - 1) / tiles;
+        if (S > Kc / 4) S = Kc / 4;
+        if (S > 16) S = 16;
+        if (S < 1) S = 1;
+    }
+    const size_t f_gp = S > 1 ? (size_t)S * zrow : 0;
+    BLK_TRY(gmmvi_ws_reserve(ctx, (f_z + f_q + f_rw + f_ld + f_lp + f_gp) * sizeof(float)));
     float* Z = (float*)ctx->ws;
     float* q = Z + f_z;
     float* rw = q + f_q;
     float* ldp = ld_out ? ld_out : (f_ld ? rw + f_rw : nullptr);
     float* lpp = lp ? lp : (f_lp ? rw + f_rw + f_ld : nullptr);
+    float* gpart = rw + f_rw + f_ld + f_lp;
     auto rowsq = [&](int k0, int kn, bool write_ld) {
         const long long rows = (long long)kn * N;
         GMMVI_PROF(ctx, "blocked_rowsq");
@@ -737,10 +761,20 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
             g.A = Z; g.lda = D; g.sA = (long long)zrow; g.a_kmajor = 0;
             g.a_rscale = rw; g.s_ars = N;
             g.B = packed + (size_t)k0 * ps + gmmvi_blocked_linv_ofs(D); g.ldb = D; g.sB = (long long)ps; g.b_kmajor = 1;
-            g.C = grad; g.ldc = D;
-            g.M = N; g.N = D; g.Kd = D; g.tri = 2; g.inner = kn; g.accumulate = c > 0;
+            g.ldc = D;
+            g.M = N; g.N = D; g.Kd = D; g.tri = 2; g.inner_total = kn;
             GMMVI_PROF(ctx, "blocked_grad");
-            BLK_TRY(bgemm(ctx, g, 1));
+            if (S > 1) {                       // component ranges over blockIdx.z, partial gradients summed in fixed order
+                g.C = gpart; g.sC = (long long)zrow; g.inner = (kn + S - 1) / S;
+                const int nz = (kn + g.inner - 1) / g.inner;
+                BLK_TRY(bgemm(ctx, g, nz));
+                hipLaunchKernelGGL(blk_sum_slabs_kernel, dim3((unsigned)((zrow + 255) / 256), 1), dim3(256), 0, ctx->stream, nz,
+                                   zrow, gpart, grad, c > 0 ? 1 : 0);
+                GMMVI_LAUNCH_CHECK(ctx);
+            } else {
+                g.C = grad; g.sC = 0; g.inner = kn; g.accumulate = c > 0;
+                BLK_TRY(bgemm(ctx, g, 1));
+            }
         }
     }
     return GMMVI_OK;
@@ -820,17 +854,6 @@ __global__ __launch_bounds__(1024) void blk_stein_weights_kernel(int N, int k0, 
     if (threadIdx.x == 0) Mk[kb] = M;
 }
 
-// dst[b][e] = sum_s src[b * S + s][e]: partial augmented matrices of the sample ranges, fixed order
-__global__ __launch_bounds__(256) void blk_sum_slabs_kernel(int S, size_t slab, const float* __restrict__ src,
-                                                            float* __restrict__ dst) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= slab) return;
-    const float* p = src + (size_t)blockIdx.y * S * slab + e;
-    float a = 0.f;
-    for (int s = 0; s < S; ++s) a += p[(size_t)s * slab];
-    dst[(size_t)blockIdx.y * slab + e] = a;
-}
-
 __global__ __launch_bounds__(256) void blk_stein_finalize_kernel(int D, int N, int flags, const float* __restrict__ Araw,
                                                                  const float* __restrict__ T, const float* __restrict__ Mk,
                                                                  float* __restrict__ H_neg, float* __restrict__ g_neg) {
@@ -898,7 +921,7 @@ int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
             if (S > 1) {
                 const size_t slab = (size_t)LP * LP;
                 hipLaunchKernelGGL(blk_sum_slabs_kernel, dim3((unsigned)((slab + 255) / 256), kn), dim3(256), 0, ctx->stream, S,
-                                   slab, Apart, Araw);
+                                   slab, Apart, Araw, 0);
                 GMMVI_LAUNCH_CHECK(ctx);
             }
         }
