@@ -126,8 +126,8 @@ def parse_profile(ctx):
     ctx.check(ctx.lib.gmmvi_profile_report(ctx.handle, buf, len(buf)))
     out = {}
     for line in buf.value.decode().splitlines():
-        name, cnt, ms = line.split()
-        out[name] = (int(cnt), float(ms))
+        name, cnt, ms, pairs = line.split()
+        out[name] = (int(cnt), float(ms), float(pairs))
     return out
 
 
@@ -180,12 +180,18 @@ def main():
         algo.train_iter()
     prof = parse_profile(ctx)
     ctx.check(ctx.lib.gmmvi_profile_enable(ctx.handle, 0))
-    kernels = {name: {"launches_per_step": c / prof_steps, "avg_us": 1e3 * ms / c} for name, (c, ms) in prof.items()}
+    kernels = {name: {"launches_per_step": c / prof_steps, "avg_us": 1e3 * ms / c, **({"pairs_per_launch": pr / c} if pr else {})}
+               for name, (c, ms, pr) in prof.items()}
     k_local = w["k_total"] // n_gpus
     dominant = max(kernels, key=lambda nme: kernels[nme]["avg_us"] * kernels[nme]["launches_per_step"])
     roof_name = max((nme for nme in kernels if kernel_flops(nme, 1, 1, 1) is not None),
                     key=lambda nme: kernels[nme]["avg_us"] * kernels[nme]["launches_per_step"])
-    fl = kernel_flops(roof_name, w["n_total"], k_local, w["d"])
+    # kernels that report the pairs they processed (launches of different sizes share a name on the blocked path: the target
+    # has one component, the model 64) are priced on those pairs; the others on the workload's N x K
+    if "pairs_per_launch" in kernels[roof_name]:
+        fl = kernel_flops(roof_name, kernels[roof_name]["pairs_per_launch"], 1, w["d"])
+    else:
+        fl = kernel_flops(roof_name, w["n_total"], k_local, w["d"])
     achieved = fl / (kernels[roof_name]["avg_us"] * 1e-6) / 1e12
     roof_peak = PEAK_FP64_MFMA_TFLOPS if roof_name == "more_gram" else PEAK_FP32_TFLOPS
     d, n_tot, k_tot = w["d"], w["n_total"], w["k_total"]

@@ -5,6 +5,7 @@
 std::string g_gmmvi_global_err;
 
 int gmmvi_ws_reserve(gmmvi_ctx* ctx, size_t nbytes) {
+    ++ctx->ws_epoch;
     if (nbytes <= ctx->ws_bytes) return GMMVI_OK;
     // A grow frees the old block; earlier kernels on the stream may still read it, so drain first.
     GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -57,6 +58,7 @@ void gmmvi_ctx_destroy(gmmvi_ctx* ctx) {
     }
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->zc_hash) (void)hipFree(ctx->zc_hash);
     delete ctx;
 }
 
@@ -320,7 +322,7 @@ int gmmvi_profile_report(gmmvi_ctx* ctx, char* buf, size_t buf_size) {
     GMMVI_ARG_CHECK(ctx, buf && buf_size > 0);
     GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<std::string> names;
-    std::vector<double> total;
+    std::vector<double> total, units;
     std::vector<long> count;
     for (auto& r : ctx->prof_recs) {
         float ms = 0.f;
@@ -329,14 +331,15 @@ int gmmvi_profile_report(gmmvi_ctx* ctx, char* buf, size_t buf_size) {
         (void)hipEventDestroy(r.stop);
         size_t i = 0;
         for (; i < names.size(); ++i) if (names[i] == r.name) break;
-        if (i == names.size()) { names.push_back(r.name); total.push_back(0.0); count.push_back(0); }
+        if (i == names.size()) { names.push_back(r.name); total.push_back(0.0); units.push_back(0.0); count.push_back(0); }
         total[i] += ms;
+        units[i] += r.units;
         count[i] += 1;
     }
     ctx->prof_recs.clear();
     std::string out;
     for (size_t i = 0; i < names.size(); ++i)
-        out += names[i] + " " + std::to_string(count[i]) + " " + std::to_string(total[i]) + "\n";
+        out += names[i] + " " + std::to_string(count[i]) + " " + std::to_string(total[i]) + " " + std::to_string(units[i]) + "\n";
     if (out.size() + 1 > buf_size) return gmmvi_fail(ctx, GMMVI_ERR_ARG, "gmmvi_profile_report: buffer too small");
     memcpy(buf, out.c_str(), out.size() + 1);
     return GMMVI_OK;

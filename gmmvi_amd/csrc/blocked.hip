@@ -45,6 +45,7 @@ struct BG {
     int tri;                         // 1: opB(k, n) = 0 for k > n   2: opB(k, n) = 0 for k < n
     int accumulate;                  // C += result
     int ksplit;                      // > 1: grid.z = batches * ksplit, slab z of C receives the partial sum over its k range
+    const int* skip;                 // optional device flag: non-zero = the result is already in place, do nothing
     float alpha;
 };
 
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
     constexpr int NVB = (BN * BK / 4 + 255) / 256;          // 16-byte pieces of the B tile per thread
     __shared__ __align__(16) float As[2][BK * LDA_S];
     __shared__ __align__(16) float Bs[2][BK * LDB_S];
+    if (g.skip != nullptr && *g.skip != 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
@@ -651,16 +653,49 @@ size_t z_budget_floats() {
     return e ? (size_t)atoll(e) / 4 : ((size_t)4 << 30) / 4;
 }
 
+// order-sensitive 64-bit content hash of n words: sum_i bits_i * odd(i) mod 2^64 (integer atomics: order-independent result)
+__global__ __launch_bounds__(256) void blk_hash_kernel(const uint32_t* __restrict__ data, size_t n, unsigned long long* out) {
+    __shared__ unsigned long long red[256];
+    unsigned long long h = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        h += (unsigned long long)data[i] * ((0x9E3779B97F4A7C15ull * (i + 1)) | 1ull);
+    red[threadIdx.x] = h;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+
+__global__ void blk_hash_match_kernel(unsigned long long* h) {
+    reinterpret_cast<int*>(h + 4)[0] = (h[0] == h[2] && h[1] == h[3]) ? 1 : 0;
+}
+
+// hashes of (component blocks, samples) into h[slot], h[slot + 1]
+int blk_hash_inputs(gmmvi_ctx* ctx, const float* packed, size_t n_packed, const float* X, size_t n_x, int slot) {
+    if (ctx->zc_hash == nullptr) GMMVI_HIP_CHECK(ctx, hipMalloc((void**)&ctx->zc_hash, 8 * sizeof(unsigned long long)));
+    GMMVI_HIP_CHECK(ctx, hipMemsetAsync(ctx->zc_hash + slot, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(blk_hash_kernel, dim3(512), dim3(256), 0, ctx->stream, reinterpret_cast<const uint32_t*>(packed), n_packed,
+                       ctx->zc_hash + slot);
+    hipLaunchKernelGGL(blk_hash_kernel, dim3(512), dim3(256), 0, ctx->stream, reinterpret_cast<const uint32_t*>(X), n_x,
+                       ctx->zc_hash + slot + 1);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
 // Z[kb][n][0:D] = (x_n - mu_k) L_k^-T for the components k0 .. k0 + kn - 1 (row stride ldz)
-int blk_forward(gmmvi_ctx* ctx, int D, const float* packed, int k0, int kn, const float* X, int N, float* Z, int ldz) {
+int blk_forward(gmmvi_ctx* ctx, int D, const float* packed, int k0, int kn, const float* X, int N, float* Z, int ldz,
+                const int* skip = nullptr) {
     const size_t ps = gmmvi_blocked_stride(D);
     BG g = bg_zero();
     g.A = X; g.lda = D; g.sA = 0; g.a_kmajor = 0;
     g.a_sub = packed + (size_t)k0 * ps; g.s_asub = (long long)ps;
     g.B = packed + (size_t)k0 * ps + gmmvi_blocked_linv_ofs(D); g.ldb = D; g.sB = (long long)ps; g.b_kmajor = 0;
     g.C = Z; g.ldc = ldz; g.sC = (long long)N * ldz;
-    g.M = N; g.N = D; g.Kd = D; g.tri = 1;
-    GMMVI_PROF(ctx, "blocked_forward");
+    g.M = N; g.N = D; g.Kd = D; g.tri = 1; g.skip = skip;
+    // a launch that may find Z in place (skip flag) is timed under its own name: it is not a whitening pass
+    GMMVI_PROF_UNITS(ctx, skip ? "blocked_forward_or_reuse" : "blocked_forward", skip ? 0.0 : (double)kn * N);
     return bgemm(ctx, g, kn);
 }
 
@@ -704,7 +739,8 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
                                const float* logw2, const float* X, int N, float* ld_out, float* lp, float* grad, float* lp2) {
     const size_t ps = gmmvi_blocked_stride(D);
     const bool need_lse = lp || grad || lp2;
-    const size_t zrow = (size_t)N * D;
+    const int LP = ((D + 1 + 3) / 4) * 4;                  // row stride of Z: the Stein estimate reuses it with [.; 1; 0..] appended
+    const size_t zrow = (size_t)N * LP, gslab = (size_t)N * D;
     size_t kc = z_budget_floats() / zrow;
     const int Kc = (int)(kc < 1 ? 1 : (kc > (size_t)K ? (size_t)K : kc));
     const int nchunks = (K + Kc - 1) / Kc;
@@ -720,7 +756,7 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         if (S > 16) S = 16;
         if (S < 1) S = 1;
     }
-    const size_t f_gp = S > 1 ? (size_t)S * zrow : 0;
+    const size_t f_gp = S > 1 ? (size_t)S * gslab : 0;
     BLK_TRY(gmmvi_ws_reserve(ctx, (f_z + f_q + f_rw + f_ld + f_lp + f_gp) * sizeof(float)));
     float* Z = (float*)ctx->ws;
     float* q = Z + f_z;
@@ -732,11 +768,11 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         const long long rows = (long long)kn * N;
         GMMVI_PROF(ctx, "blocked_rowsq");
         hipLaunchKernelGGL(blk_rowsq_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, ctx->stream, family, nu, D,
-                           N, rows, Z, D, packed + (size_t)k0 * ps, ps, q, (write_ld && ldp) ? ldp + (size_t)k0 * N : nullptr);
+                           N, rows, Z, LP, packed + (size_t)k0 * ps, ps, q, (write_ld && ldp) ? ldp + (size_t)k0 * N : nullptr);
     };
     for (int c = 0; c < nchunks; ++c) {
         const int k0 = c * Kc, kn = (K - k0 < Kc) ? K - k0 : Kc;
-        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, D));
+        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP));
         rowsq(k0, kn, true);
         GMMVI_LAUNCH_CHECK(ctx);
     }
@@ -749,7 +785,7 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         for (int c = 0; c < nchunks; ++c) {
             const int k0 = c * Kc, kn = (K - k0 < Kc) ? K - k0 : Kc;
             if (nchunks > 1) {
-                BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, D));
+                BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP));
                 rowsq(k0, kn, false);
                 GMMVI_LAUNCH_CHECK(ctx);
             }
@@ -758,24 +794,32 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
                                kn, ldp + (size_t)k0 * N, logw + k0, lpp, q, rw);
             GMMVI_LAUNCH_CHECK(ctx);
             BG g = bg_zero();
-            g.A = Z; g.lda = D; g.sA = (long long)zrow; g.a_kmajor = 0;
+            g.A = Z; g.lda = LP; g.sA = (long long)zrow; g.a_kmajor = 0;
             g.a_rscale = rw; g.s_ars = N;
             g.B = packed + (size_t)k0 * ps + gmmvi_blocked_linv_ofs(D); g.ldb = D; g.sB = (long long)ps; g.b_kmajor = 1;
             g.ldc = D;
             g.M = N; g.N = D; g.Kd = D; g.tri = 2; g.inner_total = kn;
-            GMMVI_PROF(ctx, "blocked_grad");
+            GMMVI_PROF_UNITS(ctx, "blocked_grad", (double)kn * N);
             if (S > 1) {                       // component ranges over blockIdx.z, partial gradients summed in fixed order
-                g.C = gpart; g.sC = (long long)zrow; g.inner = (kn + S - 1) / S;
+                g.C = gpart; g.sC = (long long)gslab; g.inner = (kn + S - 1) / S;
                 const int nz = (kn + g.inner - 1) / g.inner;
                 BLK_TRY(bgemm(ctx, g, nz));
-                hipLaunchKernelGGL(blk_sum_slabs_kernel, dim3((unsigned)((zrow + 255) / 256), 1), dim3(256), 0, ctx->stream, nz,
-                                   zrow, gpart, grad, c > 0 ? 1 : 0);
+                hipLaunchKernelGGL(blk_sum_slabs_kernel, dim3((unsigned)((gslab + 255) / 256), 1), dim3(256), 0, ctx->stream, nz,
+                                   gslab, gpart, grad, c > 0 ? 1 : 0);
                 GMMVI_LAUNCH_CHECK(ctx);
             } else {
                 g.C = grad; g.sC = 0; g.inner = kn; g.accumulate = c > 0;
                 BLK_TRY(bgemm(ctx, g, 1));
             }
         }
+    }
+    // hand-over to the Stein estimate of the same iteration (gmmvi_stein takes ld / qgrad "from gmmvi_mixture_eval on the same
+    // X"): Z of all components is at the start of the scratch; remember what it was computed from
+    ctx->zc.valid = false;
+    if (nchunks == 1 && ld_out != nullptr && grad != nullptr) {
+        BLK_TRY(blk_hash_inputs(ctx, packed, (size_t)K * ps, X, gslab, 0));
+        ctx->zc.valid = true; ctx->zc.epoch = ctx->ws_epoch; ctx->zc.ws = ctx->ws;
+        ctx->zc.K = K; ctx->zc.N = N; ctx->zc.D = D; ctx->zc.ldz = LP;
     }
     return GMMVI_OK;
 }
@@ -898,13 +942,24 @@ int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
     float* Araw = Mk + f_m;
     float* T = Araw + f_a;
     float* Apart = T + f_t;
+    // Z may still be in place from the density sweep that produced ld / qgrad: same scratch block, nothing reserved in
+    // between, same shapes -- and, decided on the device, identical content hashes of the component blocks and the samples
+    const int* skip = nullptr;
+    if (ctx->zc.valid && ctx->zc.epoch + 1 == ctx->ws_epoch && ctx->zc.ws == ctx->ws && ctx->zc.K == K && ctx->zc.N == N &&
+        ctx->zc.D == D && ctx->zc.ldz == LP && Kc == K) {
+        BLK_TRY(blk_hash_inputs(ctx, packed, (size_t)K * ps, X, (size_t)N * D, 2));
+        hipLaunchKernelGGL(blk_hash_match_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->zc_hash);
+        GMMVI_LAUNCH_CHECK(ctx);
+        skip = reinterpret_cast<const int*>(ctx->zc_hash + 4);
+    }
+    ctx->zc.valid = false;
     hipLaunchKernelGGL(blk_stein_g_kernel, dim3((unsigned)((zrow + 255) / 256)), dim3(256), 0, ctx->stream, N, D, LP, tgrad, qgrad,
                        G1);
     GMMVI_LAUNCH_CHECK(ctx);
     for (int k0 = 0; k0 < K; k0 += Kc) {
         const int kn = (K - k0 < Kc) ? K - k0 : Kc;
         const long long rows = (long long)kn * N;
-        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP));
+        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP, skip));
         hipLaunchKernelGGL(blk_fill_col_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, rows, D, LP, Z);
         hipLaunchKernelGGL(blk_stein_weights_kernel, dim3(kn), dim3(1024), 0, ctx->stream, N, k0, ld, bg, mapping, map_offset,
                            flags, e, Mk);
@@ -916,7 +971,7 @@ int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
             g.B = Z; g.ldb = LP; g.sB = (long long)zrow; g.b_kmajor = 1;  // opB(k = n, n = b) = Z1[n][b]
             g.C = S > 1 ? Apart : Araw; g.ldc = LP; g.sC = (long long)LP * LP;
             g.M = LP; g.N = LP; g.Kd = N; g.ksplit = S;
-            GMMVI_PROF(ctx, "blocked_stein_accumulate");
+            GMMVI_PROF_UNITS(ctx, "blocked_stein_accumulate", (double)kn * N);
             BLK_TRY(bgemm(ctx, g, kn));
             if (S > 1) {
                 const size_t slab = (size_t)LP * LP;

@@ -15,6 +15,13 @@ struct gmmvi_ctx {
     // scratch reused by multi-kernel entry points (grown on demand, never shrunk)
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    // Every gmmvi_ws_reserve starts a new epoch of the scratch: contents survive from one entry point to the next only by
+    // the explicit hand-over below.  Blocked path: the whitened samples Z of the last single-chunk density sweep stay at the
+    // start of ws; the Stein estimate that follows reuses them when the scratch is untouched and 64-bit content hashes of
+    // (component blocks, samples) match (blocked.hip).
+    uint64_t ws_epoch = 0;
+    struct ZCache { bool valid = false; uint64_t epoch = 0; const void* ws = nullptr; int K = 0, N = 0, D = 0, ldz = 0; } zc;
+    unsigned long long* zc_hash = nullptr;       // device: [0,1] recorded with Z, [2,3] current call, [4] match flag
     void* arena = nullptr;       // persistent scratch of the single-call iteration (fused.hip)
     size_t arena_bytes = 0;
     void* comm = nullptr;        // ncclComm_t
@@ -22,22 +29,23 @@ struct gmmvi_ctx {
     int num_cus = 256;
     // optional per-kernel HIP-event timing (bench.py roofline leg): events are recorded on ctx->stream
     bool prof = false;
-    struct ProfRec { const char* name; hipEvent_t start, stop; };
+    struct ProfRec { const char* name; hipEvent_t start, stop; double units; };   // units: (sample, component) pairs of the launch
     std::vector<ProfRec> prof_recs;
 };
 
 struct GmmviProfScope {
     gmmvi_ctx* ctx; hipEvent_t stop = nullptr;
-    GmmviProfScope(gmmvi_ctx* c, const char* name) : ctx(c) {
+    GmmviProfScope(gmmvi_ctx* c, const char* name, double units = 0.0) : ctx(c) {
         if (!c->prof) return;
         hipEvent_t start;
         if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) { stop = nullptr; return; }
         (void)hipEventRecord(start, c->stream);
-        c->prof_recs.push_back({name, start, stop});
+        c->prof_recs.push_back({name, start, stop, units});
     }
     ~GmmviProfScope() { if (stop) (void)hipEventRecord(stop, ctx->stream); }
 };
 #define GMMVI_PROF(ctx, name) GmmviProfScope prof_scope__(ctx, name)
+#define GMMVI_PROF_UNITS(ctx, name, units) GmmviProfScope prof_scope__(ctx, name, units)
 
 extern std::string g_gmmvi_global_err;
 

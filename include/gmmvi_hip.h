@@ -99,7 +99,8 @@ int gmmvi_event_elapsed_ms(gmmvi_ctx* ctx, void* start, void* stop, float* out_m
 
 /* Per-kernel timing for bench.py's roofline leg: while enabled, every kernel-launching entry point brackets its
  * launches with HIP events on the context's stream.  gmmvi_profile_report synchronises, writes one line per kernel
- * name ("name count total_ms\n") into buf and clears the records. */
+ * name ("name count total_ms total_pairs\n"; total_pairs = (sample, component) pairs processed, 0 where not counted) into
+ * buf and clears the records. */
 int gmmvi_profile_enable(gmmvi_ctx* ctx, int on);
 int gmmvi_profile_report(gmmvi_ctx* ctx, char* buf, size_t buf_size);
 

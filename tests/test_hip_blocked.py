@@ -218,3 +218,32 @@ def test_blocked_runner_flow_stm300():
             elbos.append(-m["-elbo"])
     assert len(elbos) >= 3 and all(np.isfinite(elbos)) and elbos[-1] > elbos[0]
     assert runner.gmmvi.model.num_dimensions == 300
+
+
+def test_blocked_stein_reuses_whitened_samples_only_when_inputs_match(ctx, rng):
+    """The Stein estimate reuses the whitened samples left in the scratch by the density sweep that produced ld / qgrad,
+    guarded by device-side content hashes: stale scratch (same pointers, different contents) is recomputed."""
+    k, d, n = 3, 72, 400
+    m, x2, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
+    x1 = x2 + rng.normal(size=x2.shape)
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    bgd, tgd = ctx.asarray(bg), ctx.asarray(tg)
+    x2d = ctx.asarray(x2)
+    ld2, _, qg2 = ops().mixture_eval(ctx, packed, logw, x2d, d, want_ld=True, want_grad=True)
+    h_ref, g_ref = ops().stein(ctx, packed, x2d, ld2, qg2, bgd, tgd, d)          # reuse: same contents
+    # defeat the hand-over (another scratch user in between): same result bit for bit
+    ld2b, _, qg2b = ops().mixture_eval(ctx, packed, logw, x2d, d, want_ld=True, want_grad=True)
+    ops().mixture_eval(ctx, packed, logw, ctx.asarray(x1), d)
+    h_b, g_b = ops().stein(ctx, packed, x2d, ld2b, qg2b, bgd, tgd, d)
+    np.testing.assert_array_equal(h_b.numpy(), h_ref.numpy())
+    np.testing.assert_array_equal(g_b.numpy(), g_ref.numpy())
+    # stale scratch: the sweep ran on x1, then the SAME buffer is overwritten with x2
+    xbuf = ctx.asarray(x1)
+    ops().mixture_eval(ctx, packed, logw, xbuf, d, want_ld=True, want_grad=True)
+    xbuf.copy_from(x2d)
+    h_c, g_c = ops().stein(ctx, packed, xbuf, ld2, qg2, bgd, tgd, d)
+    np.testing.assert_array_equal(h_c.numpy(), h_ref.numpy())
+    np.testing.assert_array_equal(g_c.numpy(), g_ref.numpy())
+    rh, rg = ostein.get_expected_hessian_and_grad(m, x2, mapping, bg, tlp, tg, False, True)
+    assert np.all(np.abs(h_ref.numpy() - rh) <= 1e-2 * np.abs(rh).max(axis=(1, 2), keepdims=True) + 1e-6)
