@@ -353,6 +353,18 @@ __device__ __forceinline__ float block_sum(float v, float* red) {          // re
     for (int i = 0; i < nw; ++i) s += red[i];
     return s;
 }
+// two sums at the price of one (red: >= 32 floats)
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+    a = gmmvi_wave_sum(a);
+    b = gmmvi_wave_sum(b);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[w] = a; red[16 + w] = b; }
+    __syncthreads();
+    float sa = 0.f, sb = 0.f;
+    for (int i = 0; i < nw; ++i) { sa += red[i]; sb += red[16 + i]; }
+    a = sa; b = sb;
+}
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = gmmvi_wave_max(v);
     const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -1010,11 +1022,11 @@ __global__ __launch_bounds__(256) void blk_upd_prep_kernel(int D, const float* _
     const float* R = H_neg + (size_t)k * D * D;
     const float* mu = means + (size_t)k * D;
     float* o = Rs + (size_t)k * D * D;
-    for (int e = threadIdx.x; e < D * D; e += 256) {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < D * D; e += gridDim.y * 256) {
         const int i = e / D, j = e % D;
         o[e] = (j <= i) ? R[e] : R[(size_t)j * D + i];
     }
-    for (int t = threadIdx.x; t < D; t += 256) {
+    for (int t = blockIdx.y * 256 + threadIdx.x; t < D; t += gridDim.y * 256) {
         float g = g_neg[(size_t)k * D + t];
         for (int j = t + 1; j < D; ++j) g = fmaf(R[(size_t)j * D + t] - R[(size_t)t * D + j], mu[j], g);
         gt[(size_t)k * D + t] = g;
@@ -1029,7 +1041,7 @@ __global__ __launch_bounds__(256) void blk_upd_sym_kernel(int D, const float* __
     float* Mk = M + (size_t)k * D * D;
     float* Ck = Mc + (size_t)k * D * D;
     const float* L = chols + (size_t)k * D * D;
-    for (int e = threadIdx.x; e < D * D; e += 256) {
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < D * D; e += gridDim.y * 256) {
         const int i = e / D, j = e % D;
         if (j < i) {
             const float m = 0.5f * (Mk[e] + Mk[(size_t)j * D + i]);
@@ -1039,7 +1051,7 @@ __global__ __launch_bounds__(256) void blk_upd_sym_kernel(int D, const float* __
             Ck[e] = Mk[e];
         }
     }
-    for (int t = threadIdx.x; t < D; t += 256) {
+    for (int t = blockIdx.y * 256 + threadIdx.x; t < D; t += gridDim.y * 256) {
         float a = 0.f;
         for (int c = t; c < D; ++c) a = fmaf(L[(size_t)c * D + t], gt[(size_t)k * D + c], a);
         w[(size_t)k * D + t] = a;
@@ -1118,8 +1130,10 @@ __global__ __launch_bounds__(1024) void blk_tridiag_kernel(int D, int DT, int G,
     float* v = va;
     float* v2 = vb;
     for (int c = 0; c + 2 < D; ++c) {
-        const float kk = 0.5f * beta * block_sum(vi * p, red);
-        const float wdot = beta * block_sum(vi * wti, red);
+        float s_vp = vi * p, s_vw = vi * wti;
+        block_sum2(s_vp, s_vw, red);
+        const float kk = 0.5f * beta * s_vp;
+        const float wdot = beta * s_vw;
         if (g0) q[i] = (i > c) ? p - kk * vi : 0.f;
         wti -= wdot * vi;
         __syncthreads();
@@ -1382,7 +1396,8 @@ int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* c
     float* scratch = te + f_vec;
     float* state = scratch + f_scr;
     GMMVI_PROF(ctx, "blocked_update_kl");
-    hipLaunchKernelGGL(blk_upd_prep_kernel, dim3(K), dim3(256), 0, ctx->stream, D, H_neg, g_neg, means, Rs, gt);
+    const int slices = (D * D + 256 * 16 - 1) / (256 * 16);          // ~16 elements per thread
+    hipLaunchKernelGGL(blk_upd_prep_kernel, dim3(K, slices), dim3(256), 0, ctx->stream, D, H_neg, g_neg, means, Rs, gt);
     GMMVI_LAUNCH_CHECK(ctx);
     {
         BG g = bg_zero();
@@ -1400,7 +1415,7 @@ int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* c
         g.M = D; g.N = D; g.Kd = D;
         BLK_TRY(bgemm(ctx, g, K));
     }
-    hipLaunchKernelGGL(blk_upd_sym_kernel, dim3(K), dim3(256), 0, ctx->stream, D, chols, gt, M, Mc, w, wt);
+    hipLaunchKernelGGL(blk_upd_sym_kernel, dim3(K, slices), dim3(256), 0, ctx->stream, D, chols, gt, M, Mc, w, wt);
     GMMVI_LAUNCH_CHECK(ctx);
     {
         const int DT = blk_threads(D);
