@@ -25,3 +25,6 @@ int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
 int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* chols, const float* H_neg, const float* g_neg,
                             const float* stepsizes, float temperature, float l2_init, float* last_eta, float* l2,
                             float* num_updates, int32_t* success_out, float* kl_out, int32_t* nprobes_out, float* packed_out);
+int gmmvi_blocked_update_plain(gmmvi_ctx* ctx, int mode, int K, int D, float* means, float* chols, const float* H_neg,
+                               const float* g_neg, const float* stepsizes, float l2_init, float* l2, float* num_updates,
+                               int32_t* success_out);

@@ -1306,11 +1306,15 @@ __global__ __launch_bounds__(64) void blk_search_kernel(int D, const float* __re
     }
 }
 
-// B = I + Mc/eta* = U U^T through the Cholesky factor C of the index-reversed matrix (U = J C J); L' = L U^-T and
-// z = U^-1 w by forward substitution with C on the reversed rows of L (one thread per row, thread D: w);
+// mode 0 (KL-constrained): B = I + Mc/eta* = U U^T through the Cholesky factor C of the index-reversed matrix (U = J C J);
+// L' = L U^-T and z = U^-1 w by forward substitution with C on the reversed rows of L (one thread per row, thread D: w);
 // mu' = mu - L' z / eta*.  Commits means / chols on success and does the bookkeeping of :518-524.
-__global__ __launch_bounds__(576) void blk_upd_final_kernel(int D, const float* __restrict__ Mc_all, const float* __restrict__ w_all,
-                                                            float* __restrict__ W_all, float* __restrict__ X_all, const float* __restrict__ state,
+// modes 1 / 2 (direct :97-141, iBLR :160-223): Mc holds the new precision Q' (lower triangle read, as tf.linalg.cholesky
+// does); Q' = U U^T the same way, the new factor is L' = U^-T (rows of the identity as right-hand sides), the new mean
+// L' (U^-1 lin') for the direct update (w = new linear term), the precomputed mean (w) for iBLR.
+__global__ __launch_bounds__(576) void blk_upd_final_kernel(int D, int mode, const float* __restrict__ Mc_all,
+                                                            const float* __restrict__ w_all, float* __restrict__ W_all,
+                                                            float* __restrict__ X_all, const float* __restrict__ state,
                                                             float* __restrict__ means, float* __restrict__ chols,
                                                             float l2_init, float* __restrict__ last_eta, float* __restrict__ l2,
                                                             float* __restrict__ num_updates, int32_t* __restrict__ success_out,
@@ -1318,24 +1322,30 @@ __global__ __launch_bounds__(576) void blk_upd_final_kernel(int D, const float* 
     extern __shared__ __align__(16) float dyn[];
     __shared__ int anybad;
     const int k = blockIdx.x, t = threadIdx.x;
-    const float eta_star = state[4 * k];
-    bool success = state[4 * k + 1] != 0.f;
-    const float kl_val = state[4 * k + 2];
+    const float eta_star = mode == 0 ? state[4 * k] : 1.f;
+    bool success = mode == 0 ? state[4 * k + 1] != 0.f : true;
+    const float kl_val = mode == 0 ? state[4 * k + 2] : 0.f;
     const float inv = 1.f / eta_star;
+    const float diag_add = mode == 0 ? 1.f : 0.f;
     float* L = chols + (size_t)k * D * D;
     float* mu = means + (size_t)k * D;
     if (success) {
         const float* Mc = Mc_all + (size_t)k * D * D;
         float* W = W_all + (size_t)k * D * D;
-        success = blk_cholesky(D, [Mc, D, inv](int i, int j) {
-            return (i == j ? 1.f : 0.f) + Mc[(size_t)(D - 1 - i) * D + (D - 1 - j)] * inv; }, W, dyn);
+        success = blk_cholesky(D, [Mc, D, inv, diag_add](int i, int j) {
+            return (i == j ? diag_add : 0.f) + Mc[(size_t)(D - 1 - j) * D + (D - 1 - i)] * inv; }, W, dyn);
         if (success) {
             const float* w = w_all + (size_t)k * D;
             float* X = X_all + (size_t)k * D * (D + 1);
             const int ldx = D + 1;
-            blk_trsm<true>(D, W, D + 1,
-                           [L, w, D](int i, int tt) { return tt < D ? L[(size_t)tt * D + (D - 1 - i)] : w[D - 1 - i]; },
-                           t < D ? D - 1 - t : 0, X, ldx, dyn);
+            if (mode == 0)
+                blk_trsm<true>(D, W, D + 1,
+                               [L, w, D](int i, int tt) { return tt < D ? L[(size_t)tt * D + (D - 1 - i)] : w[D - 1 - i]; },
+                               t < D ? D - 1 - t : 0, X, ldx, dyn);
+            else
+                blk_trsm<true>(D, W, mode == 1 ? D + 1 : D,
+                               [w, D](int i, int tt) { return tt < D ? (tt == D - 1 - i ? 1.f : 0.f) : w[D - 1 - i]; },
+                               t < D ? D - 1 - t : 0, X, ldx, dyn);
             if (t == 0) anybad = 0;
             __syncthreads();
             float new_mu = 0.f;
@@ -1344,11 +1354,11 @@ __global__ __launch_bounds__(576) void blk_upd_final_kernel(int D, const float* 
                 bool bad = false;
                 for (int i = 0; i < D; ++i) {
                     const float x = X[(size_t)i * ldx + t];
-                    acc = fmaf(x, X[(size_t)i * ldx + D], acc);
+                    if (mode != 2) acc = fmaf(x, X[(size_t)i * ldx + D], acc);
                     bad |= !(x == x);
                 }
                 bad |= !(X[(size_t)(D - 1 - t) * ldx + t] > 0.f);          // diagonal of L'
-                new_mu = mu[t] - acc * inv;
+                new_mu = mode == 0 ? mu[t] - acc * inv : (mode == 1 ? acc : w[t]);
                 bad |= !(new_mu == new_mu);
                 if (bad) anybad = 1;
             }
@@ -1364,13 +1374,43 @@ __global__ __launch_bounds__(576) void blk_upd_final_kernel(int D, const float* 
         }
     }
     if (t == 0) {
-        last_eta[k] = success ? eta_star : -1.f;
-        if (kl_out) kl_out[k] = success ? kl_val : -1.f;
-        if (nprobes_out) nprobes_out[k] = (int32_t)state[4 * k + 3];
+        if (mode == 0) {
+            last_eta[k] = success ? eta_star : -1.f;
+            if (kl_out) kl_out[k] = success ? kl_val : -1.f;
+            if (nprobes_out) nprobes_out[k] = (int32_t)state[4 * k + 3];
+        }
         const float old = l2[k];
         l2[k] = success ? fmaxf(0.5f * old, l2_init) : fminf(1e-6f, 10.f * old);
         num_updates[k] += 1.f;
         if (success_out) success_out[k] = success ? 1 : 0;
+    }
+}
+
+// direct: Qp = Q + step R, vec = Q mu + step (R mu - g_neg).   iBLR: Qp = Q + step (R + step/2 T2) with T2 = R Sigma R,
+// vec = mu - step Sigma g_neg (mu itself on the component's first update, :184-186).
+__global__ __launch_bounds__(256) void blk_plain_prep_kernel(int mode, int D, const float* __restrict__ Q,
+                                                             const float* __restrict__ H_neg, const float* __restrict__ g_neg,
+                                                             const float* __restrict__ means, const float* __restrict__ stepsizes,
+                                                             const float* __restrict__ num_updates, const float* __restrict__ Sig,
+                                                             const float* __restrict__ T2, float* __restrict__ Qp,
+                                                             float* __restrict__ vec) {
+    const int k = blockIdx.x;
+    const size_t o = (size_t)k * D * D;
+    const float step = stepsizes[k];
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < D * D; e += gridDim.y * 256)
+        Qp[o + e] = Q[o + e] + step * (mode == 1 ? H_neg[o + e] : H_neg[o + e] + 0.5f * step * T2[o + e]);
+    const float* mu = means + (size_t)k * D;
+    const float* g = g_neg + (size_t)k * D;
+    for (int t = blockIdx.y * 256 + threadIdx.x; t < D; t += gridDim.y * 256) {
+        float a = 0.f;
+        if (mode == 1) {
+            float b = 0.f;
+            for (int j = 0; j < D; ++j) { a = fmaf(Q[o + (size_t)t * D + j], mu[j], a); b = fmaf(H_neg[o + (size_t)t * D + j], mu[j], b); }
+            vec[(size_t)k * D + t] = a + step * (b - g[t]);
+        } else {
+            for (int j = 0; j < D; ++j) a = fmaf(Sig[o + (size_t)t * D + j], g[j], a);
+            vec[(size_t)k * D + t] = (num_updates[k] == 0.f) ? mu[t] : mu[t] - step * a;
+        }
     }
 }
 
@@ -1437,10 +1477,70 @@ int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* c
         }
         const size_t a = blk_trsm_lds_floats(D), b = blk_chol_lds_floats(D);
         hipLaunchKernelGGL(blk_upd_final_kernel, dim3(K), dim3(blk_threads(D + 1)), (a > b ? a : b) * sizeof(float), ctx->stream, D,
-                           Mc, w, T1, Xs, state, means, chols, l2_init, last_eta, l2, num_updates, success_out, kl_out,
+                           0, Mc, w, T1, Xs, state, means, chols, l2_init, last_eta, l2, num_updates, success_out, kl_out,
                            nprobes_out);
     }
     GMMVI_LAUNCH_CHECK(ctx);
     if (packed_out) BLK_TRY(gmmvi_blocked_pack(ctx, GMMVI_GAUSS, 0.f, K, D, means, chols, packed_out, nullptr));
+    return GMMVI_OK;
+}
+
+// DirectNgBasedComponentUpdater (:97-141, mode 0) and NgBasedComponentUpdaterIblr (:160-223, mode 1) on the blocked path
+int gmmvi_blocked_update_plain(gmmvi_ctx* ctx, int mode, int K, int D, float* means, float* chols, const float* H_neg,
+                               const float* g_neg, const float* stepsizes, float l2_init, float* l2, float* num_updates,
+                               int32_t* success_out) {
+    const size_t DD = (size_t)D * D, ps = gmmvi_blocked_stride(D);
+    const size_t f_mat = (size_t)K * DD, f_pk = (size_t)K * ps, f_x = (size_t)K * D * (D + 1), f_vec = (size_t)K * D;
+    const int nmat = mode == 0 ? 3 : 6;
+    BLK_TRY(gmmvi_ws_reserve(ctx, (f_pk + nmat * f_mat + f_x + f_vec) * sizeof(float)));
+    float* pk = (float*)ctx->ws;          // [mu | const | L^-1] of the current components
+    float* Q = pk + f_pk;                 // old precision L^-T L^-1
+    float* Qp = Q + f_mat;                // new precision
+    float* W = Qp + f_mat;                // column-major Cholesky factor
+    float* Sig = W + f_mat;               // iBLR: Sigma, R Sigma, R Sigma R
+    float* T = Sig + (mode == 0 ? 0 : f_mat);
+    float* T2 = T + (mode == 0 ? 0 : f_mat);
+    float* Xs = W + (size_t)(nmat - 2) * f_mat;
+    float* vec = Xs + f_x;
+    GMMVI_PROF(ctx, "blocked_update_plain");
+    BLK_TRY(gmmvi_blocked_pack(ctx, GMMVI_GAUSS, 0.f, K, D, means, chols, pk, nullptr));
+    const float* Linv = pk + gmmvi_blocked_linv_ofs(D);
+    {
+        BG g = bg_zero();
+        g.A = Linv; g.lda = D; g.sA = (long long)ps; g.a_kmajor = 1;          // opA(m = i, k = c) = L^-1[c][i]
+        g.B = Linv; g.ldb = D; g.sB = (long long)ps; g.b_kmajor = 1;
+        g.C = Q; g.ldc = D; g.sC = (long long)DD;
+        g.M = D; g.N = D; g.Kd = D;
+        BLK_TRY(bgemm(ctx, g, K));
+    }
+    if (mode == 1) {
+        BG g = bg_zero();
+        g.A = chols; g.lda = D; g.sA = (long long)DD; g.a_kmajor = 0;
+        g.B = chols; g.ldb = D; g.sB = (long long)DD; g.b_kmajor = 0;         // opB(k = c, n = j) = L[j][c]
+        g.C = Sig; g.ldc = D; g.sC = (long long)DD;
+        g.M = D; g.N = D; g.Kd = D;
+        BLK_TRY(bgemm(ctx, g, K));
+        g.A = H_neg; g.B = Sig; g.b_kmajor = 1; g.C = T;                       // R Sigma
+        BLK_TRY(bgemm(ctx, g, K));
+        g.A = T; g.B = H_neg; g.C = T2;                                        // (R Sigma) R
+        BLK_TRY(bgemm(ctx, g, K));
+    }
+    const int slices = (D * D + 256 * 16 - 1) / (256 * 16);
+    hipLaunchKernelGGL(blk_plain_prep_kernel, dim3(K, slices), dim3(256), 0, ctx->stream, mode == 0 ? 1 : 2, D, Q, H_neg, g_neg,
+                       means, stepsizes, num_updates, Sig, T2, Qp, vec);
+    GMMVI_LAUNCH_CHECK(ctx);
+    {
+        static bool attr_done = false;
+        if (!attr_done) {
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_upd_final_kernel,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            attr_done = true;
+        }
+        const size_t a = blk_trsm_lds_floats(D), b = blk_chol_lds_floats(D);
+        hipLaunchKernelGGL(blk_upd_final_kernel, dim3(K), dim3(blk_threads(D + 1)), (a > b ? a : b) * sizeof(float), ctx->stream, D,
+                           mode == 0 ? 1 : 2, Qp, vec, W, Xs, nullptr, means, chols, l2_init, nullptr, l2, num_updates,
+                           success_out, nullptr, nullptr);
+        GMMVI_LAUNCH_CHECK(ctx);
+    }
     return GMMVI_OK;
 }

@@ -8,6 +8,7 @@
 // reference's stop rules decision for decision.  A non-positive or non-finite Cholesky pivot takes the
 // reference's "NaN in the factor" branch (:320-324, :493).
 #include "common.h"
+#include "blocked.h"
 #include <cfloat>
 
 namespace {
@@ -366,9 +367,12 @@ int gmmvi_update_components_kl_reference(gmmvi_ctx* ctx, int K, int D, float* me
 static int launch_plain(gmmvi_ctx* ctx, int mode, int K, int D, float* means_dev, float* chols_dev,
                         const float* H_neg_dev, const float* g_neg_dev, const float* stepsizes_dev, float l2_init,
                         float* l2_dev, float* num_received_updates_dev, int32_t* success_out_dev) {
-    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM);
+    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM_BLOCKED);
     GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && H_neg_dev && g_neg_dev && stepsizes_dev && l2_dev &&
                              num_received_updates_dev);
+    if (gmmvi_is_blocked_dim(D))
+        return gmmvi_blocked_update_plain(ctx, mode, K, D, means_dev, chols_dev, H_neg_dev, g_neg_dev, stepsizes_dev, l2_init,
+                                          l2_dev, num_received_updates_dev, success_out_dev);
     size_t shmem = update_lds_bytes(D);
     if (shmem > 64 * 1024)
         GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)update_plain_kernel,

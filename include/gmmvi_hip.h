@@ -54,7 +54,7 @@ enum gmmvi_stein_flags {
 #define GMMVI_MAX_DIM 64       /* register-resident kernels: D <= 64 */
 #define GMMVI_MAX_DIM_BLOCKED 512   /* 64 < D <= 512: blocked kernels (dense L^-1 blocks, fp32 MFMA contractions)
                                      * behind gmmvi_packed_stride / pack_components / cholesky / mixture_eval(_dual) /
-                                     * sample_components / stein / update_components_kl */
+                                     * sample_components / stein / update_components_kl / _direct / _iblr */
 
 /* ---- context, errors, memory ------------------------------------------------------------------------ */
 int gmmvi_device_count(void);

@@ -254,3 +254,24 @@ def test_blocked_stein_reuses_whitened_samples_only_when_inputs_match(ctx, rng):
     np.testing.assert_array_equal(g_c.numpy(), g_ref.numpy())
     rh, rg = ostein.get_expected_hessian_and_grad(m, x2, mapping, bg, tlp, tg, False, True)
     assert np.all(np.abs(h_ref.numpy() - rh) <= 1e-2 * np.abs(rh).max(axis=(1, 2), keepdims=True) + 1e-6)
+
+
+@pytest.mark.parametrize("mode", ["direct", "iblr"])
+@pytest.mark.parametrize("k,d", [(3, 72), (2, 130)])
+def test_blocked_update_components_plain(ctx, rng, mode, k, d):
+    m, hs, gs = _update_inputs(rng, k, d)
+    hs[0] = -50.0 * np.eye(d)     # direct: new precision not positive definite -> rejected, parameters kept (iBLR stays PD)
+    w = ogmm.GmmWrapper(m, 0.1, 1e-12, 4)
+    steps = np.full(k, 0.3)
+    logw, means, chols = upload_model(ctx, m)
+    l2 = ctx.asarray(w.l2_regularizers); nupd = ctx.asarray(w.num_received_updates)
+    for round_ in range(2):
+        succ = ops().update_components_plain(ctx, mode, means, chols, ctx.asarray(hs), ctx.asarray(gs),
+                                             ctx.asarray(steps), 1e-12, l2, nupd)
+        rs = (oupd.apply_ng_update_direct if mode == "direct" else oupd.apply_ng_update_iblr)(w, hs, gs, steps)
+        np.testing.assert_array_equal(succ.numpy().astype(bool), rs)
+        assert rs[1:].all() and (mode == "iblr" or not rs[0])
+        np.testing.assert_allclose(means.numpy(), m.means, rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(chols.numpy(), m.chol_cov, rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(l2.numpy(), w.l2_regularizers, rtol=1e-6)
+        np.testing.assert_allclose(nupd.numpy(), w.num_received_updates)
