@@ -39,6 +39,7 @@ WORKLOADS = {
     # = 64 components per GPU, N = 20k samples/iter; blocked path (csrc/blocked.hip).  No CPU baseline: the oracle's
     # [K,N,D] fp64 temporaries make one iteration take minutes ("C5 infeasible on CPU")
     "c5": ("gauss300", 300, 64, 312),
+    "c5_full": ("gauss300", 300, 512, 39),   # all of BASELINE configs[4] on ONE GPU (component chunks: Z of 512 components > scratch budget)
     "tiny": ("stm", 4, 4, 16),         # host-overhead probe (kernels are empty; time = launch path)
 }
 
