@@ -78,6 +78,13 @@ _PROTOS = {
     "gmmvi_allgather_f32": (_i, [_p, _p, _p, _sz]),
     "gmmvi_allreduce_f32": (_i, [_p, _p, _sz, _i]),
     "gmmvi_combine_partials": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
+    "gmmvi_diag_embed": (_i, [_p, _i, _i, _p, _p]),
+    "gmmvi_diag_extract": (_i, [_p, _i, _i, _p, _p]),
+    "gmmvi_reciprocal_f32": (_i, [_p, _p, _sz, _p]),
+    "gmmvi_update_components_diag_kl": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "gmmvi_update_components_diag_iblr": (_i, [_p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _p, _p]),
+    "gmmvi_mmd_scratch_doubles": (_sz, [_i, _i]),
+    "gmmvi_mmd_pair_sum": (_i, [_p, _p, _i, _p, _i, _i, _p, _p, _p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())

@@ -1,6 +1,7 @@
 """Experiment set-up (reference: src/gmmvi/experiments/setup_experiment.py:10-160)."""
 import numpy as np
 
+from ..models.diagonal_gmm import DiagonalGMM
 from ..models.full_cov_gmm import FullCovGMM
 from ..models.gmm_wrapper import GmmWrapper
 
@@ -36,23 +37,35 @@ def get_target_lnpdf(experiment, environment_config, seed):
     elif experiment.startswith("GMM"):
         from .target_distributions.gmm import make_target
         return make_target(**environment_config)
+    elif experiment.startswith("DIAGGMM"):
+        from .target_distributions.diag_gmm import make_target
+        return make_target(**environment_config)
     raise ValueError(f"get_target_lnpdf() was called with unknown experiment name: {experiment} "
-                     f"(in scope: PlanarRobot1/4, STM, GMM*; pass other targets as config['target_fn'])")
+                     f"(in scope: PlanarRobot1/4, STM, GMM*, DIAGGMM*; pass other targets as config['target_fn'])")
 
 
 def construct_initial_mixture(num_dimensions, num_initial_components, prior_mean, prior_scale, use_diagonal_covs,
                               initial_cov=None):
     """setup_experiment.py:88-160: equal weights, means ~ N(prior_mean, prior_scale^2) from the global NumPy RNG,
     covariance initial_cov * I (or the prior covariance)."""
-    if use_diagonal_covs:
-        raise NotImplementedError("diagonal GMMs are outside the hot-path scope (DESIGN.md, out of scope)")
     if np.isscalar(prior_mean):
         prior_mean = prior_mean * np.ones(num_dimensions)
     if np.isscalar(prior_scale):
         prior_scale = prior_scale * np.ones(num_dimensions)
-    prior = np.diag(np.array(prior_scale) ** 2)
     weights = np.ones(num_initial_components, dtype=np.float32) / num_initial_components
     means = np.zeros((num_initial_components, num_dimensions), dtype=np.float32)
+    if use_diagonal_covs:                                                                       # :129-141
+        prior = np.array(prior_scale) ** 2
+        initial_cov = prior if initial_cov is None else initial_cov * np.ones(num_dimensions)
+        covs = np.ones((num_initial_components, num_dimensions), dtype=np.float32)
+        for i in range(num_initial_components):
+            if num_initial_components == 1:
+                means[i] = prior_mean
+            else:
+                means[i] = prior_mean + np.sqrt(prior) * np.random.standard_normal([num_dimensions])
+            covs[i] = initial_cov
+        return DiagonalGMM(weights, means, covs)
+    prior = np.diag(np.array(prior_scale) ** 2)
     initial_cov = prior if initial_cov is None else initial_cov * np.eye(num_dimensions)
     covs = np.ones((num_initial_components, num_dimensions, num_dimensions), dtype=np.float32)
     for i in range(num_initial_components):

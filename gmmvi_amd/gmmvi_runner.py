@@ -24,9 +24,13 @@ class GmmviRunner:
         target_distribution, initial_model = init_experiment(self.config)
         initial_model.model.seed = int(config["seed"])
         self.gmmvi = GMMVI.build_from_config(self.config, target_distribution, initial_model)
-        if "mmd_evaluation_config" in config.keys():
-            raise NotImplementedError("MMD evaluation is outside the hot-path scope (SURVEY.md section 2, row 18)")
-        self.mmd = None
+        if "mmd_evaluation_config" in config.keys():                                       # gmmvi_runner.py:45-54
+            from .experiments.evaluation.mmd import MMD
+            dir_path = os.path.dirname(os.path.realpath(__file__))
+            samples = np.load(os.path.join(dir_path, config['mmd_evaluation_config']['sample_dir']))
+            self.mmd = MMD(samples, config['mmd_evaluation_config']["alpha"])
+        else:
+            self.mmd = None
         if "dump_gmm_path" not in self.config:
             self.dump_gmms = False
         else:
@@ -64,6 +68,8 @@ class GmmviRunner:
                                   "algo_time": np.sum(self.wall_times)})
         expensive_metrics.update(
             self.gmmvi.sample_selector.target_distribution.expensive_metrics(self.gmmvi.model, test_samples))
+        if self.mmd is not None:                                                           # gmmvi_runner.py:140-142
+            expensive_metrics.update({"MMD:": self.mmd.compute_MMD(test_samples)})
         return expensive_metrics
 
     def iterate_and_log(self, n: int) -> dict:

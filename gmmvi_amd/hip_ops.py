@@ -199,6 +199,72 @@ def update_components_plain(ctx, mode, means, chols, h_neg, g_neg, stepsizes, l2
     return success
 
 
+def diag_embed(ctx, chols_diag):
+    """[K,D] sigma -> dense lower-triangular factors [K,D,D] = diag(sigma) for the dense density / sampling kernels."""
+    k, d = chols_diag.shape
+    _req(chols_diag, (k, d), name="chols_diag")
+    dense = ctx.empty((k, d, d))
+    ctx.check(ctx.lib.gmmvi_diag_embed(ctx.handle, k, d, chols_diag.ptr, dense.ptr))
+    return dense
+
+
+def diag_extract(ctx, dense):
+    """[K,D,D] -> its diagonals [K,D]."""
+    k, d, _ = dense.shape
+    _req(dense, (k, d, d), name="dense")
+    diag = ctx.empty((k, d))
+    ctx.check(ctx.lib.gmmvi_diag_extract(ctx.handle, k, d, dense.ptr, diag.ptr))
+    return diag
+
+
+def reciprocal(ctx, a):
+    if a.dtype != F32:
+        raise ValueError("reciprocal: fp32 only")
+    out = ctx.empty(a.shape)
+    ctx.check(ctx.lib.gmmvi_reciprocal_f32(ctx.handle, a.ptr, a.size, out.ptr))
+    return out
+
+
+def update_components_diag(ctx, mode, means, chols_diag, h_neg_diag, g_neg, stepsizes, temperature, l2_init, last_eta, l2,
+                           num_updates, want_info=False):
+    """Diagonal-covariance component update, mode "kl" or "iblr" -> (success, kl | None, probes | None)."""
+    k, d = means.shape
+    _req(means, (k, d), name="means"); _req(chols_diag, (k, d), name="chols_diag")
+    _req(h_neg_diag, (k, d), name="h_neg_diag"); _req(g_neg, (k, d), name="g_neg")
+    _req(stepsizes, (k,), name="stepsizes"); _req(l2, (k,), name="l2"); _req(num_updates, (k,), name="num_updates")
+    success = ctx.empty((k,), np.int32)
+    if mode == "iblr":
+        ctx.check(ctx.lib.gmmvi_update_components_diag_iblr(ctx.handle, k, d, means.ptr, chols_diag.ptr, h_neg_diag.ptr,
+                                                            g_neg.ptr, stepsizes.ptr, float(l2_init), l2.ptr,
+                                                            num_updates.ptr, success.ptr))
+        return success, None, None
+    if mode != "kl":
+        raise ValueError(f"update_components_diag: unknown mode {mode!r}")
+    _req(last_eta, (k,), name="last_eta")
+    kl = ctx.empty((k,)) if want_info else None
+    probes = ctx.empty((k,), np.int32) if want_info else None
+    ctx.check(ctx.lib.gmmvi_update_components_diag_kl(ctx.handle, k, d, means.ptr, chols_diag.ptr, h_neg_diag.ptr,
+                                                      g_neg.ptr, stepsizes.ptr, float(temperature), float(l2_init),
+                                                      last_eta.ptr, l2.ptr, num_updates.ptr, success.ptr,
+                                                      None if kl is None else kl.ptr,
+                                                      None if probes is None else probes.ptr))
+    return success, kl, probes
+
+
+def mmd_pair_sum(ctx, a, b, inv_bandwidth):
+    """sum_i sum_j exp(-sum_d inv_bandwidth[d] (a[i,d] - b[j,d])^2) -> Python float (fp64 sum)."""
+    na, d = a.shape
+    nb = b.shape[0]
+    _req(a, (na, d), name="a"); _req(b, (nb, d), name="b"); _req(inv_bandwidth, (d,), name="inv_bandwidth")
+    if na == 0 or nb == 0:
+        return 0.0
+    # fp64 scratch / result held in fp32-typed device buffers of twice the length (DeviceArray is 4-byte typed)
+    scratch = ctx.empty((2 * int(ctx.lib.gmmvi_mmd_scratch_doubles(na, nb)),))
+    out = ctx.empty((2,))
+    ctx.check(ctx.lib.gmmvi_mmd_pair_sum(ctx.handle, a.ptr, na, b.ptr, nb, d, inv_bandwidth.ptr, scratch.ptr, out.ptr))
+    return float(out.numpy().view(np.float64)[0])
+
+
 def expected_log_ratios(ctx, ld, bg, tlp, logq, beta, logw, self_normalized=True, reward_out=None, want_ess=False):
     k, n = ld.shape
     _req(ld, (k, n), name="ld"); _req(bg, (n,), name="bg"); _req(tlp, (n,), name="tlp"); _req(logq, (n,), name="logq")

@@ -1,6 +1,6 @@
 """Host-side mirror of the reference's GMM base class (reference: src/gmmvi/models/gmm.py:5-418).
 
-Parameters live in HBM as ``DeviceArray``s (log_weights [K], means [K,D], chol_cov [K,D,D]); every density /
+Parameters live in HBM as ``DeviceArray``s (log_weights [K], means [K,D], chol_cov [K,D,D] -- [K,D] for DiagonalGMM); every density /
 sampling method launches the HIP kernels of libgmmvi_hip.so.  Method names, argument order and return tuples are
 the reference's; returned arrays are device resident and offer ``.numpy()``.
 """
@@ -39,6 +39,10 @@ class GMM:
         if self._packed is None:
             self._packed, _ = hip_ops.pack_components(self.ctx, self.means, self.chol_cov)
         return self._packed
+
+    def _kernel_chol(self):
+        """Dense [K,D,D] factors the sampling kernel reads (DiagonalGMM: the embedded diag(sigma))."""
+        return self.chol_cov
 
     # ---- properties -------------------------------------------------------------------------------------
     @property
@@ -126,7 +130,7 @@ class GMM:
         n = int(offsets[-1])
         offsets_dev = self.ctx.cached_const(("offsets", offsets.tobytes()),
                                             lambda: self.ctx.asarray(offsets, np.int32))
-        return hip_ops.sample_components(self.ctx, self.means, self.chol_cov, offsets_dev, n,
+        return hip_ops.sample_components(self.ctx, self.means, self._kernel_chol(), offsets_dev, n,
                                          seed=self.seed if seed is None else seed, first_index=first_index,
                                          stream_id=stream_id,
                                          eps=None if eps is None else self.ctx.asarray(eps))

@@ -5,7 +5,7 @@ Stein estimator, KL-constrained component updater, improvement-based or fixed st
 updater, built-in target), the iteration is issued by ONE C call (``gmmvi_train_iter_samtron``) that composes the same
 entry points the modules call, on the same state arrays.  Python only does the bookkeeping the reference keeps in
 ``tf.Variable``s (DB length, ring positions, counters).  Anything else -- reuse ratio > 0, MORE, direct/iBLR updaters,
-own-samples-only, user targets, want_info -- takes the modular path.  Disable with ``GMMVI_FAST_PATH=0``.
+own-samples-only, user targets, diagonal GMMs, want_info -- takes the modular path.  Disable with ``GMMVI_FAST_PATH=0``.
 """
 import ctypes as C
 import os
@@ -69,7 +69,8 @@ class SamtronFastPath:
               and hasattr(tgt, "_fast_path_target")
               and not est._only_use_own_samples
               and est._use_self_normalized_importance_weights == wu.use_self_normalized_importance_weights
-              and g.sample_db.keep_samples and g.model.num_dimensions < _lib.MAX_DIM)
+              and g.sample_db.keep_samples and g.model.num_dimensions < _lib.MAX_DIM
+              and not g.model.diagonal_covs)
         return bool(ok)
 
     def eligible(self):

@@ -101,7 +101,8 @@ class VipsComponentAdaptation(ComponentAdaptation):
         d = m.num_dimensions
         h_unscaled = 0.5 * d * (np.log(2.0 * np.pi) + 1)
         c = np.exp((2 * (des_entropy - h_unscaled)) / d)
-        m.add_component(init_weight, new_mean, c * np.eye(d), [self.thresholds_for_addHeuristic[it]], [des_entropy])
+        new_cov = c * np.ones(d) if m.diagonal_covs else c * np.eye(d)                               # :220-223
+        m.add_component(init_weight, new_mean, new_cov, [self.thresholds_for_addHeuristic[it]], [des_entropy])
 
     def select_samples_for_adding_heuristic(self):
         """:228-249."""

@@ -35,6 +35,8 @@ class DirectNgBasedComponentUpdater(NgBasedComponentUpdater):
     def apply_NG_update(self, expected_hessians_neg, expected_gradients_neg, stepsizes):
         m = self.model
         ctx = m.ctx
+        if m.diagonal_covs:
+            raise NotImplementedError("the reference's direct updater has no diagonal branch (:106 inverts chol_cov)")
         self.last_success = hip_ops.update_components_plain(
             ctx, "direct", m.means, m.chol_cov, ctx.asarray(expected_hessians_neg), ctx.asarray(expected_gradients_neg),
             ctx.asarray(stepsizes), m.initial_regularizer, m.l2_regularizers, m.num_received_updates)
@@ -47,6 +49,13 @@ class NgBasedComponentUpdaterIblr(NgBasedComponentUpdater):
     def apply_NG_update(self, expected_hessians_neg, expected_gradients_neg, stepsizes):
         m = self.model
         ctx = m.ctx
+        if m.diagonal_covs:                                                               # :170-174, :188-197
+            self.last_success, _, _ = hip_ops.update_components_diag(
+                ctx, "iblr", m.means, m.chol_cov, ctx.asarray(expected_hessians_neg),
+                ctx.asarray(expected_gradients_neg), ctx.asarray(stepsizes), 0.0, m.initial_regularizer, None,
+                m.l2_regularizers, m.num_received_updates)
+            m.model._invalidate()
+            return
         self.last_success = hip_ops.update_components_plain(
             ctx, "iblr", m.means, m.chol_cov, ctx.asarray(expected_hessians_neg), ctx.asarray(expected_gradients_neg),
             ctx.asarray(stepsizes), m.initial_regularizer, m.l2_regularizers, m.num_received_updates)
@@ -60,6 +69,15 @@ class KLConstrainedNgBasedComponentUpdater(NgBasedComponentUpdater):
     def apply_NG_update(self, expected_hessians_neg, expected_gradients_neg, stepsizes):
         m = self.model
         ctx = m.ctx
+        if m.diagonal_covs:                                                               # :447-453, :304-318
+            succ, kl, probes = hip_ops.update_components_diag(
+                ctx, "kl", m.means, m.chol_cov, ctx.asarray(expected_hessians_neg), ctx.asarray(expected_gradients_neg),
+                ctx.asarray(stepsizes), self.temperature, m.initial_regularizer, m.last_log_etas, m.l2_regularizers,
+                m.num_received_updates, want_info=self.want_info)
+            self.last_success = succ
+            self.last_info = (kl, probes)
+            m.model._invalidate()
+            return
         succ, kl, probes, packed = hip_ops.update_components_kl(
             ctx, m.means, m.chol_cov, ctx.asarray(expected_hessians_neg), ctx.asarray(expected_gradients_neg),
             ctx.asarray(stepsizes), self.temperature, m.initial_regularizer, m.last_log_etas, m.l2_regularizers,

@@ -58,9 +58,15 @@ class SteinNgEstimator(NgEstimator):
             host = getattr(m, "_mapping_max_hint", None)
             mx = int(host) if host is not None else int(np.asarray(map_dev.numpy()).max())
             map_offset = k - 1 - mx
-        return hip_ops.stein(ctx, m.packed, x, ld, model_grads, bg, tgrad, d, mapping=map_dev, map_offset=map_offset,
-                             self_normalized=self._use_self_normalized_importance_weights,
-                             own_samples_only=self._only_use_own_samples)
+        h_neg, g_neg = hip_ops.stein(ctx, m.packed, x, ld, model_grads, bg, tgrad, d, mapping=map_dev,
+                                     map_offset=map_offset,
+                                     self_normalized=self._use_self_normalized_importance_weights,
+                                     own_samples_only=self._only_use_own_samples)
+        if m.diagonal_covs:
+            # :159-162 / :178-181: h[i] = E_w[g[i] (x[i] - mu[i]) / sigma[i]^2] is the diagonal of the dense estimate
+            # computed on L = diag(sigma) (the symmetrisation leaves the diagonal alone)
+            h_neg = hip_ops.diag_extract(ctx, h_neg)
+        return h_neg, g_neg
 
 
 class MoreNgEstimator(NgEstimator):
@@ -75,6 +81,9 @@ class MoreNgEstimator(NgEstimator):
         l2 = model.l2_regularizers.numpy()
         if not np.all(l2 == np.float32(initial_l2_regularizer)):                          # :293
             raise ValueError("model.l2_regularizers must equal initial_l2_regularizer")
+        if model.diagonal_covs:
+            raise ValueError("MoreNgEstimator needs a full-covariance model (the reference's QuadFunc whitening, "
+                             "least_squares.py:126-191, has no diagonal branch)")
         if model.num_dimensions > 21:
             raise ValueError("MoreNgEstimator: the HIP kernel supports D <= 21 (DESIGN.md section 7)")
         self.last_model_densities = None

@@ -78,11 +78,9 @@ class _HostGrowable:
 
 class SampleDB:
     def __init__(self, dim, diagonal_covariances, keep_samples, max_samples=None, ctx=None):
-        if diagonal_covariances:
-            raise NotImplementedError("diagonal GMMs are outside the hot-path scope (DESIGN.md, out of scope)")
         self.ctx = ctx if ctx is not None else get_context()
         self._dim = int(dim)
-        self.diagonal_covariances = False
+        self.diagonal_covariances = bool(diagonal_covariances)                                 # :32
         self.keep_samples = keep_samples
         self.max_samples = max_samples
         d = self._dim
@@ -91,7 +89,7 @@ class SampleDB:
         self._target_grads = _Growable(self.ctx, (d,))
         self._mapping_dev = _Growable(self.ctx, (), np.int32)
         self._means = _Growable(self.ctx, (d,))
-        self._chols = _Growable(self.ctx, (d, d))
+        self._chols = _Growable(self.ctx, (d,) if self.diagonal_covariances else (d, d))       # :36-41
         self._packed = _Growable(self.ctx, (hip_ops.packed_stride(d),))
         self._mapping_host = _HostGrowable(np.int32)
         self._num_samples_written = 0
@@ -120,6 +118,8 @@ class SampleDB:
     @property
     def inv_chols(self):
         """sample_db.py:121: explicit inverses (API compatibility; the density kernels solve with L directly)."""
+        if self.diagonal_covariances:                                                          # :119,:130
+            return hip_ops.reciprocal(self.ctx, self.chols)
         if self._means.n == 0:
             return self.ctx.empty((0, self._dim, self._dim))
         return hip_ops.pack_components(self.ctx, self.means, self.chols, want_inverse=True)[1]
@@ -152,6 +152,16 @@ class SampleDB:
     @property
     def num_samples_written(self):
         return SampleDB._Counter(self)
+
+    def _dense(self, chols):
+        """Dense lower-triangular factors for the density kernels ([K,D] standard deviations -> diag(sigma))."""
+        if chols.ndim == 2:
+            if not self.diagonal_covariances:
+                raise ValueError("SampleDB(diagonal_covariances=False) got [K,D] Cholesky factors")
+            return hip_ops.diag_embed(self.ctx, chols)
+        if self.diagonal_covariances:
+            raise ValueError("SampleDB(diagonal_covariances=True) got [K,D,D] Cholesky factors")
+        return chols
 
     # ---- mutation --------------------------------------------------------------------------------------------------
     def remove_every_nth_sample(self, N):
@@ -191,7 +201,7 @@ class SampleDB:
         if mapping_host is None:
             mapping_host = np.asarray(mapping.numpy() if isinstance(mapping, DeviceArray) else mapping, np.int32)
         if packed is None:
-            packed, _ = hip_ops.pack_components(ctx, means, chols)
+            packed, _ = hip_ops.pack_components(ctx, means, self._dense(chols))
         tl = ctx.asarray(target_lnpdfs); tg = ctx.asarray(target_grads)
         mapping = ctx.asarray(mapping, np.int32)
         if self.keep_samples:
@@ -233,7 +243,7 @@ class SampleDB:
         compatibility; the kernel solves with ``chols``."""
         ctx = self.ctx
         means = ctx.asarray(means); chols = ctx.asarray(chols)
-        packed, _ = hip_ops.pack_components(ctx, means, chols)
+        packed, _ = hip_ops.pack_components(ctx, means, self._dense(chols))
         w = np.asarray(weights.numpy() if hasattr(weights, "numpy") else weights, np.float64)
         _, lp, _ = hip_ops.mixture_eval(ctx, packed, ctx.asarray(np.log(w).astype(np.float32)), ctx.asarray(samples),
                                         self._dim, want_lp=True)

@@ -287,6 +287,38 @@ int gmmvi_allreduce_f32(gmmvi_ctx* ctx, float* buf_dev, size_t count, int op /* 
 int gmmvi_combine_partials(gmmvi_ctx* ctx, int R, int N, int D, const float* lp_parts_dev,
                            const float* grad_parts_dev, float* lp_out_dev, float* grad_out_dev);
 
+/* ---- diagonal-covariance GMMs (models/diagonal_gmm.py:6-59) ---------------------------------------------------- */
+/* chol[K,D] = sigma (square roots of the covariance diagonal).  Densities / gradients / sampling / background /
+ * Stein use the dense entry points above on L = diag(sigma):
+ * gmmvi_diag_embed writes dense[K,D,D] from diag[K,D]; gmmvi_diag_extract reads diag[K,D] = diagonal of dense[K,D,D]
+ * (the diagonal Stein estimate of gmmvi_modules/ng_estimator.py:159-162,:178-181 is the diagonal of gmmvi_stein's
+ * H_neg); gmmvi_reciprocal_f32 is SampleDB's inv_chols = 1 / chols (optimization/sample_db.py:119,:130). */
+int gmmvi_diag_embed(gmmvi_ctx* ctx, int K, int D, const float* diag_dev, float* dense_out_dev);
+int gmmvi_diag_extract(gmmvi_ctx* ctx, int K, int D, const float* dense_dev, float* diag_out_dev);
+int gmmvi_reciprocal_f32(gmmvi_ctx* ctx, const float* src_dev, size_t n, float* dst_dev);
+/* KLConstrainedNgBasedComponentUpdater.apply_NG_update, diagonal branches (gmmvi_modules/
+ * ng_based_component_updater.py:447-453, kl() :304-318, :483-490); same contract as gmmvi_update_components_kl with
+ * chols[K,D] and H_neg[K,D].  D <= GMMVI_MAX_DIM_BLOCKED. */
+int gmmvi_update_components_diag_kl(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_diag_dev,
+                                    const float* H_neg_diag_dev, const float* g_neg_dev, const float* stepsizes_dev,
+                                    float temperature, float l2_init, float* last_eta_dev, float* l2_dev,
+                                    float* num_received_updates_dev, int32_t* success_out_dev, float* kl_out_dev,
+                                    int32_t* n_probes_out_dev);
+/* NgBasedComponentUpdaterIblr, diagonal branches (:170-174, :188-189, :195-197).  (The reference's direct updater
+ * has no diagonal branch.) */
+int gmmvi_update_components_diag_iblr(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_diag_dev,
+                                      const float* H_neg_diag_dev, const float* g_neg_dev, const float* stepsizes_dev,
+                                      float l2_init, float* l2_dev, float* num_received_updates_dev,
+                                      int32_t* success_out_dev);
+
+/* ---- MMD (experiments/evaluation/mmd.py:41-58) ------------------------------------------------------------------ */
+/* sum_out = sum_{i<Na} sum_{j<Nb} exp(-sum_d inv_bandwidth[d] (A[i,d] - B[j,d])^2)  (fp32 pairs, fp64 sums, fixed
+ * summation order).  compute_ustat(sample) is (A, B) = (sample, sample); kernel_mix(sample) is (groundtruth, sample);
+ * inv_bandwidth[d] = 1 / (alpha * sigma[d,d]).  scratch_dev holds gmmvi_mmd_scratch_doubles(Na, Nb) doubles. */
+size_t gmmvi_mmd_scratch_doubles(int Na, int Nb);
+int gmmvi_mmd_pair_sum(gmmvi_ctx* ctx, const float* A_dev, int Na, const float* B_dev, int Nb, int D,
+                       const float* inv_bandwidth_dev, double* scratch_dev, double* sum_out_dev);
+
 #ifdef __cplusplus
 }
 #endif

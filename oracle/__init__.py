@@ -20,4 +20,4 @@ Every function cites the reference file:line (relative to /root/reference/src/gm
 whose arithmetic it restates.
 """
 
-from . import philox, gmm, targets, sample_db, stein, more, updaters, weights, stepsizes, adaptation, train  # noqa: F401
+from . import philox, gmm, targets, sample_db, stein, more, updaters, weights, stepsizes, adaptation, train, mmd  # noqa: F401

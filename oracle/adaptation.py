@@ -72,7 +72,8 @@ class VipsComponentAdaptation:
         d = self.model.num_dimensions
         h_unscaled = 0.5 * d * (np.log(2.0 * np.pi) + 1)
         c = np.exp((2 * (des_entropy - h_unscaled)) / d)
-        self.model.add_component(1e-29, new_mean, c * np.eye(d), [self.thresholds[it]], [des_entropy])
+        new_cov = c * np.ones(d) if self.model.diagonal_covs else c * np.eye(d)                       # :220-223
+        self.model.add_component(1e-29, new_mean, new_cov, [self.thresholds[it]], [des_entropy])
 
     def add_new_component(self):
         """:228-259."""

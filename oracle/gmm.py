@@ -1,6 +1,6 @@
-"""Oracle restatement of the full-covariance GMM and its wrapper.  TEST INFRASTRUCTURE.
+"""Oracle restatement of the full-covariance and diagonal GMMs and their wrapper.  TEST INFRASTRUCTURE.
 
-Follows models/full_cov_gmm.py:29-68, models/gmm.py:124-216,249-300,340-418 and
+Follows models/full_cov_gmm.py:29-68, models/diagonal_gmm.py:6-59, models/gmm.py:124-216,249-300,340-418 and
 models/gmm_wrapper.py:33-182 (paths relative to /root/reference/src/gmmvi).
 Gradients that the reference obtains by reverse-mode AD (models/gmm.py:294-300) are written
 analytically here and verified by central finite differences in tests/test_oracle_gmm.py.
@@ -24,6 +24,7 @@ def gaussian_log_pdf_from_chol(x, mean, chol):
 
 class FullCovGMM:
     """models/full_cov_gmm.py:6-68 + models/gmm.py:5-418, NumPy state instead of tf.Variable."""
+    diagonal_covs = False
 
     def __init__(self, weights, means, covs, dtype=np.float64):
         self.dtype = dtype
@@ -156,6 +157,68 @@ class FullCovGMM:
         self.replace_weights(np.delete(self.log_weights, idx))
         self.means = np.delete(self.means, idx, axis=0)
         self.chol_cov = np.delete(self.chol_cov, idx, axis=0)
+
+
+class DiagonalGMM(FullCovGMM):
+    """models/diagonal_gmm.py:6-59: chol_cov is [K, D] (square roots of the diagonal covariance entries)."""
+
+    def __init__(self, weights, means, covs, dtype=np.float64):
+        self.dtype = dtype
+        means = np.asarray(means, dtype=dtype)
+        self.num_dimensions = means.shape[1]
+        self.means = means.copy()
+        self.chol_cov = np.sqrt(np.asarray(covs, dtype=dtype))                                    # diagonal_gmm.py:23
+        self.log_weights = np.log(np.asarray(weights, dtype=dtype))
+        self.replace_weights(self.log_weights)
+        self.diagonal_covs = True                                                                # :28
+
+    @property
+    def covs(self):
+        return np.square(self.chol_cov)                                                          # :36-38
+
+    @staticmethod
+    def diagonal_gaussian_log_pdf(dim, mean, chol, x):
+        """:30-34."""
+        const = -0.5 * dim * np.log(2 * np.pi) - np.sum(np.log(chol))
+        return const - 0.5 * np.sum(np.square((1.0 / chol)[None, :] * (mean[None, :] - x)), axis=1)
+
+    def component_log_densities(self, samples):
+        """:47-53 -> [K, N]."""
+        samples = np.asarray(samples, dtype=self.dtype)
+        return np.stack([self.diagonal_gaussian_log_pdf(self.num_dimensions, self.means[i], self.chol_cov[i], samples)
+                         for i in range(self.num_components)])
+
+    def log_density_and_grad(self, samples):
+        """gmm.py:274-300 (reverse-mode AD upstream): grad = -sum_k r_k (x - mu_k) / sigma_k^2."""
+        samples = np.asarray(samples, dtype=self.dtype)
+        logq, cld = self.log_densities_also_individual(samples)
+        resp = np.exp(cld + self.log_weights[:, None] - logq[None, :])
+        grad = np.zeros_like(samples)
+        for i in range(self.num_components):
+            grad -= resp[i][:, None] * (samples - self.means[i]) / np.square(self.chol_cov[i])[None, :]
+        return logq, grad, cld
+
+    def component_marginal_log_densities(self, samples, dim):
+        var = self.covs[:, dim]
+        diffs = samples[None, :, dim] - self.means[:, dim, None]
+        return -0.5 * diffs * diffs / var[:, None] - 0.5 * np.log(var)[:, None] - 0.5 * np.log(2 * np.pi)
+
+    def gaussian_entropy(self, chol):
+        """:40-41."""
+        return 0.5 * self.num_dimensions * (np.log(2 * np.pi) + 1) + np.sum(np.log(chol))
+
+    def sample_from_components_no_shuffle(self, samples_per_component, eps):
+        """gmm.py:361-386 + diagonal_gmm.py:43-45: x = mu_k + sigma_k * eps."""
+        n_k = np.asarray(samples_per_component, dtype=np.int64)
+        mapping = np.repeat(np.arange(self.num_components, dtype=np.int32), n_k)
+        eps = np.asarray(eps, dtype=self.dtype)
+        return self.means[mapping] + self.chol_cov[mapping] * eps, mapping
+
+    def add_component(self, initial_weight, initial_mean, initial_cov):
+        """:55-59."""
+        self.means = np.concatenate([self.means, np.asarray(initial_mean, self.dtype)[None]], axis=0)
+        self.chol_cov = np.concatenate([self.chol_cov, np.sqrt(np.asarray(initial_cov, self.dtype))[None]], axis=0)
+        self.replace_weights(np.concatenate([self.log_weights, [np.log(self.dtype(initial_weight))]]))
 
 
 class GmmWrapper:

@@ -10,15 +10,16 @@ from . import philox
 
 class SampleDB:
     def __init__(self, dim, diagonal_covariances, keep_samples, max_samples=None, dtype=np.float64):
-        assert not diagonal_covariances, "diagonal GMMs are out of scope (SURVEY.md section 2, row 19)"
+        self.diagonal_covariances = bool(diagonal_covariances)                         # :32
         self._dim = dim
         self.dtype = dtype
         self.keep_samples = keep_samples
         self.max_samples = max_samples
         self.samples = np.zeros((0, dim), dtype)
         self.means = np.zeros((0, dim), dtype)
-        self.chols = np.zeros((0, dim, dim), dtype)
-        self.inv_chols = np.zeros((0, dim, dim), dtype)
+        cshape = (0, dim) if self.diagonal_covariances else (0, dim, dim)              # :36-41
+        self.chols = np.zeros(cshape, dtype)
+        self.inv_chols = np.zeros(cshape, dtype)
         self.target_lnpdfs = np.zeros(0, dtype)
         self.target_grads = np.zeros((0, dim), dtype)
         self.mapping = np.zeros(0, np.int32)
@@ -46,7 +47,10 @@ class SampleDB:
         if self.max_samples is not None and samples.shape[0] + self.samples.shape[0] > self.max_samples:
             self.remove_every_nth_sample(2)
         self.num_samples_written += samples.shape[0]
-        inv = np.linalg.inv(np.asarray(chols, dt))                                     # :121 / :132
+        if self.diagonal_covariances:
+            inv = 1.0 / np.asarray(chols, dt)                                          # :119 / :130
+        else:
+            inv = np.linalg.inv(np.asarray(chols, dt))                                 # :121 / :132
         if self.keep_samples:
             self.mapping = np.concatenate([self.mapping, np.asarray(mapping, np.int32) + self.chols.shape[0]])
             self.means = np.concatenate([self.means, np.asarray(means, dt)])
@@ -71,7 +75,10 @@ class SampleDB:
         return self.samples[idx], self.target_lnpdfs[idx]
 
     def gaussian_log_pdf(self, mean, chol, inv_chol, x):
-        """sample_db.py:154-162 (full-covariance branch): uses inv_chol @ (mean - x)^T."""
+        """sample_db.py:154-162: uses inv_chol @ (mean - x)^T (diagonal branch :155-158: elementwise)."""
+        if self.diagonal_covariances:
+            const = -0.5 * self._dim * np.log(2 * np.pi) - np.sum(np.log(chol))
+            return const - 0.5 * np.sum(np.square(inv_chol[:, None] * (mean[None, :] - x).T), axis=0)
         const = -0.5 * self._dim * np.log(2 * np.pi) - np.sum(np.log(np.diag(chol)))
         return const - 0.5 * np.sum(np.square(inv_chol @ (mean - x).T), axis=0)
 

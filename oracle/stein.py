@@ -33,13 +33,17 @@ def get_rewards_for_comp(index, samples, mapping, component_log_densities, log_r
 
 def expected_gradient_and_hessian_self_normalized(chol_cov, mean, component_log_densities, samples,
                                                   background_densities, log_ratio_grads):
-    """ng_estimator.py:171-188 (full-covariance branch); note the double normalisation (:174-176) and the
-    orientation H[i, j] = sum_n wg[n, i] * y[n, j] before symmetrising (:184-186)."""
+    """ng_estimator.py:171-188; note the double normalisation (:174-176) and the orientation
+    H[i, j] = sum_n wg[n, i] * y[n, j] before symmetrising (:184-186).  Diagonal branch (:178-181, chol_cov [D]):
+    only the diagonal  h[i] = sum_n wg[n, i] (x[n, i] - mu[i]) / sigma[i]^2  is estimated."""
     lw = component_log_densities - background_densities
     lw = lw - logsumexp(lw)
     w = np.exp(lw)
     iw = w / np.sum(w)
     wg = iw[:, None] * log_ratio_grads
+    if chol_cov.ndim == 1:
+        prec_times_diff = (1.0 / np.square(chol_cov))[:, None] * (samples - mean).T             # [D, N]
+        return np.sum(wg, axis=0), np.sum(prec_times_diff.T * wg, axis=0)
     y = cho_solve((chol_cov, True), (samples - mean).T)          # Sigma^{-1}(x - mu): [D, N]
     h = np.einsum('ni,nj->ij', wg, y.T)
     h = 0.5 * (h + h.T)
@@ -48,9 +52,12 @@ def expected_gradient_and_hessian_self_normalized(chol_cov, mean, component_log_
 
 def expected_gradient_and_hessian_standard(chol_cov, mean, component_log_densities, samples,
                                            background_densities, log_ratio_grads):
-    """ng_estimator.py:154-169 (full-covariance branch): plain importance weights, NOT symmetrised."""
+    """ng_estimator.py:154-169: plain importance weights, NOT symmetrised (diagonal branch :159-162)."""
     lw = component_log_densities - background_densities
     g = _signed_expectation(lw, log_ratio_grads)
+    if chol_cov.ndim == 1:
+        prec_times_diff = (1.0 / np.square(chol_cov))[:, None] * (samples - mean).T
+        return g, _signed_expectation(lw, prec_times_diff.T * log_ratio_grads)
     y = cho_solve((chol_cov, True), (samples - mean).T)
     prod = y.T[:, None, :] * log_ratio_grads[:, :, None]         # [n, i, j] = g[n, i] * y[n, j]   (:165-166)
     h = _signed_expectation(lw, prod)
@@ -59,7 +66,7 @@ def expected_gradient_and_hessian_standard(chol_cov, mean, component_log_densiti
 
 def get_expected_hessian_and_grad(model, samples, mapping, background_densities, target_lnpdfs, target_lnpdf_grads,
                                   only_use_own_samples=False, use_self_normalized_importance_weights=True):
-    """ng_estimator.py:204-263.  Returns (expected_hessian_neg [K,D,D], expected_gradient_neg [K,D])."""
+    """ng_estimator.py:204-263.  Returns (expected_hessian_neg [K,D,D] -- [K,D] for a diagonal model --, expected_gradient_neg [K,D])."""
     k = model.num_components
     relative_mapping = mapping - (np.max(mapping) if mapping.size else 0) + k - 1        # :244
     model_densities, model_grads, cld = model.log_density_and_grad(samples)            # :246

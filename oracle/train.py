@@ -10,10 +10,20 @@ from . import philox, sample_db as odb, stein, more, updaters, weights as oweigh
 
 
 def construct_initial_mixture(num_dimensions, num_initial_components, prior_mean, prior_scale, initial_cov, rng,
-                              dtype=np.float64):
-    """setup_experiment.py:88-160 (full-covariance branch), NumPy Generator instead of np.random global."""
+                              dtype=np.float64, use_diagonal_covs=False):
+    """setup_experiment.py:88-160, NumPy Generator instead of np.random global."""
     prior_mean = np.broadcast_to(np.asarray(prior_mean, float), (num_dimensions,))
     prior_scale = np.broadcast_to(np.asarray(prior_scale, float), (num_dimensions,))
+    if use_diagonal_covs:                                                                        # :129-141
+        prior = prior_scale ** 2
+        cov = prior if initial_cov is None else np.asarray(initial_cov, float) * np.ones(num_dimensions)
+        means = np.zeros((num_initial_components, num_dimensions))
+        for i in range(num_initial_components):
+            means[i] = prior_mean if num_initial_components == 1 else \
+                prior_mean + np.sqrt(prior) * rng.standard_normal(num_dimensions)
+        w = np.ones(num_initial_components, np.float32) / num_initial_components
+        covs = np.broadcast_to(cov.astype(np.float32), (num_initial_components, num_dimensions))
+        return ogmm.DiagonalGMM(w, means.astype(np.float32), covs, dtype=dtype)
     prior = np.diag(prior_scale ** 2)
     cov = prior if initial_cov is None else np.asarray(initial_cov, float) * np.eye(num_dimensions)
     w = np.ones(num_initial_components) / num_initial_components
@@ -52,7 +62,7 @@ class OracleGMMVI:
         self.temperature = temperature
         self.target = target
         self.model = ogmm.GmmWrapper(model, cs["initial_stepsize"], initial_l2_regularizer, max_reward_history_length)
-        self.sample_db = odb.SampleDB(model.num_dimensions, False, keep_samples, max_database_size, model.dtype)
+        self.sample_db = odb.SampleDB(model.num_dimensions, model.diagonal_covs, keep_samples, max_database_size, model.dtype)
         sel = odb.VipsSampleSelector if sample_selector == "component-based" else odb.LinSampleSelector
         self.sample_selector = sel(target, self.model, self.sample_db, desired_samples_per_component,
                                    ratio_reused_samples_to_desired, seed)

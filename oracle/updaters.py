@@ -37,11 +37,23 @@ def _update_l2(wrapper, successes):
 # ---------------------------------------------------------------------------------------------------
 
 def kl(eta, old_lin, old_prec, old_inv_chol, reward_lin, reward_quad, kl_const_part, old_mean, eta_in_logspace):
-    """:244-333 (full-covariance branch).  Returns (kl, new_mean, new_precision, inv_chol_inv)."""
+    """:244-333.  Returns (kl, new_mean, new_precision, inv_chol_inv).  Diagonal branch (:304-318, all operands
+    [D]): no failure test -- a negative new precision gives a NaN KL, which the search treats as "KL too large"
+    (both comparisons false, :410-419) and the final ``kl < float32.max`` test rejects (:488)."""
     if eta_in_logspace:
         eta = np.exp(eta)
     new_lin = (eta * old_lin + reward_lin) / eta
     new_prec = (eta * old_prec + reward_quad) / eta
+    if np.ndim(old_prec) == 1:
+        with np.errstate(invalid='ignore', divide='ignore'):
+            chol_prec = np.sqrt(new_prec)
+            new_mean = 1.0 / new_prec * new_lin
+            inv_chol_inv = 1.0 / chol_prec
+            diff = old_mean - new_mean
+            inner = np.sum(np.log(new_prec / old_prec) + old_prec / new_prec) - old_mean.shape[0]
+            inner = inner if np.isnan(inner) else max(0.0, inner)              # tf.maximum propagates NaN
+            val = 0.5 * (inner + np.sum(np.square(old_inv_chol * diff)))                          # :314-317
+        return val, new_mean, new_prec, inv_chol_inv
     c = _chol(new_prec)
     if c is None:                                                    # :320-324
         return FLOAT32_MAX, old_mean, old_prec, old_inv_chol
@@ -97,11 +109,19 @@ def apply_ng_update_kl(wrapper, expected_hessians_neg, expected_gradients_neg, s
         last_eta = wrapper.last_log_etas[i]
         eps = stepsizes[i]
         reward_quad = expected_hessians_neg[i]
-        reward_lin = reward_quad @ old_mean - expected_gradients_neg[i]            # :455
-        old_logdet = 2.0 * np.sum(np.log(np.diag(old_chol)))                        # :456
-        old_inv_chol = _tri_inv(old_chol)                                           # :457
-        old_prec = old_inv_chol.T @ old_inv_chol                                    # :458
-        old_lin = old_prec @ old_mean                                               # :459
+        diag = np.ndim(old_chol) == 1                                               # model.diagonal_covs
+        if diag:                                                                    # :447-453
+            reward_lin = reward_quad * old_mean - expected_gradients_neg[i]
+            old_logdet = 2.0 * np.sum(np.log(old_chol))
+            old_inv_chol = 1.0 / old_chol
+            old_prec = old_inv_chol ** 2
+            old_lin = old_prec * old_mean
+        else:
+            reward_lin = reward_quad @ old_mean - expected_gradients_neg[i]        # :455
+            old_logdet = 2.0 * np.sum(np.log(np.diag(old_chol)))                    # :456
+            old_inv_chol = _tri_inv(old_chol)                                       # :457
+            old_prec = old_inv_chol.T @ old_inv_chol                                # :458
+            old_lin = old_prec @ old_mean                                           # :459
         kl_const = old_logdet - d                                                   # :460
         if last_eta < 0:                                                            # :462-471
             lb, ub = dt(-20.0), dt(80.0)
@@ -119,9 +139,9 @@ def apply_ng_update_kl(wrapper, expected_hessians_neg, expected_gradients_neg, s
             success = True
             this_kl, new_mean, _, cinv = kl(eta, old_lin, old_prec, old_inv_chol, reward_lin, reward_quad,
                                             kl_const, old_mean, False)
-            new_cov = cinv.T @ cinv                                                 # :486
+            new_cov = np.square(cinv) if diag else cinv.T @ cinv                    # :483-486
             if this_kl < FLOAT32_MAX:
-                new_chol = _chol(new_cov)                                           # :492
+                new_chol = np.sqrt(new_cov) if diag else _chol(new_cov)             # :489-492
                 if new_chol is None:
                     success = False
             else:
@@ -174,13 +194,30 @@ def apply_ng_update_direct(wrapper, expected_hessians_neg, expected_gradients_ne
 
 
 def apply_ng_update_iblr(wrapper, expected_hessians_neg, expected_gradients_neg, stepsizes):
-    """:160-223 (full-covariance branch); the first update of a component leaves its mean alone (:184-186)."""
+    """:160-223; the first update of a component leaves its mean alone (:184-186).  Diagonal branch: elementwise
+    (:170-174, :188-189, :195-197), failure = NaN in sqrt(1 / new_precision) (:202)."""
     model = wrapper.model
     k = model.num_components
     means, chols, succ = [], [], []
     for i in range(k):
         old_chol, old_mean = model.chol_cov[i], model.means[i]
         h = expected_hessians_neg[i]
+        if np.ndim(old_chol) == 1:                                                   # model.diagonal_covs
+            correction = stepsizes[i] / 2 * h * old_chol * old_chol * h
+            old_prec = (1.0 / old_chol) ** 2
+            delta_mean = -expected_gradients_neg[i]
+            if wrapper.num_received_updates[i] == 0:
+                new_mean = old_mean
+            else:
+                new_mean = old_mean + stepsizes[i] * old_chol * old_chol * delta_mean
+            new_prec = old_prec + stepsizes[i] * (h + correction)
+            with np.errstate(invalid='ignore', divide='ignore'):
+                new_chol = np.sqrt(1.0 / new_prec)
+            ok = not np.any(np.isnan(new_chol))
+            if not ok:
+                new_mean, new_chol = old_mean, old_chol
+            means.append(new_mean); chols.append(new_chol); succ.append(ok)
+            continue
         correction = stepsizes[i] / 2 * h @ old_chol @ old_chol.T @ h                # :176-177
         old_inv_chol = _tri_inv(old_chol)
         old_prec = old_inv_chol.T @ old_inv_chol

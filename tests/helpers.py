@@ -5,11 +5,11 @@ from oracle import targets as otargets, train as otrain
 
 
 def samtron_config(desired_samples, reuse_ratio=0.0, initial_stepsize=0.1, adaptive=None, updater="trust-region",
-                   weight_updater="trust-region", snis=True, own=False, wstep=1.0, estimator="Stein"):
+                   weight_updater="trust-region", snis=True, own=False, wstep=1.0, estimator="Stein", diag=False):
     """SAMTRON-style config dict with the keys of the reference's example_config.yml."""
     cfg = {
         "temperature": 1.0, "use_sample_database": True, "max_database_size": 10000000, "seed": 0,
-        "model_initialization": {"use_diagonal_covs": False, "prior_mean": 0., "initial_cov": 1.0},
+        "model_initialization": {"use_diagonal_covs": bool(diag), "prior_mean": 0., "initial_cov": 1.0},
         "ng_estimator_type": estimator,
         "ng_estimator_config": dict({"only_use_own_samples": own, "use_self_normalized_importance_weights": snis},
                                     **({"initial_l2_regularizer": 1e-12} if estimator == "MORE" else {})),
@@ -42,6 +42,10 @@ def make_oracle_target(kind, d, seed):
         return otargets.make_stm_target(d, rng)
     if kind == "gmm":
         return otargets.make_gmm_target(d, rng, num_components=4)
+    if kind == "diaggmm":                      # target_distributions/diag_gmm.py:33-45 law, 4 components
+        means = 100 * (rng.random((4, d)) - 0.5) * 0.2
+        covs = 10 * rng.random((4, d)) + 0.5
+        return otargets.GmmTarget(np.ones(4) / 4, means, [np.diag(c) for c in covs])
     if kind == "gauss":
         a = rng.normal(size=(d, d))
         return otargets.GmmTarget([1.0], [rng.normal(size=d) * 3], [a @ a.T + np.eye(d)])
@@ -58,13 +62,16 @@ def init_params(kind, d, k, seed):
         return 10.0, 30.0
     if kind == "gmm":
         return 30.0, 100.0
+    if kind == "diaggmm":
+        return 10.0, 20.0
     return 5.0, 10.0
 
 
 def make_oracle(kind, d, k, s, seed, cfg, dtype=np.float64):
     tgt = make_oracle_target(kind, d, seed)
     ps, ic = init_params(kind, d, k, seed)
-    model = otrain.construct_initial_mixture(d, k, 0.0, ps, ic, np.random.default_rng(seed + 1), dtype=dtype)
+    model = otrain.construct_initial_mixture(d, k, 0.0, ps, ic, np.random.default_rng(seed + 1), dtype=dtype,
+                                             use_diagonal_covs=cfg["model_initialization"]["use_diagonal_covs"])
     algo = otrain.OracleGMMVI(
         tgt, model, temperature=cfg["temperature"], seed=seed,
         desired_samples_per_component=cfg["sample_selector_config"]["desired_samples_per_component"],
@@ -96,10 +103,17 @@ def make_device(kind, d, k, s, seed, cfg, oracle_algo):
         tgt = StudentTMixture_LNPDF(t.weights, t.means, t.covs, alpha=2)
     elif kind in ("gmm", "gauss"):
         tgt = GMM_LNPDF(t.weights, t.means, t.covs)
+    elif kind == "diaggmm":
+        from gmmvi_amd.experiments.target_distributions.diag_gmm import DIAGGMM_LNPDF
+        tgt = DIAGGMM_LNPDF(t.weights, t.means, np.stack([np.diag(c) for c in t.covs]))
     else:
         tgt = PlanarRobot(d, 4)
     om = oracle_algo.model.model
-    model = FullCovGMM(om.weights, om.means.astype(np.float32), om.covs.astype(np.float32))
+    if om.diagonal_covs:
+        from gmmvi_amd.models.diagonal_gmm import DiagonalGMM
+        model = DiagonalGMM(om.weights, om.means.astype(np.float32), om.covs.astype(np.float32))
+    else:
+        model = FullCovGMM(om.weights, om.means.astype(np.float32), om.covs.astype(np.float32))
     model.seed = seed
     wrapper = GmmWrapper(model, cfg["component_stepsize_adapter_config"]["initial_stepsize"], 1e-12, 400)
     cfg = dict(cfg)

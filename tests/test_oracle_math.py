@@ -426,3 +426,114 @@ def test_elbo_nondecreasing_on_stm():
         algo.train_iter()
     e1 = algo.elbo(4000, 7)[0]
     assert e1 > e0 + 1.0 and e1 <= 0.2        # normalised target: ELBO <= log Z = 0 (up to MC noise)
+
+
+# ---- diagonal-covariance branches and MMD (models/diagonal_gmm.py, experiments/evaluation/mmd.py) --------------------
+
+def _diag_and_full(rng, k, d):
+    from oracle import gmm as og
+    means = rng.normal(size=(k, d)) * 2
+    var = rng.uniform(0.4, 2.5, size=(k, d))
+    w = rng.random(k) + 0.1
+    w /= w.sum()
+    return og.DiagonalGMM(w, means, var), og.FullCovGMM(w, means, np.stack([np.diag(v) for v in var]))
+
+
+def test_diagonal_gmm_matches_scipy_and_full_cov_oracle(rng):
+    from scipy.stats import multivariate_normal
+    dm, fm = _diag_and_full(rng, 4, 6)
+    x = rng.normal(size=(50, 6)) * 2
+    ld = dm.component_log_densities(x)
+    for i in range(4):
+        np.testing.assert_allclose(ld[i], multivariate_normal(dm.means[i], np.diag(dm.covs[i])).logpdf(x), rtol=1e-10)
+    for a, b in zip(dm.log_density_and_grad(x), fm.log_density_and_grad(x)):
+        np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-12)
+    eps = 1e-5                                              # central finite differences of the analytic gradient
+    g = dm.log_density_and_grad(x)[1]
+    for c in range(6):
+        e = np.zeros(6); e[c] = eps
+        np.testing.assert_allclose(g[:, c], (dm.log_density(x + e) - dm.log_density(x - e)) / (2 * eps), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(dm.get_average_entropy(), fm.get_average_entropy(), rtol=1e-12)
+
+
+@pytest.mark.parametrize("snis", [True, False])
+def test_diagonal_stein_is_the_diagonal_of_the_full_estimate(rng, snis):
+    """ng_estimator.py:159-162 / :178-181 against the full-covariance branch on L = diag(sigma)."""
+    from oracle import stein
+    dm, fm = _diag_and_full(rng, 3, 5)
+    n = 300
+    x = rng.normal(size=(n, 5)) * 2
+    bg = dm.log_density(x) + 0.1 * rng.normal(size=n)
+    tlp, tg = rng.normal(size=n), rng.normal(size=(n, 5))
+    mp = np.sort(rng.integers(0, 3, n)).astype(np.int32)
+    hd, gd = stein.get_expected_hessian_and_grad(dm, x, mp, bg, tlp, tg, False, snis)
+    hf, gf = stein.get_expected_hessian_and_grad(fm, x, mp, bg, tlp, tg, False, snis)
+    np.testing.assert_allclose(hd, np.stack([np.diag(h) for h in hf]), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(gd, gf, rtol=1e-12)
+
+
+def test_diagonal_kl_update_matches_closed_form_and_full_cov_updater(rng):
+    from oracle import gmm as og, updaters
+    dm, fm = _diag_and_full(rng, 4, 5)
+    hs = rng.uniform(0.1, 1.0, size=(4, 5))
+    gs = rng.normal(size=(4, 5))
+    old_means, old_var = dm.means.copy(), dm.covs.copy()
+    wd, wf = og.GmmWrapper(dm, 1.0, 1e-12, 4), og.GmmWrapper(fm, 1.0, 1e-12, 4)
+    eps = np.array([0.01, 0.05, 0.2, 0.5])
+    sd, etas_d, kls_d, _ = updaters.apply_ng_update_kl(wd, hs, gs, eps, 1.0, traces=[])
+    sf, etas_f, kls_f, _ = updaters.apply_ng_update_kl(wf, np.stack([np.diag(h) for h in hs]), gs, eps, 1.0, traces=[])
+    assert sd.all() and sf.all()
+    np.testing.assert_allclose(etas_d, etas_f, rtol=1e-9)
+    np.testing.assert_allclose(dm.means, fm.means, rtol=1e-9)
+    np.testing.assert_allclose(dm.chol_cov, np.stack([np.diag(c) for c in fm.chol_cov]), rtol=1e-9)
+    # the reported KL is the closed-form Gaussian KL(new || old) and respects the bound
+    new_var = dm.covs
+    kl = 0.5 * np.sum(np.log(old_var / new_var) + new_var / old_var - 1 + np.square(dm.means - old_means) / old_var, axis=1)
+    np.testing.assert_allclose(kls_d, kl, rtol=1e-8, atol=1e-12)
+    assert np.all(kls_d < 1.1 * eps)
+
+
+def test_diagonal_iblr_matches_full_cov_updater(rng):
+    from oracle import gmm as og, updaters
+    dm, fm = _diag_and_full(rng, 3, 4)
+    hs = rng.uniform(-0.2, 1.0, size=(3, 4))
+    gs = rng.normal(size=(3, 4))
+    wd, wf = og.GmmWrapper(dm, 1.0, 1e-12, 4), og.GmmWrapper(fm, 1.0, 1e-12, 4)
+    for _ in range(2):
+        sd = updaters.apply_ng_update_iblr(wd, hs, gs, np.full(3, 0.2))
+        sf = updaters.apply_ng_update_iblr(wf, np.stack([np.diag(h) for h in hs]), gs, np.full(3, 0.2))
+        np.testing.assert_array_equal(sd, sf)
+        np.testing.assert_allclose(dm.means, fm.means, rtol=1e-9)
+        np.testing.assert_allclose(dm.chol_cov, np.stack([np.diag(c) for c in fm.chol_cov]), rtol=1e-9)
+
+
+def test_diagonal_sample_db_background_matches_full(rng):
+    from oracle import sample_db as odb
+    dm, fm = _diag_and_full(rng, 3, 4)
+    x = rng.normal(size=(30, 4))
+    mp = np.repeat(np.arange(3), 10).astype(np.int32)
+    dbd, dbf = odb.SampleDB(4, True, True), odb.SampleDB(4, False, True)
+    for db, m in ((dbd, dm), (dbf, fm)):
+        db.add_samples(x, m.means, m.chol_cov, np.zeros(30), np.zeros((30, 4)), mp)
+    assert dbd.chols.shape == (3, 4) and dbd.inv_chols.shape == (3, 4)
+    np.testing.assert_allclose(dbd.get_newest_samples(30)[0], dbf.get_newest_samples(30)[0], rtol=1e-10)
+
+
+def test_mmd_oracle_properties(rng):
+    from oracle import mmd
+    gt = rng.normal(size=(60, 3)) * np.array([0.5, 1.0, 2.0])
+    sigma = mmd.compute_sigma(gt)
+    # "nearest" median of the i <= j squared differences, against a direct sort
+    iu, ju = np.triu_indices(60)
+    g32 = gt.astype(np.float32)
+    for c in range(3):
+        col = np.sort(np.square(g32[iu, c] - g32[ju, c]))
+        assert sigma[c, c] == col[int(np.round((len(col) - 1) * 0.5))]
+    assert abs(mmd.compute_mmd(gt, gt, 10.0, sigma)) < 1e-12
+    shifted = gt + 3.0
+    assert mmd.compute_mmd(gt, shifted, 10.0, sigma) > mmd.compute_mmd(gt, gt + 0.1, 10.0, sigma) > 0
+    # pair_sum against the dense formula
+    a, b = rng.normal(size=(7, 3)), rng.normal(size=(5, 3))
+    k = np.linalg.inv(10.0 * sigma)
+    dense = sum(np.exp(-(x - y) @ k @ (x - y)) for x in a for y in b)
+    np.testing.assert_allclose(mmd.pair_sum(a, b, k), dense, rtol=1e-12)
