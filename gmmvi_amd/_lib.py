@@ -14,6 +14,15 @@ MAX_DIM = 64
 MORE_MAX_DIM = 21
 
 
+def blocked_above():
+    """Dimensions above this take the blocked (MFMA) path: csrc/blocked.h gmmvi_blocked_above(), same environment knob."""
+    try:
+        t = int(os.environ.get("GMMVI_BLOCKED_ABOVE", MAX_DIM))
+    except ValueError:
+        t = MAX_DIM
+    return min(max(t, 16), MAX_DIM)
+
+
 class GmmviError(RuntimeError):
     pass
 

@@ -4,10 +4,21 @@
 // D <= 64.  Component block of this path (floats): [mu (D) | log-normaliser | pad to 4 | L^-1 dense row-major (D x D)].
 #pragma once
 #include "common.h"
+#include <cstdlib>
 
 #define GMMVI_BLOCKED_MAX_DIM GMMVI_MAX_DIM_BLOCKED
 
-inline bool gmmvi_is_blocked_dim(int D) { return D > GMMVI_MAX_DIM && D <= GMMVI_BLOCKED_MAX_DIM; }
+// Dimensions above this threshold take the blocked path.  Default GMMVI_MAX_DIM (the register-resident kernels' limit);
+// GMMVI_BLOCKED_ABOVE=<16..64> lowers it (the MFMA contractions overtake the vector substitution somewhere below 64).
+inline int gmmvi_blocked_above() {
+    static const int v = [] {
+        const char* s = getenv("GMMVI_BLOCKED_ABOVE");
+        const int t = s ? atoi(s) : GMMVI_MAX_DIM;
+        return t < 16 ? 16 : (t > GMMVI_MAX_DIM ? GMMVI_MAX_DIM : t);
+    }();
+    return v;
+}
+inline bool gmmvi_is_blocked_dim(int D) { return D > gmmvi_blocked_above() && D <= GMMVI_BLOCKED_MAX_DIM; }
 inline int gmmvi_blocked_linv_ofs(int D) { return ((D + 1 + 3) / 4) * 4; }
 inline size_t gmmvi_blocked_stride(int D) { return (size_t)gmmvi_blocked_linv_ofs(D) + (size_t)D * D; }
 

@@ -70,6 +70,7 @@ class SamtronFastPath:
               and not est._only_use_own_samples
               and est._use_self_normalized_importance_weights == wu.use_self_normalized_importance_weights
               and g.sample_db.keep_samples and g.model.num_dimensions < _lib.MAX_DIM
+              and g.model.num_dimensions <= _lib.blocked_above()
               and not g.model.diagonal_covs)
         return bool(ok)
 
