@@ -58,10 +58,6 @@ void gmmvi_ctx_destroy(gmmvi_ctx* ctx) {
     }
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->arena) (void)hipFree(ctx->arena);
-    if (ctx->ws_alt) (void)hipFree(ctx->ws_alt);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->stream_alt) (void)hipStreamDestroy(ctx->stream_alt);
     if (ctx->zc_hash) (void)hipFree(ctx->zc_hash);
     delete ctx;
 }

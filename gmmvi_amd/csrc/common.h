@@ -24,12 +24,6 @@ struct gmmvi_ctx {
     unsigned long long* zc_hash = nullptr;       // device: [0,1] recorded with Z, [2,3] current call, [4] match flag
     void* arena = nullptr;       // persistent scratch of the single-call iteration (fused.hip)
     size_t arena_bytes = 0;
-    // second stream + scratch of the single-call iteration: the target evaluation of the fresh samples runs beside the
-    // model / background density sweep (both only read the samples); fork / join through events (fused.hip)
-    hipStream_t stream_alt = nullptr;
-    void* ws_alt = nullptr;
-    size_t ws_alt_bytes = 0;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     void* comm = nullptr;        // ncclComm_t
     int n_ranks = 1, rank = 0;
     int num_cus = 256;

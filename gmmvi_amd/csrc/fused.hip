@@ -8,8 +8,6 @@
 #include "common.h"
 #include "stepsize_rules.h"
 #include "iter_prep.h"
-#include <cstdlib>
-#include <utility>
 
 namespace {
 struct Arena {
@@ -28,36 +26,6 @@ static int arena_reserve(gmmvi_ctx* ctx, size_t floats) {
     size_t want = floats * sizeof(float) * 3 / 2;
     GMMVI_HIP_CHECK(ctx, hipMalloc(&ctx->arena, want));
     ctx->arena_bytes = want;
-    return GMMVI_OK;
-}
-
-// Fork: the side stream waits for everything issued so far on the main stream, then ctx->stream / ctx->ws name the side
-// stream and its own scratch until side_end().  Join: the main stream waits for the side stream's work.
-static bool overlap_enabled() {
-    static const bool on = [] { const char* s = getenv("GMMVI_OVERLAP"); return !(s && s[0] == '0'); }();
-    return on;
-}
-
-static int side_begin(gmmvi_ctx* ctx) {
-    if (!ctx->stream_alt) {
-        GMMVI_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream_alt, hipStreamNonBlocking));
-        GMMVI_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        GMMVI_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    }
-    GMMVI_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-    GMMVI_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream_alt, ctx->ev_fork, 0));
-    std::swap(ctx->stream, ctx->stream_alt);
-    std::swap(ctx->ws, ctx->ws_alt);
-    std::swap(ctx->ws_bytes, ctx->ws_alt_bytes);
-    return GMMVI_OK;
-}
-
-static int side_end(gmmvi_ctx* ctx) {
-    hipError_t e = hipEventRecord(ctx->ev_join, ctx->stream);          // ctx->stream is the side stream here
-    std::swap(ctx->stream, ctx->stream_alt);
-    std::swap(ctx->ws, ctx->ws_alt);
-    std::swap(ctx->ws_bytes, ctx->ws_alt_bytes);
-    GMMVI_HIP_CHECK(ctx, e);
     return GMMVI_OK;
 }
 
@@ -110,27 +78,16 @@ extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan
         GMMVI_TRY(gmmvi_sample_components_prep(ctx, K, D, p->means, p->chols, p->offsets, N, (N + K - 1) / K, p->seed,
                                                p->first_index, x, p->db_mapping, p->mapping_base, q));
     }
-    // The target evaluation and the model / background sweep both only read the fresh samples: the former runs on the side
-    // stream (own scratch) while the latter is issued on the main stream; the Stein estimate needs both (join).
-    const bool overlap = overlap_enabled();
-    if (overlap) GMMVI_TRY(side_begin(ctx));
-    int rc_t;
     if (p->target_kind == 1) {
-        rc_t = gmmvi_target_planar(ctx, D, p->planar_prior_std, p->planar_goals_count, p->planar_goals,
-                                   p->planar_likelihood_std, x, N, p->db_tlp, p->db_tgrad);
+        GMMVI_TRY(gmmvi_target_planar(ctx, D, p->planar_prior_std, p->planar_goals_count, p->planar_goals,
+                                      p->planar_likelihood_std, x, N, p->db_tlp, p->db_tgrad));
     } else {
-        rc_t = gmmvi_mixture_eval(ctx, p->target_family, p->target_nu, p->target_K, D, p->target_packed, p->target_logw, x,
-                                  N, nullptr, p->db_tlp, p->db_tgrad);
+        GMMVI_TRY(gmmvi_mixture_eval(ctx, p->target_family, p->target_nu, p->target_K, D, p->target_packed,
+                                     p->target_logw, x, N, nullptr, p->db_tlp, p->db_tgrad));
     }
-    if (overlap) {
-        const int rc_e = side_end(ctx);
-        if (rc_t == GMMVI_OK) rc_t = rc_e;
-    }
-    GMMVI_TRY(rc_t);
     // ---- background + model density / gradient in one sweep (sample_db.py:194-228, gmm.py:274-300) ------------------------
     GMMVI_TRY(gmmvi_mixture_eval_dual(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, p->logw, p->bg_logw, x, N, a.ld, a.lq, a.qgrad,
                                       a.bg));
-    if (overlap) GMMVI_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     // ---- component update (gmmvi.py:165-169) -----------------------------------------------------------------------------
     GMMVI_TRY(gmmvi_stein(ctx, K, D, p->packed, x, N, a.ld, a.qgrad, a.bg, p->db_tgrad, nullptr, 0, p->stein_flags, a.H,
                           a.g));
