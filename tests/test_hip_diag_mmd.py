@@ -250,3 +250,41 @@ def test_mmd_class_matches_oracle(ctx, rng):
     assert abs(mmd.compute_MMD(ctx.asarray(gt))) < 1e-6          # MMD(X, X) = 0
     mmd.set_alpha(5.0)
     np.testing.assert_allclose(mmd.compute_MMD(sample), ommd.compute_mmd(gt, sample, 5.0, sigma), rtol=1e-3, atol=1e-6)
+
+
+def test_runner_diagonal_model_with_mmd(tmp_path):
+    """GmmviRunner flow (configs -> runner -> iterate_and_log -> npz dumps) with a diagonal model
+    (model_initialization.use_diagonal_covs), the DIAGGMM target of setup_experiment.py:71-73 and the MMD metric of
+    gmmvi_runner.py:45-54,140-142; the default SAMTRON modules incl. sample reuse and component adaptation."""
+    from gmmvi.gmmvi_runner import GmmviRunner
+    from gmmvi.configs import update_config, get_default_experiment_config, get_default_algorithm_config
+    from gmmvi.experiments.target_distributions.diag_gmm import make_target
+    np.random.seed(3)
+    groundtruth = make_target(6).sample(500)[0].numpy()          # the runner reseeds: same target below (seed 3)
+    np.save(tmp_path / "gt.npy", groundtruth)
+    algorithm_config = get_default_algorithm_config("SAMTRON")
+    environment_config = update_config(get_default_experiment_config("gmm20"), {"start_seed": 3})
+    used = {"environment_name": "DIAGGMM6", "environment_config": {"num_dimensions": 6},
+            "model_initialization": {"use_diagonal_covs": True, "num_initial_components": 4, "prior_scale": 30.,
+                                     "initial_cov": 100.},
+            "num_component_adapter_config": {"del_iters": 100, "add_iters": 5},
+            "sample_selector_config": {"desired_samples_per_component": 60},
+            "gmmvi_runner_config": {"log_metrics_interval": 10},
+            "mmd_evaluation_config": {"sample_dir": str(tmp_path / "gt.npy"), "alpha": 20.},
+            "dump_gmm_path": str(tmp_path)}
+    config = update_config(environment_config, update_config(algorithm_config, used))
+    runner = GmmviRunner.build_from_config(config=config)
+    assert runner.gmmvi.model.diagonal_covs and runner.gmmvi.sample_db.diagonal_covariances
+    elbos, mmds = [], []
+    for n in range(41):
+        metrics = runner.iterate_and_log(n)
+        runner.log_to_disk(n)
+        if "-elbo" in metrics:
+            elbos.append(-metrics["-elbo"])
+            mmds.append(metrics["MMD:"])
+    runner.finalize()
+    assert runner.gmmvi.model.num_components > 4
+    assert elbos[-1] > elbos[0] and all(e == e for e in elbos)
+    assert mmds[-1] < mmds[0] and mmds[-1] >= -1e-6
+    dump = np.load(str(next(tmp_path.glob("*/final_gmm_dump.npz"))))
+    assert dump["covs"].shape == (runner.gmmvi.model.num_components, 6)
