@@ -17,9 +17,9 @@ MORE_MAX_DIM = 21
 def blocked_above():
     """Dimensions above this take the blocked (MFMA) path: csrc/blocked.h gmmvi_blocked_above(), same environment knob."""
     try:
-        t = int(os.environ.get("GMMVI_BLOCKED_ABOVE", MAX_DIM))
+        t = int(os.environ.get("GMMVI_BLOCKED_ABOVE", MAX_DIM - 1))
     except ValueError:
-        t = MAX_DIM
+        t = MAX_DIM - 1
     return min(max(t, 16), MAX_DIM)
 
 

@@ -8,12 +8,13 @@
 
 #define GMMVI_BLOCKED_MAX_DIM GMMVI_MAX_DIM_BLOCKED
 
-// Dimensions above this threshold take the blocked path.  Default GMMVI_MAX_DIM (the register-resident kernels' limit);
-// GMMVI_BLOCKED_ABOVE=<16..64> lowers it (the MFMA contractions overtake the vector substitution somewhere below 64).
+// Dimensions above this threshold take the blocked path.  Default GMMVI_MAX_DIM - 1 = 63: the register-resident Stein kernel
+// needs D + 1 <= 64 lanes for the augmented matrix, so D = 64 runs blocked as a whole.  GMMVI_BLOCKED_ABOVE=<16..64> moves
+// the threshold (measured at D = 50: the two paths are on par, profiles/r01_notes.md).
 inline int gmmvi_blocked_above() {
     static const int v = [] {
         const char* s = getenv("GMMVI_BLOCKED_ABOVE");
-        const int t = s ? atoi(s) : GMMVI_MAX_DIM;
+        const int t = s ? atoi(s) : GMMVI_MAX_DIM - 1;
         return t < 16 ? 16 : (t > GMMVI_MAX_DIM ? GMMVI_MAX_DIM : t);
     }();
     return v;
