@@ -40,6 +40,8 @@ WORKLOADS = {
     # [K,N,D] fp64 temporaries make one iteration take minutes ("C5 infeasible on CPU")
     "c5": ("gauss300", 300, 64, 312),
     "c5_full": ("gauss300", 300, 512, 39),   # all of BASELINE configs[4] on ONE GPU (component chunks: Z of 512 components > scratch budget)
+    # dimension sweep at the C3 shape (crossover of the register-resident and the blocked kernels, GMMVI_BLOCKED_ABOVE)
+    "d32": ("gmm", 32, 100, 100), "d40": ("gmm", 40, 100, 100), "d63": ("gmm", 63, 100, 100),
     "tiny": ("stm", 4, 4, 16),         # host-overhead probe (kernels are empty; time = launch path)
 }
 

@@ -12,14 +12,15 @@ GAUSS, STUDENT_T = 0, 1
 SELF_NORMALIZED, OWN_SAMPLES_ONLY = 1, 2
 MAX_DIM = 64
 MORE_MAX_DIM = 21
+BLOCKED_ABOVE_DEFAULT = 50     # csrc/blocked.h: D > 50 runs the blocked (MFMA) kernels
 
 
 def blocked_above():
     """Dimensions above this take the blocked (MFMA) path: csrc/blocked.h gmmvi_blocked_above(), same environment knob."""
     try:
-        t = int(os.environ.get("GMMVI_BLOCKED_ABOVE", MAX_DIM - 1))
+        t = int(os.environ.get("GMMVI_BLOCKED_ABOVE", BLOCKED_ABOVE_DEFAULT))
     except ValueError:
-        t = MAX_DIM - 1
+        t = BLOCKED_ABOVE_DEFAULT
     return min(max(t, 16), MAX_DIM)
 
 
