@@ -58,6 +58,7 @@ void gmmvi_ctx_destroy(gmmvi_ctx* ctx) {
     }
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->zc_hash) (void)hipFree(ctx->zc_hash);
     delete ctx;
 }

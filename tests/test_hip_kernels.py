@@ -145,7 +145,7 @@ def _stein_inputs(rng, k, d, n):
 
 
 @pytest.mark.parametrize("k,d,n", [(3, 4, 64), (8, 20, 512), (5, 10, 700), (2, 2, 33), (6, 31, 300), (3, 40, 260),
-                                   (40, 20, 3000)])
+                                   (40, 20, 3000), (4, 50, 300), (3, 45, 520)])   # d > 40: blocked contractions on rebuilt L^-1 blocks
 @pytest.mark.parametrize("snis", [True, False])
 def test_stein(ctx, rng, k, d, n, snis):
     m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
@@ -163,8 +163,8 @@ def test_stein(ctx, rng, k, d, n, snis):
     assert np.all(np.abs(g.numpy() - rg) <= 3e-3 * scale_g + 1e-6)
 
 
-def test_stein_own_samples(ctx, rng):
-    k, d, n = 4, 6, 400
+@pytest.mark.parametrize("k,d,n", [(4, 6, 400), (3, 48, 600)])
+def test_stein_own_samples(ctx, rng, k, d, n):
     m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
     logw, means, chols = upload_model(ctx, m)
     packed, _ = ops().pack_components(ctx, means, chols)
