@@ -110,8 +110,13 @@ __global__ __launch_bounds__(64) void cholesky_kernel(int D, const float* __rest
 #define GMMVI_ME_THREADS 1024
 #define GMMVI_ME_MINW 1
 #endif
+// DP >= 40: at most 8 waves per workgroup, so that the compiler may use 256 VGPRs (x, z, y and the gradient accumulators are
+// 4 DP registers; under the 128-register cap of a 16-wave workgroup the DP = 50 gradient kernel spilled 196 of them to scratch)
+#ifndef GMMVI_ME_WIDE_DP
+#define GMMVI_ME_WIDE_DP 40
+#endif
 template <int DP, int FAMILY, bool GRAD, bool LDSFEED>
-__global__ __launch_bounds__(GMMVI_ME_THREADS, GMMVI_ME_MINW) void mixture_eval_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
+__global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GMMVI_ME_MINW) void mixture_eval_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
                                                             const float* __restrict__ logw, const float* __restrict__ X,
                                                             int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
                                                             float* __restrict__ grad_out, const float* __restrict__ logw2,
@@ -276,7 +281,8 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     // Measured on MI355X (tools/tune_mixture_eval.py; profiles/r01_notes.md): with few sample tiles (N = 10^4: 157) one
     // 16-wave workgroup per tile leaves 40 % of the CUs idle; 8 waves per workgroup and K split so that ~2 workgroups per CU
     // are in flight is 11-13 % faster including the (coalesced) combine launch.  Plenty of tiles: 16 waves, no split.
-    int ky = 1, nw = K < 16 ? K : 16;
+    const int nw_max = DP >= GMMVI_ME_WIDE_DP ? 8 : 16;
+    int ky = 1, nw = K < nw_max ? K : nw_max;
     if (env_ky > 0) ky = env_ky < K ? env_ky : K;
     else if (K >= 16 && 2L * tiles <= 3L * ctx->num_cus) {
         ky = (int)((2L * ctx->num_cus + tiles / 2) / tiles);
@@ -288,6 +294,7 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     ky = (K + kchunk - 1) / kchunk;
     if (nw > kchunk) nw = kchunk;
     if (env_nw > 0) nw = env_nw < kchunk ? env_nw : kchunk;
+    if (nw > nw_max) nw = nw_max;
     while (nw > 1 && lds_floats(nw) * 4 > 96 * 1024) --nw;
     size_t shmem = lds_floats(nw) * 4;
     float* lp_k = lp;
