@@ -145,7 +145,7 @@ def _stein_inputs(rng, k, d, n):
 
 
 @pytest.mark.parametrize("k,d,n", [(3, 4, 64), (8, 20, 512), (5, 10, 700), (2, 2, 33), (6, 31, 300), (3, 40, 260),
-                                   (40, 20, 3000), (4, 50, 300), (3, 45, 520)])   # d > 40: blocked contractions on rebuilt L^-1 blocks
+                                   (40, 20, 3000), (4, 50, 300), (3, 45, 520), (4, 12, 300), (3, 15, 500), (3, 16, 260), (2, 23, 300)])   # d > 40: blocked contractions on rebuilt L^-1 blocks
 @pytest.mark.parametrize("snis", [True, False])
 def test_stein(ctx, rng, k, d, n, snis):
     m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)

@@ -19,7 +19,7 @@ BUF_A, BUF_B, RD0 = 40, 56, 72          # SGPR bases: two 16-dword buffers, 1/di
 
 def gen(dp, part="both"):
     """part: 'fwd' (x -> z), 'bwd' (z -> y) or 'both'."""
-    assert dp <= 20 and dp >= 2
+    assert dp <= 24 and dp >= 2
     T = dp * (dp - 1) // 2
     MU, RD, LROW, LCOL = 0, dp, 2 * dp, 2 * dp + T
     lines = []
@@ -110,7 +110,7 @@ PK_CH = int(os.environ.get("PK_CH", "16")) if "os" in dir() else 16
 def gen_pk(dp, part="both"):
     """Two samples per lane (float2 operands, v_pk_fma_f32): every scalar of L feeds two FMAs in ONE instruction -- the only
     way to the packed fp32 rate of the vector unit.  fwd + bwd in place, same element order as gen()."""
-    assert 2 <= dp <= 20
+    assert 2 <= dp <= 24
     CH = PK_CH
     A0, B0, R0 = (40, 56, 72) if CH == 16 else ((32, 56, 80) if CH == 24 else (16, 48, 80))
     T = dp * (dp - 1) // 2
@@ -205,9 +205,9 @@ def main(out):
     w.append("#include <hip/hip_runtime.h>")
     w.append("")
     w.append("template <int DP> struct SubstAsm { static constexpr bool available = false; };")
-    for dp in (10, 20):
+    for dp in (10, 12, 16, 20, 24):
         ops = ", ".join(f'"+v"(v[{i}])' for i in range(dp))
-        clob = ", ".join(f'"s{r}"' for r in range(BUF_A, RD0 + 20))
+        clob = ", ".join(f'"s{r}"' for r in range(BUF_A, RD0 + 24))
         w.append("")
         w.append(f"template <> struct SubstAsm<{dp}> {{")
         w.append("    static constexpr bool available = true;")
@@ -227,9 +227,9 @@ def main(out):
     w.append("")
     w.append("typedef float gmmvi_f32x2 __attribute__((ext_vector_type(2)));")
     w.append("template <int DP> struct SubstAsmPk { static constexpr bool available = false; };")
-    for dp in (10, 20):
+    for dp in (10, 12, 16, 20, 24):
         ops = ", ".join(f'"+v"(v[{i}])' for i in range(dp))
-        lo_c, hi_c = (40, 92) if PK_CH == 16 else ((32, 100) if PK_CH == 24 else (16, 100))
+        lo_c, hi_c = (40, 96) if PK_CH == 16 else ((32, 100) if PK_CH == 24 else (16, 100))
         clob = ", ".join(f'"s{r}"' for r in range(lo_c, hi_c))
         w.append("")
         w.append(f"template <> struct SubstAsmPk<{dp}> {{")
