@@ -47,6 +47,10 @@ struct BG {
     int ksplit;                      // > 1: grid.z = batches * ksplit, slab z of C receives the partial sum over its k range
     const int* skip;                 // optional device flag: non-zero = the result is already in place, do nothing
     float alpha;
+    // optional: per-row sums of squares of this workgroup's result columns, rowsq[blockIdx.x * rs_tile + blockIdx.z * rs_batch +
+    // row] (one partial per column tile; the caller adds the tiles).  no_store: the result itself is not written.
+    float* rowsq; long long rs_tile, rs_batch;
+    int no_store;
 };
 
 constexpr int BM = 128, BK = 16, LDA_S = BM + 4;
@@ -280,6 +284,29 @@ __global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
     }
     // the last MFMA (16 passes) must have retired before its accumulators are read (inline asm: no automatic hazard nops)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (g.rowsq != nullptr) {
+        // lane (col, half) holds rows (r & 3) + 8 (r >> 2) + 4 half of its column in every sub-tile: square-sum over the
+        // sub-tiles, then over the 32 lanes of the half
+        float rs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (n0 + 32 * t + col < g.N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = g.alpha * acc[t][r]; rs[r] = fmaf(v, v, rs[r]); }
+            }
+        }
+        float* rq = g.rowsq + (long long)blockIdx.x * g.rs_tile + (long long)blockIdx.z * g.rs_batch + rowbase;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = rs[r];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            const int i = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (col == 0 && i < Mb) rq[i] = v;
+        }
+    }
+    if (g.no_store) return;
     float* Cb = g.C + (long long)blockIdx.z * g.sC + rowbase * g.ldc;
     const float* bias = g.c_bias ? g.c_bias + (long long)bz * g.s_cb : nullptr;
 #pragma unroll
@@ -305,6 +332,16 @@ BG bg_zero() {
     memset(&g, 0, sizeof(g));
     g.alpha = 1.f;
     return g;
+}
+
+// number of column tiles bgemm_launch will use for a result of n columns (same rule as below)
+int bgemm_col_tiles(int n) {
+    int nt = 4, best = 1 << 30;
+    for (int c = 5; c >= 3; --c) {
+        const int w = (n + 32 * c - 1) / (32 * c) * 32 * c;
+        if (w < best) { best = w; nt = c; }
+    }
+    return best / (32 * nt);
 }
 
 template <int AK, int BKM, int PRO>
@@ -577,34 +614,17 @@ __global__ __launch_bounds__(512) void blk_cholesky_kernel(int D, const float* _
 // ---------------------------------------------------------------------------------------------------------------------------
 // densities
 // ---------------------------------------------------------------------------------------------------------------------------
-// q[row] = |z_row|^2 and the component log-density; 16 lanes per row of Z
-__global__ __launch_bounds__(256) void blk_rowsq_kernel(int family, float nu, int D, int N, long long rows,
-                                                        const float* __restrict__ Z, int ldz, const float* __restrict__ packed,
-                                                        size_t ps, float* __restrict__ q, float* __restrict__ ld) {
-    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
-    const int sub = threadIdx.x & 15;
-    float s = 0.f;
-    if (row < rows) {
-        const float* z = Z + row * ldz;
-        if (((ldz | D) & 3) == 0) {
-            for (int i = sub; i < D / 4; i += 16) {
-                const float4 v = reinterpret_cast<const float4*>(z)[i];
-                s = fmaf(v.x, v.x, s); s = fmaf(v.y, v.y, s); s = fmaf(v.z, v.z, s); s = fmaf(v.w, v.w, s);
-            }
-        } else {
-            for (int i = sub; i < D; i += 16) s = fmaf(z[i], z[i], s);
-        }
-    }
-    s += gmmvi_dpp<0xB1>(s);
-    s += gmmvi_dpp<0x4E>(s);
-    s += gmmvi_dpp<0x141>(s);
-    s += gmmvi_dpp<0x140>(s);
-    if (row < rows && sub == 0) {
-        const int kb = (int)(row / N);
-        const float c = packed[(size_t)kb * ps + D];
-        if (q) q[row] = s;
-        if (ld) ld[row] = (family == GMMVI_GAUSS) ? fmaf(-0.5f, s, c) : c - 0.5f * (nu + D) * log1pf(s / nu);
-    }
+// q[row] = sum over the column tiles of the |z|^2 partials the whitening launch left, and the component log-density
+__global__ __launch_bounds__(256) void blk_qfinish_kernel(int family, float nu, int D, int N, long long rows, int tiles,
+                                                          const float* __restrict__ qpart, const float* __restrict__ packed,
+                                                          size_t ps, float* __restrict__ q, float* __restrict__ ld) {
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float s = qpart[row];
+    for (int t = 1; t < tiles; ++t) s += qpart[(long long)t * rows + row];
+    const float c = packed[(size_t)(row / N) * ps + D];
+    if (q) q[row] = s;
+    if (ld) ld[row] = (family == GMMVI_GAUSS) ? fmaf(-0.5f, s, c) : c - 0.5f * (nu + D) * log1pf(s / nu);
 }
 
 __global__ __launch_bounds__(256) void blk_lse_kernel(int K, int N, const float* __restrict__ ld, const float* __restrict__ logw,
@@ -697,8 +717,10 @@ int blk_hash_inputs(gmmvi_ctx* ctx, const float* packed, size_t n_packed, const 
 }
 
 // Z[kb][n][0:D] = (x_n - mu_k) L_k^-T for the components k0 .. k0 + kn - 1 (row stride ldz)
+// qpart != nullptr: the launch also leaves |z|^2 partials, one per column tile: qpart[tile * kn * N + kb * N + n];
+// store_z = false: Z itself is not written (a density pass that needs neither the gradient nor the Stein hand-over)
 int blk_forward(gmmvi_ctx* ctx, int D, const float* packed, int k0, int kn, const float* X, int N, float* Z, int ldz,
-                const int* skip = nullptr) {
+                const int* skip = nullptr, float* qpart = nullptr, bool store_z = true) {
     const size_t ps = gmmvi_blocked_stride(D);
     BG g = bg_zero();
     g.A = X; g.lda = D; g.sA = 0; g.a_kmajor = 0;
@@ -706,6 +728,7 @@ int blk_forward(gmmvi_ctx* ctx, int D, const float* packed, int k0, int kn, cons
     g.B = packed + (size_t)k0 * ps + gmmvi_blocked_linv_ofs(D); g.ldb = D; g.sB = (long long)ps; g.b_kmajor = 0;
     g.C = Z; g.ldc = ldz; g.sC = (long long)N * ldz;
     g.M = N; g.N = D; g.Kd = D; g.tri = 1; g.skip = skip;
+    g.rowsq = qpart; g.rs_tile = (long long)kn * N; g.rs_batch = N; g.no_store = store_z ? 0 : 1;
     // a launch that may find Z in place (skip flag) is timed under its own name: it is not a whitening pass
     GMMVI_PROF_UNITS(ctx, skip ? "blocked_forward_or_reuse" : "blocked_forward", skip ? 0.0 : (double)kn * N);
     return bgemm(ctx, g, kn);
@@ -769,22 +792,28 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         if (S < 1) S = 1;
     }
     const size_t f_gp = S > 1 ? (size_t)S * gslab : 0;
-    BLK_TRY(gmmvi_ws_reserve(ctx, (f_z + f_q + f_rw + f_ld + f_lp + f_gp) * sizeof(float)));
+    const int ctiles = bgemm_col_tiles(D);
+    const size_t f_qp = (size_t)ctiles * Kc * N;              // |z|^2 partials of the whitening launch, one per column tile
+    // Z is needed after the whitening launch only by the gradient pass and by the Stein hand-over (which requires the gradient)
+    const bool store_z = grad != nullptr;
+    BLK_TRY(gmmvi_ws_reserve(ctx, (f_z + f_q + f_rw + f_ld + f_lp + f_gp + f_qp) * sizeof(float)));
     float* Z = (float*)ctx->ws;
     float* q = Z + f_z;
     float* rw = q + f_q;
     float* ldp = ld_out ? ld_out : (f_ld ? rw + f_rw : nullptr);
     float* lpp = lp ? lp : (f_lp ? rw + f_rw + f_ld : nullptr);
     float* gpart = rw + f_rw + f_ld + f_lp;
+    float* qpart = gpart + f_gp;
+    // the row norms |z|^2 come out of the whitening launch itself (per column tile; Z is not read again)
     auto rowsq = [&](int k0, int kn, bool write_ld) {
         const long long rows = (long long)kn * N;
         GMMVI_PROF(ctx, "blocked_rowsq");
-        hipLaunchKernelGGL(blk_rowsq_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, ctx->stream, family, nu, D,
-                           N, rows, Z, LP, packed + (size_t)k0 * ps, ps, q, (write_ld && ldp) ? ldp + (size_t)k0 * N : nullptr);
+        hipLaunchKernelGGL(blk_qfinish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, family, nu, D, N,
+                           rows, ctiles, qpart, packed + (size_t)k0 * ps, ps, q, (write_ld && ldp) ? ldp + (size_t)k0 * N : nullptr);
     };
     for (int c = 0; c < nchunks; ++c) {
         const int k0 = c * Kc, kn = (K - k0 < Kc) ? K - k0 : Kc;
-        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP));
+        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP, nullptr, qpart, store_z));
         rowsq(k0, kn, true);
         GMMVI_LAUNCH_CHECK(ctx);
     }
@@ -797,7 +826,7 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         for (int c = 0; c < nchunks; ++c) {
             const int k0 = c * Kc, kn = (K - k0 < Kc) ? K - k0 : Kc;
             if (nchunks > 1) {
-                BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP));
+                BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP, nullptr, qpart, true));
                 rowsq(k0, kn, false);
                 GMMVI_LAUNCH_CHECK(ctx);
             }
