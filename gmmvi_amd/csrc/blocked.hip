@@ -402,6 +402,27 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
     for (int i = 0; i < nw; ++i) { sa += red[i]; sb += red[16 + i]; }
     a = sa; b = sb;
 }
+// Variants without the leading barrier: the caller guarantees that a barrier separates this call from the previous readers
+// of the same `red` words (the tridiagonalisation alternates between two disjoint ranges, with barriers of its own in between).
+__device__ __forceinline__ float block_sum_nb(float v, float* red) {
+    v = gmmvi_wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ void block_sum2_nb(float& a, float& b, float* red) {
+    a = gmmvi_wave_sum(a);
+    b = gmmvi_wave_sum(b);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w] = a; red[16 + w] = b; }
+    __syncthreads();
+    float sa = 0.f, sb = 0.f;
+    for (int i = 0; i < nw; ++i) { sa += red[i]; sb += red[16 + i]; }
+    a = sa; b = sb;
+}
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = gmmvi_wave_max(v);
     const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -1164,7 +1185,7 @@ __global__ __launch_bounds__(1024) void blk_tridiag_kernel(int D, int DT, int G,
     float beta = 0.f, vi = 0.f, p = 0.f;
     auto make_reflector = [&](int c, float xi, float x1, float* vdst) {
         const bool mine = g0 && i > c;
-        const float tail = block_sum((mine && i > c + 1) ? xi * xi : 0.f, red);
+        const float tail = block_sum_nb((mine && i > c + 1) ? xi * xi : 0.f, red + 32);
         float v_here = 0.f;
         if (!(tail > 0.f)) {                       // column already tridiagonal (NaN lands here too: handled by the search)
             beta = 0.f;
@@ -1209,7 +1230,7 @@ __global__ __launch_bounds__(1024) void blk_tridiag_kernel(int D, int DT, int G,
     float* v2 = vb;
     for (int c = 0; c + 2 < D; ++c) {
         float s_vp = vi * p, s_vw = vi * wti;
-        block_sum2(s_vp, s_vw, red);
+        block_sum2_nb(s_vp, s_vw, red);         // red[0..31]; the reflector norm uses red[32..47]
         const float kk = 0.5f * beta * s_vp;
         const float wdot = beta * s_vw;
         if (g0) q[i] = (i > c) ? p - kk * vi : 0.f;
@@ -1539,7 +1560,7 @@ int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* c
         const int DT = blk_threads(D);
         int G = 1024 / DT;
         if (G < 1) G = 1;
-        const size_t shmem = ((size_t)4 * D + (size_t)G * DT + 32) * sizeof(float);
+        const size_t shmem = ((size_t)4 * D + (size_t)G * DT + 48) * sizeof(float);
         hipLaunchKernelGGL(blk_tridiag_kernel, dim3(K), dim3(G * DT), shmem, ctx->stream, D, DT, G, M, wt, td, te);
         GMMVI_LAUNCH_CHECK(ctx);
     }
