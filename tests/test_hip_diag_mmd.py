@@ -61,7 +61,7 @@ def test_diag_embed_extract_roundtrip(ctx, rng):
     np.testing.assert_allclose(hip_ops.reciprocal(ctx, ctx.asarray(a)).numpy(), 1.0 / a, rtol=1e-6)
 
 
-@pytest.mark.parametrize("k,d,n", [(3, 4, 200), (8, 20, 1000), (4, 40, 300)])
+@pytest.mark.parametrize("k,d,n", [(3, 4, 200), (8, 20, 1000), (4, 40, 300), (3, 70, 400)])
 @pytest.mark.parametrize("snis", [True, False])
 def test_diag_stein(ctx, rng, k, d, n, snis):
     from gmmvi_amd.models.gmm_wrapper import GmmWrapper
