@@ -72,7 +72,7 @@ __device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<u
 // (aligned operands, a full 16-wide k step, every 16-byte piece entirely valid or entirely void -- decided once per thread)
 // issues all loads back to back without a branch; the edge route handles ragged ends element by element.
 template <int NT, int AK, int BKM, int PRO>
-__global__ __launch_bounds__(256) void bgemm_kernel(BG g) {
+__global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void bgemm_kernel(BG g) {
     constexpr int BN = 32 * NT, LDB_S = BN + 4;
     constexpr int NVB = (BN * BK / 4 + 255) / 256;          // 16-byte pieces of the B tile per thread
     __shared__ __align__(16) float As[2][BK * LDA_S];
