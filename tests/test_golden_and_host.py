@@ -149,3 +149,28 @@ def test_generated_substitution_header_is_current(tmp_path):
     subprocess.run([sys.executable, os.path.join(root, "tools", "gen_subst_asm.py"), str(out)], check=True, env=env)
     committed = open(os.path.join(root, "gmmvi_amd", "csrc", "subst_asm_gen.h")).read()
     assert out.read_text() == committed
+
+
+def test_blocked_threshold_knob(monkeypatch):
+    """gmmvi_amd._lib.blocked_above() mirrors csrc/blocked.h gmmvi_blocked_above(): default 50, clamped to 16..64."""
+    from gmmvi_amd import _lib
+    monkeypatch.delenv("GMMVI_BLOCKED_ABOVE", raising=False)
+    assert _lib.blocked_above() == _lib.BLOCKED_ABOVE_DEFAULT == 50
+    for raw, want in (("32", 32), ("5", 16), ("200", 64), ("junk", 50)):
+        monkeypatch.setenv("GMMVI_BLOCKED_ABOVE", raw)
+        assert _lib.blocked_above() == want
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gmmvi_amd", "csrc", "blocked.h")).read()
+    assert "atoi(s) : 50" in src                       # the C side carries the same default
+
+
+def test_alias_maps_diagonal_and_mmd_modules():
+    """The reference's module paths for the diagonal model, its target and the MMD metric resolve through the alias."""
+    import importlib
+    for name in ("gmmvi.models.diagonal_gmm", "gmmvi.experiments.evaluation.mmd",
+                 "gmmvi.experiments.target_distributions.diag_gmm"):
+        mod = importlib.import_module(name)
+        assert mod.__name__.startswith("gmmvi")
+    from gmmvi.models.diagonal_gmm import DiagonalGMM
+    from gmmvi.experiments.evaluation.mmd import MMD
+    assert {"compute_MMD", "set_alpha", "compute_ustat", "kernel_mix", "compute_sigma"} <= set(dir(MMD))
+    assert {"component_log_densities", "add_component", "gaussian_entropy", "covs"} <= set(dir(DiagonalGMM))
