@@ -23,6 +23,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef GMMVI_STEIN_BLOCKED_FROM_DP
+#define GMMVI_STEIN_BLOCKED_FROM_DP 50     // measured: at DP = 40 the tiled kernel still wins (1.036 vs 1.075 ms per iteration at the C3 shape)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -611,7 +615,7 @@ extern "C" int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev
     // 40 < D below the blocked threshold: the tiled kernel's scalar-fed substitution spills at DP = 50 / 64 (617 us at the C3
     // shape); the blocked contractions on L^-1 blocks rebuilt from the packed ones take ~430 us (GMMVI_STEIN_TILED=1: tiled).
     static const bool force_tiled_big = getenv("GMMVI_STEIN_TILED") != nullptr;
-    if (dp >= 50 && !force_tiled_big)
+    if (dp >= GMMVI_STEIN_BLOCKED_FROM_DP && !force_tiled_big)
         return gmmvi_blocked_stein_from_register_pack(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,
                                                       mapping_dev, map_offset, flags, H_neg_out_dev, g_neg_out_dev);
     // D <= 24: wave-per-component kernel (GMMVI_STEIN_TILED=1 selects the tiled kernel with its cross-wave merge)
