@@ -51,8 +51,9 @@ enum gmmvi_stein_flags {
 };
 
 #define GMMVI_MORE_MAX_DIM 21  /* gmmvi_more: the F x F ridge system (F = D(D+1)/2 + D + 1) is factorised in LDS */
-#define GMMVI_MAX_DIM 64       /* register-resident kernels: D <= 64 */
-#define GMMVI_MAX_DIM_BLOCKED 512   /* 64 < D <= 512: blocked kernels (dense L^-1 blocks, fp32 MFMA contractions)
+#define GMMVI_MAX_DIM 64       /* register-resident kernels exist for D <= 64; they are used for D <= 50 (environment
+                                * GMMVI_BLOCKED_ABOVE, 16..64, moves that threshold) */
+#define GMMVI_MAX_DIM_BLOCKED 512   /* above the threshold, D <= 512: blocked kernels (dense L^-1 blocks, fp32 MFMA contractions)
                                      * behind gmmvi_packed_stride / pack_components / cholesky / mixture_eval(_dual) /
                                      * sample_components / stein / update_components_kl / _direct / _iblr */
 
