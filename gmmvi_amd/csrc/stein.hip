@@ -24,7 +24,7 @@
 #include <type_traits>
 
 #ifndef GMMVI_STEIN_BLOCKED_FROM_DP
-#define GMMVI_STEIN_BLOCKED_FROM_DP 50     // measured: at DP = 40 the tiled kernel still wins (1.036 vs 1.075 ms per iteration at the C3 shape)
+#define GMMVI_STEIN_BLOCKED_FROM_DP 64     // padded dimension from which gmmvi_stein takes the blocked contractions (see below)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -57,7 +57,7 @@ __device__ __forceinline__ void backward_subst_s(const float* __restrict__ P, co
 __device__ __forceinline__ float wave_max(float v) { return gmmvi_wave_max(v); }
 
 template <int DP, int NB>
-__global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, int chunk, const float* __restrict__ packed,
+__global__ __launch_bounds__(256, 2) void stein_partial_kernel(int K, int D, int chunk, const float* __restrict__ packed,
                                                             const float* __restrict__ X, const float* __restrict__ TG,
                                                             const float* __restrict__ QG, int N,
                                                             const float* __restrict__ ld, const float* __restrict__ bg,
@@ -76,8 +76,11 @@ __global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, int ch
     const int D1 = D + 1;
     const int n0 = tile * 256;
     const int n_here = min(256, N - n0);
-    float* Gs = sm;                                   // [256][LDW]  rows [g;1;0...]
-    float* Ys = sm + 256 * LDW;                       // 4 x [64][LDW] rows e*[y;1;0...]; also staging / merge scratch
+    // One [256][LDW] LDS image, used in turn as: staging of the x tile, the [g;1] rows (read once into the A fragments), then
+    // the four waves' e*[y;1] tiles / the merge scratch (a separate G image doubled the LDS to 133 KB at W = 64: one
+    // workgroup per CU).  Together with the (256, 2) launch bound two workgroups share a CU.
+    float* Ys = sm;                                   // 4 x [64][LDW] rows e*[y;1;0...]; also staging / merge scratch
+    float* Gs = sm;                                   // [256][LDW]  rows [g;1;0...] (until the A fragments are loaded)
     float* Yw = Ys + wave * 64 * LDW;
     const bool own_only = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
 
@@ -102,7 +105,6 @@ __global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, int ch
         }
         Gs[r * LDW + c] = v;
     }
-    for (int c = D1; c < W; ++c) Yw[lane * LDW + c] = 0.f;
     __syncthreads();
     // A fragments of this wave's 64 samples: lane (col = l & 31, half = l >> 5), step s -> Gs[2s + half][col]
     const int col = lane & 31, half = lane >> 5;
@@ -111,6 +113,8 @@ __global__ __launch_bounds__(256) void stein_partial_kernel(int K, int D, int ch
     for (int a = 0; a < NB; ++a)
 #pragma unroll
         for (int s = 0; s < 32; ++s) af[a][s] = Gs[(wave * 64 + 2 * s + half) * LDW + 32 * a + col];
+    __syncthreads();                                  // the G rows are in registers: the image becomes the Y tiles
+    for (int c = D1; c < W; ++c) Yw[lane * LDW + c] = 0.f;      // padded columns stay zero (columns <= D are rewritten per component)
 
     const int k_begin = blockIdx.y * chunk;
     const int k_end = min(K, k_begin + chunk);
@@ -583,7 +587,7 @@ static int launch_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
     if (rc != GMMVI_OK) return rc;
     float* part = (float*)ctx->ws;
     float* part_m = part + part_floats;
-    const size_t shmem = (size_t)(256 + 4 * 64) * LDW * sizeof(float);
+    const size_t shmem = (size_t)256 * LDW * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && shmem > 64 * 1024) {
         GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_partial_kernel<DP, NB>,
@@ -612,8 +616,9 @@ extern "C" int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev
                                    map_offset, flags, H_neg_out_dev, g_neg_out_dev);
     const int dp = gmmvi_padded_dim(D);
     const bool two = (D + 1) > 32;
-    // 40 < D below the blocked threshold: the tiled kernel's scalar-fed substitution spills at DP = 50 / 64 (617 us at the C3
-    // shape); the blocked contractions on L^-1 blocks rebuilt from the packed ones take ~430 us (GMMVI_STEIN_TILED=1: tiled).
+    // Padded dimension 64 below the blocked threshold (only when GMMVI_BLOCKED_ABOVE was raised): the blocked contractions on
+    // L^-1 blocks rebuilt from the packed ones.  Up to 50 the tiled kernel wins since it runs two workgroups per CU (C3 shape:
+    // 407 + 32 us against 29 + 188 + 257 + 18 us); GMMVI_STEIN_TILED=1 forces the tiled kernel.
     static const bool force_tiled_big = getenv("GMMVI_STEIN_TILED") != nullptr;
     if (dp >= GMMVI_STEIN_BLOCKED_FROM_DP && !force_tiled_big)
         return gmmvi_blocked_stein_from_register_pack(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,
