@@ -11,7 +11,7 @@
 // Dimensions above this threshold take the blocked path.  Default 50: the register-resident kernels are instantiated for the
 // padded dimensions ..., 40, 50, 64, so every D in 51..63 would run the 64-wide instance, which spills (mixture_eval: 300
 // VGPRs to scratch; Stein: 1400 SGPRs to VGPR lanes) and takes 3.1 ms per iteration at K = 100, N = 10^4 against 1.86 ms on
-// the blocked kernels; at D = 50 the register path still wins (1.52 against 1.60 ms), at D = 40 / 32 clearly (profiles/
+// the blocked kernels; at D = 50 the register path wins (1.22 against 1.60 ms), at D = 40 / 32 clearly (profiles/
 // r01_notes.md).  D = 64 cannot run register-resident at all (Stein needs D + 1 <= 64 lanes).  GMMVI_BLOCKED_ABOVE=<16..64>
 // moves the threshold.
 inline int gmmvi_blocked_above() {
