@@ -62,8 +62,39 @@ def kernel_flops(name, n, k, d):
     }.get(name)
 
 
-def build(workload, n_gpus, rank, seed=0):
+def spec(workload, n_gpus, seed=0):
+    """Host-only description of a workload (no GPU needed: the CPU baseline and the tests use it too): oracle target,
+    initial mixture, config."""
     from helpers import samtron_config
+    from oracle import targets as otargets
+    kind, d, k_per_gpu, s1 = WORKLOADS[workload][:4]
+    estimator = (WORKLOADS[workload] + ("Stein",))[4]
+    k_total = k_per_gpu * n_gpus
+    s = int(np.ceil(s1 / n_gpus))
+    rng = np.random.default_rng(seed)
+    if kind == "stm":
+        ot = otargets.make_stm_target(d, rng)
+        prior_scale, initial_cov = 100.0, 300.0                    # stm20.yml:9-14
+    elif kind == "gmm":
+        ot = otargets.make_gmm_target(d, rng)
+        prior_scale, initial_cov = 31.63, 1000.0                   # gmm20.yml:7-12
+    elif kind == "gauss300":
+        ot = otargets.make_gmm_target_with_scale(d, 1, 1.0, rng)
+        prior_scale, initial_cov = 100.0, 300.0                    # stm300.yml:9-14
+    else:
+        ot = otargets.PlanarRobotTarget(d, 4)
+        prior_scale, initial_cov = [1.0] + [0.2] * (d - 1), [0.0625] + [0.0025] * (d - 1)   # planar_robot_4.yml
+    init_rng = np.random.default_rng(seed + 1)
+    means = (np.asarray(prior_scale) * init_rng.standard_normal((k_total, d))).astype(np.float32)
+    covs = np.broadcast_to((np.asarray(initial_cov) * np.eye(d)).astype(np.float32), (k_total, d, d))
+    cfg = samtron_config(s, initial_stepsize=0.1, estimator=estimator)
+    cfg["model_initialization"].update(prior_mean=0.0, initial_cov=initial_cov)
+    return dict(kind=kind, d=d, k_total=k_total, s=s, n_total=k_total * s, cfg=cfg, oracle_target=ot,
+                means=means, covs=np.ascontiguousarray(covs), seed=seed + 2)
+
+
+def build(workload, n_gpus, rank, seed=0):
+    """spec() plus the device-side target and the classes of the product (needs the GPU)."""
     import gmmvi_amd  # noqa: F401
     from gmmvi_amd.models.full_cov_gmm import FullCovGMM
     from gmmvi_amd.models.gmm_wrapper import GmmWrapper
@@ -71,36 +102,16 @@ def build(workload, n_gpus, rank, seed=0):
     from gmmvi_amd.experiments.target_distributions.gmm import GMM_LNPDF
     from gmmvi_amd.experiments.target_distributions.student_t_mixture import StudentTMixture_LNPDF
     from gmmvi_amd.experiments.target_distributions.planar_robot import PlanarRobot
-    kind, d, k_per_gpu, s1 = WORKLOADS[workload][:4]
-    estimator = (WORKLOADS[workload] + ("Stein",))[4]
-    k_total = k_per_gpu * n_gpus
-    s = int(np.ceil(s1 / n_gpus))
-    rng = np.random.default_rng(seed)
-    from oracle import targets as otargets
-    if kind == "stm":
-        ot = otargets.make_stm_target(d, rng)
+    w = spec(workload, n_gpus, seed)
+    ot = w["oracle_target"]
+    if w["kind"] == "stm":
         tgt = StudentTMixture_LNPDF(ot.weights, ot.means, ot.covs, alpha=2)
-        prior_scale, initial_cov = 100.0, 300.0                    # stm20.yml:9-14
-    elif kind == "gmm":
-        ot = otargets.make_gmm_target(d, rng)
+    elif w["kind"] in ("gmm", "gauss300"):
         tgt = GMM_LNPDF(ot.weights, ot.means, ot.covs)
-        prior_scale, initial_cov = 31.63, 1000.0                   # gmm20.yml:7-12
-    elif kind == "gauss300":
-        ot = otargets.make_gmm_target_with_scale(d, 1, 1.0, rng)
-        tgt = GMM_LNPDF(ot.weights, ot.means, ot.covs)
-        prior_scale, initial_cov = 100.0, 300.0                    # stm300.yml:9-14
     else:
-        ot = otargets.PlanarRobotTarget(d, 4)
-        tgt = PlanarRobot(d, 4)
-        prior_scale, initial_cov = [1.0] + [0.2] * (d - 1), [0.0625] + [0.0025] * (d - 1)   # planar_robot_4.yml
-    init_rng = np.random.default_rng(seed + 1)
-    means = (np.asarray(prior_scale) * init_rng.standard_normal((k_total, d))).astype(np.float32)
-    covs = np.broadcast_to((np.asarray(initial_cov) * np.eye(d)).astype(np.float32), (k_total, d, d))
-    cfg = samtron_config(s, initial_stepsize=0.1, estimator=estimator)
-    cfg["model_initialization"].update(prior_mean=0.0, initial_cov=initial_cov)
-    return dict(kind=kind, d=d, k_total=k_total, s=s, n_total=k_total * s, cfg=cfg, target=tgt, oracle_target=ot,
-                means=means, covs=np.ascontiguousarray(covs), seed=seed + 2, FullCovGMM=FullCovGMM,
-                GmmWrapper=GmmWrapper, GMMVI=GMMVI)
+        tgt = PlanarRobot(w["d"], 4)
+    w.update(target=tgt, FullCovGMM=FullCovGMM, GmmWrapper=GmmWrapper, GMMVI=GMMVI)
+    return w
 
 
 def make_gmmvi(w, n_gpus, rank):
@@ -113,14 +124,86 @@ def make_gmmvi(w, n_gpus, rank):
     return ShardedGMMVI.build(w, n_gpus, rank)
 
 
-def make_oracle(w):
+def make_oracle(w, dtype=np.float64):
+    """The CPU restatement on the workload; ``dtype=np.float32`` runs it in the reference's own arithmetic."""
     from oracle import train as otrain, gmm as ogmm
     cfg = w["cfg"]
-    model = ogmm.FullCovGMM(np.ones(w["k_total"]) / w["k_total"], w["means"], w["covs"])
+    model = ogmm.FullCovGMM(np.ones(w["k_total"]) / w["k_total"], w["means"], w["covs"], dtype=dtype)
     return otrain.OracleGMMVI(w["oracle_target"], model, seed=w["seed"], ng_estimator=cfg["ng_estimator_type"],
                               desired_samples_per_component=w["s"], ratio_reused_samples_to_desired=0.0,
                               component_stepsize_config=cfg["component_stepsize_adapter_config"],
                               weight_stepsize_config=cfg["weight_stepsize_adapter_config"])
+
+
+def time_cpu_baseline(w, seconds, warmup=3, max_iters=20, min_iters=3):
+    """BASELINE.md section 3 / SURVEY.md 8(d): the CPU restatement in fp32 (the reference computes in fp32) on this host's
+    cores, ``warmup`` untimed iterations, then timed iterations until ``max_iters`` or the time budget (at least
+    ``min_iters``); median iteration time.  -> (median seconds, timed iterations, BLAS threads)."""
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count()
+    o = make_oracle(w, dtype=np.float32)
+    t_begin = time.perf_counter()
+    for _ in range(warmup):
+        o.train_iter()
+    ts = []
+    while len(ts) < max_iters and (len(ts) < min_iters or time.perf_counter() - t_begin < seconds):
+        t1 = time.perf_counter()
+        o.train_iter()
+        ts.append(time.perf_counter() - t1)
+    return float(np.median(ts)), len(ts), int(threads)
+
+
+# ---- self-launch: `python bench.py --gpus N` without a launcher starts its own ranks --------------------------------------
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n_ranks, argv, child=None, timeout=None):
+    """Start ``n_ranks`` fresh processes of this script (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT in their environment, as torch.distributed.run would set them), wait for all, relay rank 0's stdout.
+    The calling process has not touched the GPU and never does (children are new processes, nothing is re-exec'ed).
+    -> exit code: 0 when every rank exited 0, else the first non-zero one (the others are terminated)."""
+    import subprocess
+    cmd = [sys.executable, child or os.path.abspath(__file__)] + list(argv)
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    t_end = None if timeout is None else time.time() + timeout
+    out0 = b""
+    try:
+        # rank 0's pipe is drained first (one JSON line: no deadlock); then every rank is waited for
+        out0 = procs[0].communicate(timeout=None if t_end is None else max(1.0, t_end - time.time()))[0]
+        for p in procs:
+            code = p.wait(timeout=None if t_end is None else max(1.0, t_end - time.time()))
+            if code != 0 and rc == 0:
+                rc = code
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    if rc == 0:
+        sys.stdout.write(out0.decode())
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(f"bench.py: a rank failed (exit code {rc}); rank 0 printed: {out0.decode()!r}\n")
+    return rc
 
 
 def parse_profile(ctx):
@@ -141,16 +224,16 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=40.0)
     args = ap.parse_args()
+    n_gpus = args.gpus
+    if "WORLD_SIZE" not in os.environ and n_gpus > 1:
+        # no launcher: start the ranks ourselves, BEFORE anything here touches the GPU
+        raise SystemExit(spawn_ranks(n_gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n_gpus = args.gpus
-    if world != n_gpus and not (world == 1 and n_gpus == 1):
-        if world == 1:
-            raise SystemExit(f"--gpus {n_gpus} needs {n_gpus} ranks: launch with python -m torch.distributed.run "
-                             f"--nproc-per-node {n_gpus} bench.py --gpus {n_gpus} ...")
-        n_gpus = world
+    if world != n_gpus:
+        n_gpus = world                                   # under a launcher its world size wins
 
     from gmmvi_amd.device import get_context
     ctx = get_context()
@@ -170,6 +253,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         algo.train_iter()
+    if hasattr(algo, "flush"):
+        algo.flush()                 # sharded path: the last weight step rides with the next exchange; close it in the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if exchange is not None:
@@ -235,25 +320,19 @@ def main():
                                        "arrays (3 GB each) and takes minutes; parity at D = 300 is covered by "
                                        "tests/test_hip_blocked.py on smaller K, N")
     elif rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        try:
-            from threadpoolctl import threadpool_info
-            threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-        except Exception:
-            threads = os.cpu_count()
+        t_cpu, cpu_iters, threads = time_cpu_baseline(w, args.cpu_seconds)
+        result["cpu_baseline"] = {"value": n_tot * k_tot / t_cpu, "unit": "samples*components/s",
+                                  "train_iter_per_sec": 1.0 / t_cpu, "cores": threads, "kind": "port", "dtype": "f32",
+                                  "sample": f"3 warm-up + {cpu_iters} timed train_iter() of the same workload (fp32 "
+                                            f"NumPy/SciPy restatement of the reference's algorithm, the reference's own "
+                                            f"arithmetic), median iteration time"}
+        # matched ELBO: fp64 oracle and a fresh device run, the same number of iterations from the same seed, both models
+        # scored by the fp64 oracle on the same 20 000 Philox draws
+        elbo_iters = 6
         o = make_oracle(w)
-        t_start = time.perf_counter()
-        o.train_iter()
-        first = time.perf_counter() - t_start
-        n_more = int(max(1, min(8, (args.cpu_seconds - first) // max(first, 1e-3))))
-        ts = [first]
-        for _ in range(n_more):
-            t1 = time.perf_counter(); o.train_iter(); ts.append(time.perf_counter() - t1)
-        cpu_iters = len(ts)
-        t_cpu = float(np.median(ts))
-        # matched ELBO: a fresh device run of the same number of iterations from the same seed, both models scored
-        # by the oracle on the same 20 000 Philox draws
         g = make_gmmvi(build(args.workload, 1, 0), 1, 0)
-        for _ in range(cpu_iters):
+        for _ in range(elbo_iters):
+            o.train_iter()
             g.train_iter()
         elbo_cpu = o.elbo(20000, seed=12345)[0]
         om = o.model.model
@@ -261,11 +340,7 @@ def main():
         om.chol_cov = g.model.chol_cov.numpy().astype(np.float64)
         om.log_weights = g.model.log_weights.numpy().astype(np.float64)
         elbo_gpu = o.elbo(20000, seed=12345)[0]
-        result["cpu_baseline"] = {"value": n_tot * k_tot / t_cpu, "unit": "samples*components/s",
-                                  "train_iter_per_sec": 1.0 / t_cpu, "cores": int(threads), "kind": "port",
-                                  "sample": f"{cpu_iters} train_iter() of the same workload (fp64 NumPy/SciPy oracle "
-                                            f"restating the reference's algorithm), median iteration time"}
-        result["matched_elbo"] = {"iters": cpu_iters, "gpu_fp32": elbo_gpu, "cpu_fp64": elbo_cpu,
+        result["matched_elbo"] = {"iters": elbo_iters, "gpu_fp32": elbo_gpu, "cpu_fp64": elbo_cpu,
                                   "abs_diff": abs(elbo_gpu - elbo_cpu)}
     if rank == 0:
         print(json.dumps(result))

@@ -967,7 +967,9 @@ __global__ __launch_bounds__(256) void blk_stein_finalize_kernel(int D, int N, i
     const float* A = Araw + (size_t)kb * D1 * D1;
     const float* Tk = T + (size_t)kb * D * D;
     const bool snis = (flags & GMMVI_SELF_NORMALIZED) != 0;
-    const float scale = snis ? 1.f / A[(size_t)D * D1 + D] : __expf(Mk[kb]) / (float)N;
+    // own samples only: the divisor is the number of own samples = sum e (weights exp(0), ng_estimator.py:110-118,146-152)
+    const bool own = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
+    const float scale = (snis || own) ? 1.f / A[(size_t)D * D1 + D] : __expf(Mk[kb]) / (float)N;
     for (int e = threadIdx.x; e < D * D; e += 256) {
         const int i = e / D, j = e % D;
         const float v = snis ? 0.5f * (Tk[e] + Tk[(size_t)j * D + i]) : Tk[e];

@@ -251,7 +251,10 @@ __global__ __launch_bounds__(1024) void stein_finalize_kernel(int D, int R, int 
     const bool snis = (flags & GMMVI_SELF_NORMALIZED) != 0;
     // A[i][j] = sum e g_i y_j, A[i][D] = sum e g_i, A[D][D] = sum e.
     // plain importance weights: 1/N * sum exp(ld - bg) v   (ng_estimator.py:146-152), Hessian not symmetrised
-    const float scale = snis ? 1.f / A[D * D1 + D] : __expf(M) / (float)N;
+    // with only_use_own_samples the expectation runs over the component's own samples only (get_rewards_for_comp,
+    // ng_estimator.py:110-118: weights exp(0) = 1, divisor = their number): sum e = n_own exp(-M) => exp(M) / n_own = 1 / sum e
+    const bool own = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
+    const float scale = (snis || own) ? 1.f / A[D * D1 + D] : __expf(M) / (float)N;
     for (int e = threadIdx.x; e < D * D; e += blockDim.x) {
         const int i = e / D, j = e % D;
         const float v = snis ? 0.5f * (A[i * D1 + j] + A[j * D1 + i]) : A[i * D1 + j];

@@ -92,8 +92,14 @@ class GMMVI:
         # update components
         new_component_stepsizes = self.component_stepsize_adapter.update_stepsize(self.model.stepsizes)
         self.model.update_stepsizes(new_component_stepsizes)
-        # hint for only_use_own_samples: the newest sample was drawn by the newest DB component
-        self.model._mapping_max_hint = self.sample_db.means.shape[0] - 1
+        # only_use_own_samples needs max(mapping) (ng_estimator.py:244): read it off the DB's host mirror of the mapping
+        # (a mixture-based selector may leave the newest DB component without a draw, so "number of DB components - 1"
+        # is not it)
+        self.model._mapping_max_hint = None
+        if getattr(self.ng_estimator, "_only_use_own_samples", False) and hasattr(self.sample_db, "newest_mapping_host"):
+            host_mapping = self.sample_db.newest_mapping_host(samples.shape[0])
+            if host_mapping.size:
+                self.model._mapping_max_hint = int(host_mapping.max())
         expected_hessian_neg, expected_grad_neg = self.ng_estimator.get_expected_hessian_and_grad(
             samples, mapping, sample_dist_densities, target_lnpdfs, target_lnpdf_grads)
         self.ng_based_updater.apply_NG_update(expected_hessian_neg, expected_grad_neg, self.model.stepsizes)

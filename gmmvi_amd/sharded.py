@@ -7,9 +7,13 @@ three exchange steps, each an RCCL all-gather over xGMI followed by a local comb
   E1  samples, target log-densities and target gradients of the locally drawn samples      [N/R, 2D+1] per rank
   E2  per-sample partial mixtures over the local components: background (max,sum) folded into one log value,
       model log q partial and its responsibility-weighted gradient partial                  [N, D+2]   per rank
-  E3a post-update log q partial [N];  E3b per-component expected log-ratios / rewards      [N], [2 Kl] per rank
+  E3  post-update log q partial                                                              [N]        per rank
 Each step is ONE all-gather: the arrays of a step travel back to back in one buffer (xGMI collectives at these sizes are
 latency-bound, ~tens of microseconds each whatever the payload) and one de-interleave launch restores them.
+The per-component expected log-ratios and rewards of the weight step ([2 Kl] per rank) need no collective of their own:
+nothing reads the new weights or the new reward column before the NEXT iteration's density sweep and stepsize rule, so
+they ride in the next iteration's E1 buffer and the replicated weight step is applied right after that gather
+(``flush()`` sends a pending pair on its own -- call it on every rank before reading ``log_weights``).
 
 Stein estimate and the KL-constrained component update are local to the owner.  The mixture weights [K], the
 reward history and the weight trust-region step are replicated (every rank computes the identical [K]-sized update
@@ -203,7 +207,8 @@ class ShardedGMMVI:
         self.ws = cfg["weight_stepsize_adapter_config"]
         o = ops
         self.means, self.chols = o.asarray(means_loc), o.asarray(chols_loc)
-        self.log_weights = o.asarray(np.full(k_total, -np.log(k_total), np.float32))      # replicated
+        self._logw = o.asarray(np.full(k_total, -np.log(k_total), np.float32))            # replicated
+        self._pending = None           # (expected log-ratios, rewards) of the local components, weight step not applied yet
         self.stepsizes = o.full((self.Kl,), float(self.cs["initial_stepsize"]))
         self.last_eta = o.full((self.Kl,), -1.0)
         self.l2 = o.full((self.Kl,), 1e-12)
@@ -224,24 +229,62 @@ class ShardedGMMVI:
         s = (self.t_reward - 1 - back) % self.H
         return self.ops.rows(self.reward_ring, s, s + 1)
 
+    @property
+    def log_weights(self):
+        """Replicated mixture log-weights [K].  The weight step of the last iteration travels with the next exchange:
+        ``flush()`` (a collective: every rank must call it) applies it."""
+        if self._pending is not None:
+            raise RuntimeError("ShardedGMMVI.log_weights: the last weight step is still pending; call flush() on "
+                               "every rank first")
+        return self._logw
+
+    def _apply_weight_step(self, e, reward):
+        """Replicated on every rank from the gathered [K] expected log-ratios / rewards (weight_updater.py:56-100,
+        gmm_wrapper.py:150-160): new reward column, then the weight trust-region step."""
+        o = self.ops
+        s = self.t_reward % self.H
+        o.copy_into(self._row1d(o.rows(self.reward_ring, s, s + 1)), reward)
+        self.t_reward += 1
+        o.update_weights(self._logw, e, o.rows(self.wstate, 0, 1), self.temperature)
+        self._pending = None
+
+    def flush(self):
+        """Apply a pending weight step (one small all-gather of [2 Kl] floats per rank).  Collective."""
+        if self._pending is None:
+            return
+        o, ex = self.ops, self.exchange
+        e_loc, reward_loc = self._pending
+        if self.R > 1:
+            e, reward = o.unpack(ex.allgather(o.concat([e_loc, reward_loc])), self.R, [self.Kl, self.Kl])
+        else:
+            e, reward = e_loc, reward_loc
+        self._apply_weight_step(e, reward)
+
     def train_iter(self):
         o, ex, d, R, N, Nl = self.ops, self.exchange, self.d, self.R, self.N, self.Nl
-        # ---- sampling + target (local components); exchange E1: [x | log p~ | grad log p~] in ONE all-gather ---------------
+        # ---- sampling + target (local components); exchange E1: [x | log p~ | grad log p~ (| pending E, reward)] in ONE
+        # all-gather; neither sampling nor the target reads the mixture weights, so the previous weight step may still be open
         first = self.num_samples_written + self.rank * self.Nl
         x_loc = o.sample(self.means, self.chols, self.counts_loc, self.seed, first)
         tlp_loc, tgrad_loc = o.target_eval(x_loc)
+        parts, sizes = [x_loc, tlp_loc, tgrad_loc], [Nl * d, Nl, Nl * d]
+        if self._pending is not None:
+            parts += list(self._pending)
+            sizes += [self.Kl, self.Kl]
         if R > 1:
-            g1 = ex.allgather(o.concat([x_loc, tlp_loc, tgrad_loc]))
-            x, tlp, tgrad = o.unpack(g1, R, [Nl * d, Nl, Nl * d])
-            x, tgrad = x.reshape((N, d)), tgrad.reshape((N, d))
+            outs = o.unpack(ex.allgather(o.concat(parts)), R, sizes)
+            x, tlp, tgrad = outs[0].reshape((N, d)), outs[1], outs[2].reshape((N, d))
         else:
+            outs = parts
             x, tlp, tgrad = x_loc, tlp_loc, tgrad_loc
+        if self._pending is not None:
+            self._apply_weight_step(outs[3], outs[4])
         self.num_samples_written += N
         # ---- partial background / model densities over the local components (one sweep); exchange E2 ------------------------
         if self.packed is None:
             self.packed = o.pack(self.means, self.chols)
         packed = self.packed
-        logw_loc = o.rows(self.log_weights, self.lo, self.hi)
+        logw_loc = o.rows(self._logw, self.lo, self.hi)
         ld, lq_part, qg_part, bg_part = o.mixture_dual(packed, logw_loc, self.logc_loc, x, d)
         if R > 1:
             g2 = ex.allgather(o.concat([bg_part, lq_part, qg_part]))
@@ -258,19 +301,11 @@ class ShardedGMMVI:
         self.last_success, self.packed = o.update_kl(self.means, self.chols, h_neg, g_neg, self.stepsizes,
                                                      self.temperature, 1e-12, self.last_eta, self.l2,
                                                      self.num_received_updates)
-        # ---- weight update: post-update density (E3a), expected log-ratios + rewards (E3b) ------------------------------------
-        o.weight_stepsize(self.log_weights, self._row1d(self._slot(0)), self.wstate, self.ws)
+        # ---- weight update: post-update density (E3); the expected log-ratios + rewards wait for the next E1 -------------------
+        o.weight_stepsize(self._logw, self._row1d(self._slot(0)), self.wstate, self.ws)
         ld2, lq2_part, _ = o.mixture(self.packed, logw_loc, x, d, want_ld=True)
         logq2 = o.combine(self._stack(ex.allgather(lq2_part), N), None, d)[0] if R > 1 else lq2_part
-        e_loc, reward_loc = o.elr(ld2, bg, tlp, logq2, self.temperature, logw_loc)
-        if R > 1:
-            e, reward = o.unpack(ex.allgather(o.concat([e_loc, reward_loc])), R, [self.Kl, self.Kl])
-        else:
-            e, reward = e_loc, reward_loc
-        s = self.t_reward % self.H
-        o.copy_into(self._row1d(o.rows(self.reward_ring, s, s + 1)), reward)
-        self.t_reward += 1
-        o.update_weights(self.log_weights, e, o.rows(self.wstate, 0, 1), self.temperature)
+        self._pending = o.elr(ld2, bg, tlp, logq2, self.temperature, logw_loc)
         self.num_updates += 1
 
     @staticmethod
@@ -302,4 +337,5 @@ class ShardedGMMVI:
     def gather_model(self):
         """(log_weights [K], means [K,D], chols [K,D,D]) on the host, gathered from all ranks."""
         o, ex = self.ops, self.exchange
-        return (o.to_host(self.log_weights), o.to_host(ex.allgather(self.means)), o.to_host(ex.allgather(self.chols)))
+        self.flush()
+        return (o.to_host(self._logw), o.to_host(ex.allgather(self.means)), o.to_host(ex.allgather(self.chols)))

@@ -5,15 +5,16 @@ from oracle import targets as otargets, train as otrain
 
 
 def samtron_config(desired_samples, reuse_ratio=0.0, initial_stepsize=0.1, adaptive=None, updater="trust-region",
-                   weight_updater="trust-region", snis=True, own=False, wstep=1.0, estimator="Stein", diag=False):
+                   weight_updater="trust-region", snis=True, own=False, wstep=1.0, estimator="Stein", diag=False,
+                   selector="component-based", max_database_size=10000000):
     """SAMTRON-style config dict with the keys of the reference's example_config.yml."""
     cfg = {
-        "temperature": 1.0, "use_sample_database": True, "max_database_size": 10000000, "seed": 0,
+        "temperature": 1.0, "use_sample_database": True, "max_database_size": max_database_size, "seed": 0,
         "model_initialization": {"use_diagonal_covs": bool(diag), "prior_mean": 0., "initial_cov": 1.0},
         "ng_estimator_type": estimator,
         "ng_estimator_config": dict({"only_use_own_samples": own, "use_self_normalized_importance_weights": snis},
                                     **({"initial_l2_regularizer": 1e-12} if estimator == "MORE" else {})),
-        "sample_selector_type": "component-based",
+        "sample_selector_type": selector,
         "sample_selector_config": {"desired_samples_per_component": desired_samples,
                                    "ratio_reused_samples_to_desired": reuse_ratio},
         "ng_based_updater_type": updater, "ng_based_updater_config": {},
@@ -85,7 +86,8 @@ def make_oracle(kind, d, k, s, seed, cfg, dtype=np.float64):
         weight_stepsize_config=cfg["weight_stepsize_adapter_config"],
         adaptive=(dict(cfg["num_component_adapter_config"], prior_mean=0.0, initial_cov=ic)
                   if cfg["num_component_adapter_type"] == "adaptive" else None),
-        max_reward_history_length=400,
+        max_reward_history_length=400, sample_selector=cfg["sample_selector_type"],
+        max_database_size=cfg["max_database_size"],
         host_rng=np.random.default_rng(seed))
     return algo
 

@@ -174,3 +174,56 @@ def test_alias_maps_diagonal_and_mmd_modules():
     from gmmvi.experiments.evaluation.mmd import MMD
     assert {"compute_MMD", "set_alpha", "compute_ustat", "kernel_mix", "compute_sigma"} <= set(dir(MMD))
     assert {"component_log_densities", "add_component", "gaussian_entropy", "covs"} <= set(dir(DiagonalGMM))
+
+
+# ---------------------------------------------------------------------------------------------- bench.py self-launch
+def _bench_module():
+    import importlib
+    sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+def test_bench_spawns_its_own_ranks(tmp_path, capsys):
+    """`python bench.py --gpus N` without a launcher starts N fresh rank processes with the launcher's environment
+    variables, relays rank 0's JSON line and fails when any rank fails.  Stub child: no GPU involved."""
+    bench = _bench_module()
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import json, os, sys\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "assert int(os.environ['MASTER_PORT']) > 0 and os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'\n"
+        "open(os.path.join(sys.argv[1], f'rank{r}'), 'w').write(' '.join(sys.argv[2:]))\n"
+        "if '--fail' in sys.argv and r == w - 1:\n"
+        "    sys.exit(7)\n"
+        "print(json.dumps({'rank': r, 'world': w}))\n")
+    rc = bench.spawn_ranks(3, [str(tmp_path), "--gpus", "3", "--steps", "5"], child=str(child), timeout=60)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 0 and out == ['{"rank": 0, "world": 3}']                  # only rank 0's line reaches stdout
+    for r in range(3):
+        assert (tmp_path / f"rank{r}").read_text() == "--gpus 3 --steps 5"
+    rc = bench.spawn_ranks(2, [str(tmp_path), "--fail"], child=str(child), timeout=60)
+    assert rc == 7 and capsys.readouterr().out == ""
+
+
+def test_bench_main_delegates_before_touching_the_gpu(monkeypatch):
+    """With --gpus N > 1 and no WORLD_SIZE, main() must hand over to spawn_ranks before any device call."""
+    bench = _bench_module()
+    seen = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.setattr(bench, "spawn_ranks", lambda n, argv, **kw: seen.update(n=n, argv=list(argv)) or 0)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and seen == {"n": 4, "argv": ["--gpus", "4", "--steps", "3"]}
+
+
+def test_bench_workload_spec_is_host_only():
+    bench = _bench_module()
+    w = bench.spec("ns", 1)
+    assert (w["k_total"], w["d"], w["n_total"]) == (100, 20, 10000)
+    w8 = bench.spec("ns", 8)
+    assert (w8["k_total"], w8["s"]) == (800, 13)
+    o = bench.make_oracle(bench.spec("tiny", 1), dtype=np.float32)
+    o.train_iter()
+    assert o.model.means.dtype == np.float32

@@ -135,7 +135,8 @@ def test_blocked_stein(ctx, rng, k, d, n, snis):
     assert np.all(np.abs(g.numpy() - rg) <= 1e-2 * scale_g + 1e-6)
 
 
-def test_blocked_stein_own_samples(ctx, rng):
+@pytest.mark.parametrize("snis", [True, False])
+def test_blocked_stein_own_samples(ctx, rng, snis):
     k, d, n = 3, 70, 500
     m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
     logw, means, chols = upload_model(ctx, m)
@@ -144,10 +145,33 @@ def test_blocked_stein_own_samples(ctx, rng):
     ld, lp, qg = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_grad=True)
     mp = mapping + 7
     h, g = ops().stein(ctx, packed, xd, ld, qg, ctx.asarray(bg), ctx.asarray(tg), d,
-                       mapping=ctx.asarray(mp, np.int32), map_offset=k - 1 - int(mp.max()), own_samples_only=True)
-    rh, rg = ostein.get_expected_hessian_and_grad(m, x, mp, bg, tlp, tg, True, True)
+                       mapping=ctx.asarray(mp, np.int32), map_offset=k - 1 - int(mp.max()), own_samples_only=True,
+                       self_normalized=snis)
+    rh, rg = ostein.get_expected_hessian_and_grad(m, x, mp, bg, tlp, tg, True, snis)
     np.testing.assert_allclose(h.numpy(), rh, rtol=2e-3, atol=2e-3 * np.abs(rh).max())
     np.testing.assert_allclose(g.numpy(), rg, rtol=2e-3, atol=2e-3 * np.abs(rg).max())
+
+
+def test_blocked_stein_after_workspace_grow(rng):
+    """A fresh context (empty workspace): at D = 300, N = 600 the Stein scratch is about twice the density sweep's, beyond
+    the 1.5x slack of gmmvi_ws_reserve, so the workspace is re-allocated between the sweep that left Z behind and the
+    Stein call.  hipMalloc may return the old address: the hand-over of Z must be dropped with the old block
+    (api.hip gmmvi_ws_reserve), otherwise the contraction would read uninitialised memory."""
+    from gmmvi_amd.device import Context
+    fresh = Context()
+    k, d, n = 2, 300, 600
+    m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
+    logw, means, chols = upload_model(fresh, m)
+    packed, _ = ops().pack_components(fresh, means, chols)
+    xd = fresh.asarray(x)
+    for _ in range(2):          # second round: the workspace is large enough, the hand-over is taken
+        ld, lp, qg = ops().mixture_eval(fresh, packed, logw, xd, d, want_ld=True, want_grad=True)
+        h, g = ops().stein(fresh, packed, xd, ld, qg, fresh.asarray(bg), fresh.asarray(tg), d)
+        rh, rg = ostein.get_expected_hessian_and_grad(m, x, mapping, bg, tlp, tg, False, True)
+        scale_h = np.abs(rh).max(axis=(1, 2), keepdims=True)
+        scale_g = np.abs(rg).max(axis=1, keepdims=True)
+        assert np.all(np.abs(h.numpy() - rh) <= 1e-2 * scale_h + 1e-6)
+        assert np.all(np.abs(g.numpy() - rg) <= 1e-2 * scale_g + 1e-6)
 
 
 @pytest.mark.parametrize("k,d", [(3, 72), (2, 300), (3, 129)])

@@ -23,6 +23,8 @@ def _pair(kind, d, k, s, seed, cfg):
     ("gmm", 20, 8, 64, samtron_config(64, weight_updater="direct", wstep=0.05)),
     ("gmm", 3, 1, 40, samtron_config(40)),
     ("stm", 6, 5, 30, samtron_config(30, snis=False, initial_stepsize=0.01)),
+    ("gmm", 32, 4, 80, samtron_config(80)),            # tiled Stein kernel + wide mixture_eval (what bench.py c3 composes)
+    ("gmm", 50, 5, 100, samtron_config(100)),
 ])
 def test_fast_path_equals_modular_path(kind, d, k, s, cfg):
     o, fast, slow = _pair(kind, d, k, s, 23, cfg)

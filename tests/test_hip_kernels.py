@@ -164,7 +164,8 @@ def test_stein(ctx, rng, k, d, n, snis):
 
 
 @pytest.mark.parametrize("k,d,n", [(4, 6, 400), (3, 48, 600)])
-def test_stein_own_samples(ctx, rng, k, d, n):
+@pytest.mark.parametrize("snis", [True, False])
+def test_stein_own_samples(ctx, rng, k, d, n, snis):
     m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
     logw, means, chols = upload_model(ctx, m)
     packed, _ = ops().pack_components(ctx, means, chols)
@@ -172,8 +173,11 @@ def test_stein_own_samples(ctx, rng, k, d, n):
     ld, lp, qg = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_grad=True)
     mp = mapping + 7                                  # DB indices: offset so that max(mapping) -> K-1
     h, g = ops().stein(ctx, packed, xd, ld, qg, ctx.asarray(bg), ctx.asarray(tg), d,
-                       mapping=ctx.asarray(mp, np.int32), map_offset=k - 1 - int(mp.max()), own_samples_only=True)
-    rh, rg = ostein.get_expected_hessian_and_grad(m, x, mp, bg, tlp, tg, True, True)
+                       mapping=ctx.asarray(mp, np.int32), map_offset=k - 1 - int(mp.max()), own_samples_only=True,
+                       self_normalized=snis)
+    # plain importance weights over the own samples: weights exp(0), divisor = number of own samples
+    # (ng_estimator.py:110-118,146-152), Hessian not symmetrised
+    rh, rg = ostein.get_expected_hessian_and_grad(m, x, mp, bg, tlp, tg, True, snis)
     np.testing.assert_allclose(h.numpy(), rh, rtol=2e-3, atol=2e-3 * np.abs(rh).max())
     np.testing.assert_allclose(g.numpy(), rg, rtol=2e-3, atol=2e-3 * np.abs(rg).max())
 

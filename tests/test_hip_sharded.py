@@ -22,6 +22,7 @@ def test_single_rank_sharded_equals_modular_gmmvi():
     for _ in range(6):
         g.train_iter()
         sh.train_iter()
+    sh.flush()
     # not bitwise: the modular path takes the parameter blocks emitted by the update kernel, the sharded path re-packs
     # them (log-normaliser summed in a different order); 6 iterations amplify the 1e-7 difference to ~1e-5
     np.testing.assert_allclose(sh.means.numpy(), g.model.means.numpy(), rtol=2e-4, atol=2e-4)
@@ -100,6 +101,7 @@ def test_two_virtual_ranks_match_single_rank(kind, d, k, s, iters):
     ref = ShardedGMMVI(HipOps(get_context(), target), LocalExchange(), d, k, means0, chols0, s, seed, cfg)
     for _ in range(iters):
         ref.train_iter()
+    ref.flush()
 
     world, slots, barrier, turn = 2, [None, None], threading.Barrier(2), threading.Lock()
     results, errors = [None, None], []
@@ -113,6 +115,7 @@ def test_two_virtual_ranks_match_single_rank(kind, d, k, s, iters):
                               means0[rank * kl:(rank + 1) * kl], chols0[rank * kl:(rank + 1) * kl], s, seed, cfg)
             for _ in range(iters):
                 sh.train_iter()
+            sh.flush()
             results[rank] = (sh.log_weights.numpy(), sh.means.numpy(), sh.chols.numpy())
         except Exception as e:                                      # pragma: no cover - surfaced below
             errors.append(e)
