@@ -52,7 +52,9 @@ def kernel_flops(name, n, k, d):
     return {
         "mixture_eval": p * (d * d + 4 * d),              # forward substitution + square-sum + LSE
         "mixture_eval_grad": p * (2 * d * d + 8 * d),     # + backward substitution + responsibility-weighted gradient
-        "stein_partial": p * (4 * d * d + 6 * d),         # recompute y (2D^2) + rank-1 accumulate (2D^2)
+        # moment form (csrc/stein.hip): rank-1 accumulate of [g;1][x - mu;1]^T (2 (D+1)^2) + centring / weighting (3D); the
+        # per-sample substitution of SURVEY.md 8d's 4D^2 figure is gone (Sigma^-1 is applied once per component afterwards)
+        "stein_partial": p * (2 * (d + 1) * (d + 1) + 3 * d),
         # MORE: lower triangle of the (F+1)x(F+1) Gram matrix of [phi; reward], F = D(D+1)/2 + D + 1 (2 flop per MAC)
         "more_gram": p * ((d * (d + 1) // 2 + d + 2) * (d * (d + 1) // 2 + d + 3) + d * d),
         # blocked path (D > 64): triangular whitening Z = (X - mu) L^-T, gradient sum_k r Z L^-1, Stein sum e [g;1][z;1]^T
@@ -286,12 +288,18 @@ def main():
     f_alg_iter = float(n_tot) * k_tot * (8 * d * d + 12 * d)                   # SURVEY.md 8d (probes reported apart)
     b_alg_iter = 4.0 * (3 * n_tot * d + 3 * n_tot + 2 * k_tot * (d * d + d + 1))
 
+    # HBM bytes per launch of the roofline kernel from the newest committed PMC summary (profiles/rNN_traffic.json; collected
+    # with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled as MI355X_MICROARCH.md prescribes)
     traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            traffic = json.load(f).get(args.workload, {}).get(roof_name, {}).get("hbm_bytes")
-    except (OSError, ValueError):
-        pass
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                traffic = json.load(f).get(args.workload, {}).get(roof_name, {}).get("hbm_bytes")
+        except (OSError, ValueError):
+            traffic = None
+        if traffic is not None:
+            break
     result = {
         "metric": "samples_components_per_sec", "value": n_tot * k_tot / (elapsed / args.steps),
         "unit": "samples*components/s", "train_iter_per_sec": args.steps / elapsed,

@@ -61,7 +61,6 @@ void gmmvi_ctx_destroy(gmmvi_ctx* ctx) {
     }
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->arena) (void)hipFree(ctx->arena);
-    if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->zc_hash) (void)hipFree(ctx->zc_hash);
     delete ctx;
 }
@@ -193,7 +192,7 @@ int gmmvi_copy_batch(gmmvi_ctx* ctx, int n, void* const* dst_dev, const void* co
 
 struct UnpackArgs {
     const uint32_t* src; int n_ranks; unsigned long long chunk; int n_seg;
-    unsigned long long off[4], words[4]; uint32_t* dst[4];
+    unsigned long long off[8], words[8]; uint32_t* dst[8];
 };
 __global__ void unpack_gathered_kernel(UnpackArgs a) {
     const int j = blockIdx.y;
@@ -208,7 +207,7 @@ __global__ void unpack_gathered_kernel(UnpackArgs a) {
 
 int gmmvi_unpack_gathered(gmmvi_ctx* ctx, const void* src_dev, int n_ranks, size_t chunk_words, int n_seg,
                           const size_t* seg_words, void* const* dst_dev) {
-    GMMVI_ARG_CHECK(ctx, src_dev && n_ranks >= 1 && n_seg >= 1 && n_seg <= 4 && seg_words && dst_dev);
+    GMMVI_ARG_CHECK(ctx, src_dev && n_ranks >= 1 && n_seg >= 1 && n_seg <= 8 && seg_words && dst_dev);
     UnpackArgs a{};
     a.src = (const uint32_t*)src_dev; a.n_ranks = n_ranks; a.chunk = chunk_words; a.n_seg = n_seg;
     unsigned long long off = 0, mx = 0;

@@ -37,9 +37,6 @@ int gmmvi_blocked_sample(gmmvi_ctx* ctx, int K, int D, const float* means, const
 int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
                         const float* qgrad, const float* bg, const float* tgrad, const int32_t* mapping, int map_offset,
                         int flags, float* H_neg, float* g_neg);
-int gmmvi_blocked_stein_from_register_pack(gmmvi_ctx* ctx, int K, int D, const float* packed_reg, const float* X, int N,
-                                           const float* ld, const float* qgrad, const float* bg, const float* tgrad,
-                                           const int32_t* mapping, int map_offset, int flags, float* H_neg, float* g_neg);
 int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* chols, const float* H_neg, const float* g_neg,
                             const float* stepsizes, float temperature, float l2_init, float* last_eta, float* l2,
                             float* num_updates, int32_t* success_out, float* kl_out, int32_t* nprobes_out, float* packed_out);

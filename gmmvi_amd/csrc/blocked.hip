@@ -969,7 +969,9 @@ __global__ __launch_bounds__(256) void blk_stein_finalize_kernel(int D, int N, i
     const bool snis = (flags & GMMVI_SELF_NORMALIZED) != 0;
     // own samples only: the divisor is the number of own samples = sum e (weights exp(0), ng_estimator.py:110-118,146-152)
     const bool own = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
-    const float scale = (snis || own) ? 1.f / A[(size_t)D * D1 + D] : __expf(Mk[kb]) / (float)N;
+    // (an empty own-sample set: zeros in the self-normalised branch, NaN in the plain one, as upstream's reductions give)
+    const float se = A[(size_t)D * D1 + D];
+    const float scale = snis ? (se > 0.f ? 1.f / se : 0.f) : (own ? 1.f / se : __expf(Mk[kb]) / (float)N);
     for (int e = threadIdx.x; e < D * D; e += 256) {
         const int i = e / D, j = e % D;
         const float v = snis ? 0.5f * (Tk[e] + Tk[(size_t)j * D + i]) : Tk[e];
@@ -979,55 +981,6 @@ __global__ __launch_bounds__(256) void blk_stein_finalize_kernel(int D, int N, i
 }
 
 }  // namespace
-
-// Register-resident packed blocks (common.h Pack<DP>: mu | 1/diag | strict lower rows | ...) -> dense means [K,D] and lower
-// factors [K,D,D], from which blk_pack builds the blocks of this path [mu | log-normaliser | pad | L^-1 dense].
-namespace {
-__global__ __launch_bounds__(256) void blk_unpack_register_kernel(int D, int rd_ofs, int lrow_ofs, size_t src_stride,
-                                                                  const float* __restrict__ src, float* __restrict__ means,
-                                                                  float* __restrict__ chols) {
-    const int k = blockIdx.x;
-    const float* P = src + (size_t)k * src_stride;
-    for (int e = threadIdx.x; e < D * D; e += 256) {
-        const int i = e / D, j = e % D;
-        chols[(size_t)k * D * D + e] = (j < i) ? P[lrow_ofs + i * (i - 1) / 2 + j] : (j == i ? 1.f / P[rd_ofs + i] : 0.f);
-    }
-    if (threadIdx.x < D) means[(size_t)k * D + threadIdx.x] = P[threadIdx.x];
-}
-}  // namespace
-
-// Stein estimate through the blocked contractions for a model that lives in register-resident packed blocks (40 < D <= 64
-// below the blocked threshold: the tiled register kernel spills there, stein.hip).  The L^-1 blocks are rebuilt per call into a
-// buffer owned by the context.  (The diagonal comes back as 1 / (1 / L_ii): within 1 ulp of L_ii, the log-normaliser is
-// recomputed from it.)
-int gmmvi_blocked_stein_from_register_pack(gmmvi_ctx* ctx, int K, int D, const float* packed_reg, const float* X, int N,
-                                           const float* ld, const float* qgrad, const float* bg, const float* tgrad,
-                                           const int32_t* mapping, int map_offset, int flags, float* H_neg, float* g_neg) {
-    GMMVI_ARG_CHECK(ctx, D >= 1 && D <= GMMVI_MAX_DIM);
-    const int dp = gmmvi_padded_dim(D);
-    const size_t ps = gmmvi_blocked_stride(D);
-    const size_t f_blocks = (size_t)K * ps, f_means = ((size_t)K * D + 3) / 4 * 4, f_chols = (size_t)K * D * D;
-    const size_t need = (f_blocks + f_means + f_chols) * sizeof(float);
-    if (need > ctx->aux_bytes) {
-        GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->aux) GMMVI_HIP_CHECK(ctx, hipFree(ctx->aux));
-        ctx->aux = nullptr;
-        ctx->aux_bytes = 0;
-        GMMVI_HIP_CHECK(ctx, hipMalloc(&ctx->aux, need + need / 2));
-        ctx->aux_bytes = need + need / 2;
-    }
-    float* blocks = (float*)ctx->aux;
-    float* means = blocks + f_blocks;
-    float* chols = means + f_means;
-    {
-        GMMVI_PROF(ctx, "blocked_unpack_register");
-        hipLaunchKernelGGL(blk_unpack_register_kernel, dim3(K), dim3(256), 0, ctx->stream, D, dp, 2 * dp,
-                           gmmvi_packed_stride_dp(dp), packed_reg, means, chols);
-        GMMVI_LAUNCH_CHECK(ctx);
-    }
-    BLK_TRY(gmmvi_blocked_pack(ctx, GMMVI_GAUSS, 0.f, K, D, means, chols, blocks, nullptr));
-    return gmmvi_blocked_stein(ctx, K, D, blocks, X, N, ld, qgrad, bg, tgrad, mapping, map_offset, flags, H_neg, g_neg);
-}
 
 int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
                         const float* qgrad, const float* bg, const float* tgrad, const int32_t* mapping, int map_offset,

@@ -24,8 +24,6 @@ struct gmmvi_ctx {
     unsigned long long* zc_hash = nullptr;       // device: [0,1] recorded with Z, [2,3] current call, [4] match flag
     void* arena = nullptr;       // persistent scratch of the single-call iteration (fused.hip)
     size_t arena_bytes = 0;
-    void* aux = nullptr;         // L^-1 blocks rebuilt from register-resident packed blocks (blocked Stein for 40 < D <= 64)
-    size_t aux_bytes = 0;
     void* comm = nullptr;        // ncclComm_t
     int n_ranks = 1, rank = 0;
     int num_cus = 256;

@@ -1,194 +1,30 @@
 // Importance-weighted Stein estimate of the per-component expected gradient / Hessian
 // (gmmvi_modules/ng_estimator.py:204-263, :171-188 self-normalised, :154-169 plain importance weights).
 //
-// For component k:  A_k = sum_n [g_n; 1] (e_kn [y_kn; 1])^T,  e_kn = exp(ld[k,n] - bg[n] - m),  g_n = grad log p~ - grad log q,
-// y_kn = Sigma_k^-1 (x_n - mu_k).  The (D+1)x(D+1) matrix A_k carries sum e g y^T, sum e g (last column) and sum e
-// (corner), so one contraction over the samples yields the Hessian, the gradient and the normaliser.
-//
-// Two kernels produce per-(component, 256-sample tile) partials of A_k; grid = (tiles, component chunks),
-// 4 waves per workgroup, the x and g tiles of the workgroup fetched ONCE with coalesced 16-byte loads and staged through LDS
-// (per-lane row loads of a row-major [N, D] array were the dominant stall of the first version):
-//   * stein_wc_kernel (D <= 24, the production path): wave = component.  Every lane keeps its x row of the four 64-sample
-//     sub-tiles in VGPRs; wave w walks the components w, w + 4, ... of the chunk and for each of them substitutes the four
-//     sub-tiles (generated hand-scheduled scalar-fed asm for D = 10 / 20, subst_asm_gen.h), writes e * [y; 1] rows to its
-//     private LDS tile and contracts with v_mfma_f32_32x32x2 (16x16x4 for D + 1 <= 16), rescaling the accumulators online
-//     by the running maximum.  No cross-wave merge, no block barrier in the component loop.
-//   * stein_partial_kernel (D > 24): wave = 64 samples, [g;1] A-fragments in VGPRs reused for every component of the chunk,
-//     the four waves merged through LDS per component (own maximum per wave, fixed summation order).
-// stein_finalize sums the slab in fixed order (bitwise reproducible), normalises, symmetrises and negates.
+// For component k:  sum_n e_kn g_n y_kn^T,  e_kn = exp(ld[k,n] - bg[n] - m),  g_n = grad log p~ - grad log q,
+// y_kn = Sigma_k^-1 (x_n - mu_k).  The estimate is linear in y, so Sigma_k^-1 is applied once per component AFTER the sum over
+// the samples: stein_moment_kernel accumulates the raw moment matrix  A_k = sum_n e_kn [g_n; 1] [x_n - mu_k; 1]^T  on the
+// matrix cores ((D+1)x(D+1): sum e g d^T, sum e g in the last column, sum e in the corner), stein_finalize sums the
+// per-range partials in fixed order (bitwise reproducible), applies L^-T L^-1 from the right, normalises, symmetrises and
+// negates.  No per-sample triangular substitution is left on this path (the reference forms y per sample, :165-166, :184).
 #include "common.h"
 #include "blocked.h"
 #include "wave_reduce.h"
-#include "subst_asm_gen.h"
 #include <cstdlib>
-#include <type_traits>
 
-#ifndef GMMVI_STEIN_BLOCKED_FROM_DP
-#define GMMVI_STEIN_BLOCKED_FROM_DP 64     // padded dimension from which gmmvi_stein takes the blocked contractions (see below)
-#endif
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <int DP>
-__device__ __forceinline__ void forward_subst_s(const float* __restrict__ P, const float (&x)[DP], float (&z)[DP]) {
-    using PK = Pack<DP>;
-#pragma unroll
-    for (int i = 0; i < DP; ++i) {
-        float t = x[i] - P[PK::MU + i];
-#pragma unroll
-        for (int j = 0; j < i; ++j) t = fmaf(-P[PK::LROW + PK::rowofs(i) + j], z[j], t);
-        z[i] = t * P[PK::RD + i];
-    }
-}
-
-template <int DP>
-__device__ __forceinline__ void backward_subst_s(const float* __restrict__ P, const float (&z)[DP], float (&y)[DP]) {
-    using PK = Pack<DP>;
-#pragma unroll
-    for (int i = DP - 1; i >= 0; --i) {
-        float t = z[i];
-#pragma unroll
-        for (int j = i + 1; j < DP; ++j) t = fmaf(-P[PK::LCOL + PK::colofs(i) + (j - i - 1)], y[j], t);
-        y[i] = t * P[PK::RD + i];
-    }
-}
 
 __device__ __forceinline__ float wave_max(float v) { return gmmvi_wave_max(v); }
 
-template <int DP, int NB>
-__global__ __launch_bounds__(256, 2) void stein_partial_kernel(int K, int D, int chunk, const float* __restrict__ packed,
-                                                            const float* __restrict__ X, const float* __restrict__ TG,
-                                                            const float* __restrict__ QG, int N,
-                                                            const float* __restrict__ ld, const float* __restrict__ bg,
-                                                            const int32_t* __restrict__ mapping, int map_offset, int flags,
-                                                            float* __restrict__ part, float* __restrict__ part_m) {
-    using PK = Pack<DP>;
-    constexpr int W = 32 * NB;         // padded width of [g;1] and [y;1]
-    constexpr int LDW = W + 1;         // LDS row stride of the MFMA operand tiles
-    extern __shared__ float sm[];
-    __shared__ float sm_m[4];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x;
-    const int n_tiles = gridDim.x;
-    const int D1 = D + 1;
-    const int n0 = tile * 256;
-    const int n_here = min(256, N - n0);
-    // One [256][LDW] LDS image, used in turn as: staging of the x tile, the [g;1] rows (read once into the A fragments), then
-    // the four waves' e*[y;1] tiles / the merge scratch (a separate G image doubled the LDS to 133 KB at W = 64: one
-    // workgroup per CU).  Together with the (256, 2) launch bound two workgroups share a CU.
-    float* Ys = sm;                                   // 4 x [64][LDW] rows e*[y;1;0...]; also staging / merge scratch
-    float* Gs = sm;                                   // [256][LDW]  rows [g;1;0...] (until the A fragments are loaded)
-    float* Yw = Ys + wave * 64 * LDW;
-    const bool own_only = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
-
-    // ---- stage the x tile (coalesced) through Ys, keep this lane's row in registers -------------------------------
-    const int ldx = D | 1;                            // odd stride: conflict-free row reads
-    for (int e = tid; e < n_here * D; e += 256) Ys[(e / D) * ldx + (e % D)] = X[(size_t)n0 * D + e];
-    __syncthreads();
-    const int row = wave * 64 + lane;
-    const bool valid = row < n_here;
-    const int n = n0 + row;
-    float x[DP];
-#pragma unroll
-    for (int i = 0; i < DP; ++i) x[i] = (valid && i < D) ? Ys[row * ldx + i] : 0.f;
-    __syncthreads();
-    // ---- stage the g tile (coalesced) as [g;1] rows, zero padding; pre-zero the padded columns of the Y tiles ----------
-    for (int e = tid; e < 256 * W; e += 256) {
-        const int r = e / W, c = e % W;
-        float v = 0.f;
-        if (r < n_here) {
-            const size_t gi = (size_t)(n0 + r) * D + c;
-            v = (c < D) ? TG[gi] - QG[gi] : (c == D ? 1.f : 0.f);       // g = grad log p~ - grad log q (:248)
-        }
-        Gs[r * LDW + c] = v;
-    }
-    __syncthreads();
-    // A fragments of this wave's 64 samples: lane (col = l & 31, half = l >> 5), step s -> Gs[2s + half][col]
-    const int col = lane & 31, half = lane >> 5;
-    float af[NB][32];
-#pragma unroll
-    for (int a = 0; a < NB; ++a)
-#pragma unroll
-        for (int s = 0; s < 32; ++s) af[a][s] = Gs[(wave * 64 + 2 * s + half) * LDW + 32 * a + col];
-    __syncthreads();                                  // the G rows are in registers: the image becomes the Y tiles
-    for (int c = D1; c < W; ++c) Yw[lane * LDW + c] = 0.f;      // padded columns stay zero (columns <= D are rewritten per component)
-
-    const int k_begin = blockIdx.y * chunk;
-    const int k_end = min(K, k_begin + chunk);
-    for (int k = k_begin; k < k_end; ++k) {
-        const float* __restrict__ P = packed + (size_t)k * PK::STRIDE;
-        float a_log = -3.0e38f;
-        if (valid) {
-            if (own_only) a_log = (mapping[n] + map_offset == k) ? 0.f : -3.0e38f;
-            else a_log = ld[(size_t)k * N + n] - bg[n];
-        }
-        const float m_w = wave_max(a_log);
-        const float e = (valid && a_log > -1.0e38f) ? __expf(a_log - m_w) : 0.f;
-
-        float z[DP];
-        forward_subst_s<DP>(P, x, z);                  // z form: L^-T is applied once per component in stein_finalize
-#pragma unroll
-        for (int i = 0; i < DP; ++i)
-            if (i < D) Yw[lane * LDW + i] = e * z[i];
-        Yw[lane * LDW + D] = e;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-
-        f32x16 acc[NB][NB];
-#pragma unroll
-        for (int a = 0; a < NB; ++a)
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int t = 0; t < 16; ++t) acc[a][b][t] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            float bf[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) bf[b] = Yw[(2 * s + half) * LDW + 32 * b + col];
-#pragma unroll
-            for (int a = 0; a < NB; ++a)
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[b], acc[a][b], 0, 0, 0);
-        }
-
-        // ---- merge the four waves: common maximum, fixed order ------------------------------------------------------
-        if (lane == 0) sm_m[wave] = m_w;
-        __syncthreads();                                  // also: every wave is done reading its Y tile
-        const float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
-        const float f = __expf(m_w - M);
-#pragma unroll
-        for (int a = 0; a < NB; ++a)
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int i = 32 * a + (t & 3) + 8 * (t >> 2) + 4 * half;
-                    const int j = 32 * b + col;
-                    Yw[i * W + j] = acc[a][b][t] * f;      // W*W <= 64*LDW floats
-                }
-        __syncthreads();
-        float* out = part + ((size_t)k * n_tiles + tile) * (size_t)(D1 * D1);
-        for (int el = tid; el < D1 * D1; el += 256) {
-            const int i = el / D1, j = el % D1;
-            out[el] = (Ys[i * W + j] + Ys[64 * LDW + i * W + j]) + (Ys[2 * 64 * LDW + i * W + j] + Ys[3 * 64 * LDW + i * W + j]);
-        }
-        if (tid == 0) part_m[(size_t)k * n_tiles + tile] = M;
-        __syncthreads();
-        // the merge overwrote the padded columns of the Y tiles: restore the zeros for the next component
-        for (int c = D1; c < W; ++c) Yw[lane * LDW + c] = 0.f;
-    }
-}
-
-// DPZ > 0: the partials are in z form (see stein_wc_kernel) and DPZ is the padded dimension of the packed blocks; 0: y form
-template <int DPZ>
+// One workgroup per component: sums the R per-range partials of A_k (each referred to its own maximum m_r) in fixed order,
+// applies Sigma_k^-1 = L^-T L^-1 from the right to the D x D block (row i of the result: h' L^T = t ascending over the rows of
+// L, then h L = h' descending over its columns; L from the component's packed block, common.h Pack<DP>: 1/diag, rows,
+// columns, staged in LDS; the row in registers, loops unrolled for the padded dimension), normalises, symmetrises, negates.
+template <int DP>
 __global__ __launch_bounds__(1024) void stein_finalize_kernel(int D, int R, int N, int flags, const float* __restrict__ part,
                                                              const float* __restrict__ part_m, float* __restrict__ H_neg,
-                                                             float* __restrict__ g_neg, const float* __restrict__ packed_z) {
+                                                             float* __restrict__ g_neg, const float* __restrict__ packed) {
+    using PK = Pack<DP>;
     extern __shared__ float A[];       // (D+1)^2, then R scale factors
     const int k = blockIdx.x;
     const int D1 = D + 1;
@@ -220,30 +56,33 @@ __global__ __launch_bounds__(1024) void stein_finalize_kernel(int D, int R, int 
         A[e] = a;
     }
     __syncthreads();
-    if constexpr (DPZ > 0) {
-        // the partials hold sum e g z^T with z = L^-1 (x - mu): y = L^-T z, so row i of sum e g y^T is (row i) L^-1, i.e.
-        // h L = b solved from the last column; L from the component's packed block (common.h Pack<DP>: 1/diag, columns)
-        // staged in LDS, the row in registers, loops unrolled for the padded dimension
-        using PK = Pack<DPZ>;
-        const float* Pk = packed_z + (size_t)k * PK::STRIDE;
-        float* Lc = Ag;                                // the group sums are consumed: reuse as [1/diag (DPZ) | columns (T)]
-        for (int e = threadIdx.x; e < DPZ + PK::T; e += blockDim.x)
-            Lc[e] = (e < DPZ) ? Pk[PK::RD + e] : Pk[PK::LCOL + (e - DPZ)];
+    {
+        const float* Pk = packed + (size_t)k * PK::STRIDE;
+        float* Lc = Ag;                  // the group sums are consumed: reuse as [1/diag (DP) | columns (T) | rows (T)]
+        for (int e = threadIdx.x; e < DP + 2 * PK::T; e += blockDim.x)
+            Lc[e] = (e < DP) ? Pk[PK::RD + e] : (e < DP + PK::T ? Pk[PK::LCOL + (e - DP)] : Pk[PK::LROW + (e - DP - PK::T)]);
         __syncthreads();
         if (threadIdx.x < D) {
             float* row = A + threadIdx.x * D1;
-            float h[DPZ];
+            float h[DP];
 #pragma unroll
-            for (int j = 0; j < DPZ; ++j) h[j] = (j < D) ? row[j] : 0.f;
+            for (int j = 0; j < DP; ++j) h[j] = (j < D) ? row[j] : 0.f;
 #pragma unroll
-            for (int j = DPZ - 1; j >= 0; --j) {
+            for (int j = 0; j < DP; ++j) {                                  // h' L^T = t
                 float t = h[j];
 #pragma unroll
-                for (int m = j + 1; m < DPZ; ++m) t = fmaf(-h[m], Lc[DPZ + PK::colofs(j) + (m - j - 1)], t);   // padding: L = 0
+                for (int m = 0; m < j; ++m) t = fmaf(-h[m], Lc[DP + PK::T + PK::rowofs(j) + m], t);      // padding: L = 0
                 h[j] = t * Lc[j];
             }
 #pragma unroll
-            for (int j = 0; j < DPZ; ++j)
+            for (int j = DP - 1; j >= 0; --j) {                             // h L = h'
+                float t = h[j];
+#pragma unroll
+                for (int m = j + 1; m < DP; ++m) t = fmaf(-h[m], Lc[DP + PK::colofs(j) + (m - j - 1)], t);
+                h[j] = t * Lc[j];
+            }
+#pragma unroll
+            for (int j = 0; j < DP; ++j)
                 if (j < D) row[j] = h[j];
         }
         __syncthreads();
@@ -254,7 +93,10 @@ __global__ __launch_bounds__(1024) void stein_finalize_kernel(int D, int R, int 
     // with only_use_own_samples the expectation runs over the component's own samples only (get_rewards_for_comp,
     // ng_estimator.py:110-118: weights exp(0) = 1, divisor = their number): sum e = n_own exp(-M) => exp(M) / n_own = 1 / sum e
     const bool own = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
-    const float scale = (snis || own) ? 1.f / A[D * D1 + D] : __expf(M) / (float)N;
+    // self-normalised weights over an EMPTY own-sample set: every reduce_sum of the reference runs over nothing and returns
+    // zeros (ng_estimator.py:171-188), the plain branch divides by the set's length (NaN, a rejected update)
+    const float se = A[D * D1 + D];
+    const float scale = snis ? (se > 0.f ? 1.f / se : 0.f) : (own ? 1.f / se : __expf(M) / (float)N);
     for (int e = threadIdx.x; e < D * D; e += blockDim.x) {
         const int i = e / D, j = e % D;
         const float v = snis ? 0.5f * (A[i * D1 + j] + A[j * D1 + i]) : A[i * D1 + j];
@@ -263,347 +105,361 @@ __global__ __launch_bounds__(1024) void stein_finalize_kernel(int D, int R, int 
     for (int i = threadIdx.x; i < D; i += blockDim.x) g_neg[(size_t)k * D + i] = -A[i * D1 + D] * scale;
 }
 
-template <int DPZ>
-static int launch_stein_finalize_t(gmmvi_ctx* ctx, int K, int D, int R, int N, int flags, const float* part,
-                                   const float* part_m, float* H_neg, float* g_neg, const float* packed_z) {
+template <int DP>
+static int launch_stein_finalize(gmmvi_ctx* ctx, int K, int D, int R, int N, int flags, const float* part,
+                                 const float* part_m, float* H_neg, float* g_neg, const float* packed) {
     const int D1 = D + 1;
     size_t floats = (size_t)5 * D1 * D1 + R;
-    if (DPZ > 0 && (size_t)D1 * D1 + R + DPZ + Pack<(DPZ > 0 ? DPZ : 2)>::T > floats)
-        floats = (size_t)D1 * D1 + R + DPZ + Pack<(DPZ > 0 ? DPZ : 2)>::T;
+    if ((size_t)D1 * D1 + R + DP + 2 * Pack<DP>::T > floats) floats = (size_t)D1 * D1 + R + DP + 2 * Pack<DP>::T;
     const size_t shmem = floats * sizeof(float);
     static size_t attr = 64 * 1024;
     if (shmem > attr) {
-        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_finalize_kernel<DPZ>,
+        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_finalize_kernel<DP>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         attr = shmem;
     }
     GMMVI_PROF(ctx, "stein_finalize");
-    hipLaunchKernelGGL(stein_finalize_kernel<DPZ>, dim3(K), dim3(1024), shmem, ctx->stream, D, R, N, flags, part, part_m, H_neg,
-                       g_neg, packed_z);
+    hipLaunchKernelGGL(stein_finalize_kernel<DP>, dim3(K), dim3(1024), shmem, ctx->stream, D, R, N, flags, part, part_m, H_neg,
+                       g_neg, packed);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }
 
-// packed_z != nullptr: partials in z form (wave-per-component kernel), L^-T applied here
-static int launch_stein_finalize(gmmvi_ctx* ctx, int K, int D, int R, int N, int flags, const float* part,
-                                 const float* part_m, float* H_neg, float* g_neg, const float* packed_z = nullptr) {
-    if (packed_z == nullptr) return launch_stein_finalize_t<0>(ctx, K, D, R, N, flags, part, part_m, H_neg, g_neg, nullptr);
-    switch (gmmvi_padded_dim(D)) {
-#define GMMVI_FIN(DPV) case DPV: return launch_stein_finalize_t<DPV>(ctx, K, D, R, N, flags, part, part_m, H_neg, g_neg, packed_z)
-        GMMVI_FIN(2); GMMVI_FIN(4); GMMVI_FIN(8); GMMVI_FIN(10); GMMVI_FIN(12); GMMVI_FIN(16); GMMVI_FIN(20); GMMVI_FIN(24);
-        GMMVI_FIN(32); GMMVI_FIN(40); GMMVI_FIN(50); GMMVI_FIN(64);
-#undef GMMVI_FIN
-        default: return gmmvi_fail(ctx, GMMVI_ERR_ARG, "stein_finalize: unsupported dimension");
-    }
-}
-
-// Row tile [rows, D] (contiguous in memory) -> LDS image with row stride ld, all loads of a thread in flight at once:
-// 16-byte loads when the tile is 16-byte aligned, one division per float4; A minus B when B is given.
-template <int VMAX>
-__device__ __forceinline__ void stage_rows(const float* __restrict__ A, const float* __restrict__ B, int total, int D,
-                                           float* dst, int ld, int tid) {
-    const bool vec = ((reinterpret_cast<uintptr_t>(A) | (B ? reinterpret_cast<uintptr_t>(B) : 0)) & 15) == 0;
-    if (vec) {
-        const int nv = total >> 2;
-        float4 v[VMAX];
-#pragma unroll
-        for (int u = 0; u < VMAX; ++u) {
-            const int idx = tid + 256 * u;
-            if (idx < nv) {
-                v[u] = reinterpret_cast<const float4*>(A)[idx];
-                if (B) {
-                    const float4 b = reinterpret_cast<const float4*>(B)[idx];
-                    v[u].x -= b.x; v[u].y -= b.y; v[u].z -= b.z; v[u].w -= b.w;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < VMAX; ++u) {
-            const int idx = tid + 256 * u;
-            if (idx < nv) {
-                int r = (4 * idx) / D, c = (4 * idx) - r * D;
-                const float vals[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    dst[r * ld + c] = vals[q];
-                    if (++c == D) { c = 0; ++r; }
-                }
-            }
-        }
-        for (int e = 4 * nv + tid; e < total; e += 256) dst[(e / D) * ld + (e % D)] = B ? A[e] - B[e] : A[e];
-    } else {
-        for (int e = tid; e < total; e += 256) dst[(e / D) * ld + (e % D)] = B ? A[e] - B[e] : A[e];
-    }
-}
-
-// Wave-per-component form (D <= 24): the workgroup stages a 256-sample tile once; wave w then takes the components
-// k_begin + w, + 4, ... of the chunk and runs over all four 64-sample sub-tiles itself, accumulating the augmented
-// matrix in its MFMA registers with an online rescale of the running maximum.  Nothing is merged across waves and the
-// component loop has no block barrier: one partial per (component, tile) leaves straight from the accumulators.  A
-// component's block is read through the scalar cache four times in a row (once per sub-tile) instead of by four waves
-// in four different places.  The kernel accumulates  sum_n e [g;1] [z;1]^T  with the FORWARD-substituted z = L^-1 (x - mu) only:
-// y = L^-T z is linear in z with a per-component matrix, so L^-T is applied once per component to the finished sum
-// (stein_finalize, z_form) instead of once per sample -- half the per-sample vector work.
-// W = 32: v_mfma_f32_32x32x2 (D + 1 <= 32); W = 16: v_mfma_f32_16x16x4 for D + 1 <= 16 -- a quarter of the matrix-pipe time
-// and half the LDS, the 32-wide tile is 88 % padding at D = 10.  D[i][j] of the 16x16x4 form: i = 4 (l / 16) + r, j = l % 16
-// (probed: tools/probe/mfma_f32_16x16x4_layout.hip).
-// The e * [y; 1] tile is private to the wave: ordering its LDS writes against the MFMA operand reads only needs the wave's own
-// LDS queue drained (and the compiler kept from moving the accesses).  A workgroup-scope fence would also wait for every
-// outstanding GLOBAL access -- the prefetched log-density rows, the previous component's partial stores -- ~1 us each time.
+// A wave-private LDS image: ordering its writes against the same wave's later reads only needs the wave's own LDS queue
+// drained (and the compiler kept from moving the accesses).  A workgroup-scope fence would also wait for every outstanding
+// GLOBAL access -- the prefetched rows of the next chunk -- ~1 us each time.
 #define WAVE_LDS_SYNC()                                        \
     do {                                                       \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
         __builtin_amdgcn_wave_barrier();                       \
     } while (0)
 
-template <int DP, int W>
-__global__ __launch_bounds__(256, 2) void stein_wc_kernel(int K, int D, int chunk, const float* __restrict__ packed,
-                                                          const float* __restrict__ X, const float* __restrict__ TG,
-                                                          const float* __restrict__ QG, int N,
-                                                          const float* __restrict__ ld, const float* __restrict__ bg,
-                                                          const int32_t* __restrict__ mapping, int map_offset, int flags,
-                                                          float* __restrict__ part, float* __restrict__ part_m) {
-    using PK = Pack<DP>;
-    constexpr int LDW = W + 1;
-    constexpr int NACC = W == 16 ? 4 : 16;
-    using AccT = typename std::conditional<W == 16, f32x4, f32x16>::type;
+// =====================================================================================================================
+// Moment form (all D <= 63): the estimate is LINEAR in y = Sigma_k^-1 (x - mu_k), so nothing has to be whitened per sample:
+//     A_k = sum_n e_kn [g_n; 1] [x_n - mu_k; 1]^T            (one dense contraction over the samples)
+//     sum_n e g y^T = A_k[:D,:D] Sigma_k^-1 = A_k[:D,:D] L_k^-T L_k^-1   (two triangular solves per COMPONENT, stein_finalize)
+// The contraction is a GEMM whose left operand [g; 1] is common to all components; the right operands of NB components are
+// stacked along the N side of the matrix-core tile (NB (D+1) columns in NT 16-column tiles), so the padding of a (D+1)-wide
+// tile is paid once per stack on the M side only (D = 20: 21 rows in 2 x 16, 3 x 21 = 63 of 64 columns).
+// v_mfma_f32_16x16x4_f32: A lane l -> A[i = l & 15][k = l >> 4], B lane l -> B[k = l >> 4][j = l & 15],
+// D lane l, reg r -> D[i = 4 (l >> 4) + r][j = l & 15]  (tools/probe/mfma_f32_16x16x4_layout.hip).
+//
+// Grid (stack of NB components, sample range); 4 waves per workgroup, all on the same stack, the range split evenly over
+// them.  A wave works through its samples in chunks of 64 WITHOUT any workgroup barrier: lane = sample loads its x / g row,
+// transposed into a wave-private feature-major LDS image T[feature][sample] (row stride 72: the ds_read_b128 of a 16-lane
+// group hit disjoint banks), the importance weights e = exp(ld - bg - M) with lane = sample (M: the maximum over the wave's
+// samples, found by a first pass over the log weights alone), then per 16 samples: MT + 2 NT ds_read_b128 (four MFMA steps each),
+// (x - mu) e on the vector unit, 4 MT NT MFMAs.  Which sample sits in which k-slot of which step is free (the contraction
+// sums over all of them): the lane with k-slot q takes samples 16 u + 4 q + {0,1,2,3} for its four steps of block u, which
+// are contiguous in the image.
+// The four waves are merged through LDS in fixed order (common maximum); one partial per (component, range) goes to the
+// slab that stein_finalize sums -- K x R x (D+1)^2 floats with R ~ 2 x CUs / stacks ranges instead of one per 256 samples.
+// =====================================================================================================================
+constexpr int SM_RS = 72;          // LDS row stride (floats) of the transposed images: 64 samples + 8
+constexpr int SM_NBMAX = 5;        // most components stacked in one tile row
+
+// Tiling of the padded dimension DP (covers D in (previous DP, DP]): MT row tiles for the D + 1 rows of [g; 1], NB components
+// stacked along NT column tiles -- the (NT, NB) with the fewest padded columns among NT <= NTMAX (accumulators: 4 MT NT
+// registers), ties to the smaller tile.
+template <int DP>
+struct SteinTile {
+    static constexpr int D1 = DP + 1 < 64 ? DP + 1 : 64;           // D <= 63
+    static constexpr int MT = (D1 + 15) / 16;
+    static constexpr int NTMAX = MT <= 2 ? 6 : (MT == 3 ? 6 : 7);
+    static constexpr int pick_nt() {
+        int best = 1;
+        long best_num = 0, best_den = 1;                        // efficiency best_num / best_den
+        for (int nt = 1; nt <= NTMAX; ++nt) {
+            int nb = (16 * nt) / D1;
+            if (nb > SM_NBMAX) nb = SM_NBMAX;
+            if (nb < 1) continue;
+            const long num = (long)nb * D1, den = 16L * nt;
+            if (num * best_den > best_num * den) { best = nt; best_num = num; best_den = den; }
+        }
+        return best;
+    }
+    static constexpr int NT = pick_nt();
+    static constexpr int NB = (16 * NT) / D1 < SM_NBMAX ? (16 * NT) / D1 : SM_NBMAX;
+    static constexpr int PREV = DP == 2 ? 0 : DP == 4 ? 2 : DP == 8 ? 4 : DP == 10 ? 8 : DP == 12 ? 10 : DP == 16 ? 12 : DP == 20 ? 16
+                                : DP == 24 ? 20 : DP == 32 ? 24 : DP == 40 ? 32 : DP == 50 ? 40 : 50;     // D > PREV
+};
+
+// A lane's row of a row-major [*, D] array into registers, VW floats per load (VW > 1: D == DP, rows VW*4-byte aligned); the
+// loads of a lane walk the same cache lines, only the first goes past the L1.  No per-lane predication: rows beyond the
+// range are CLAMPED to a valid row by the caller (finite data, weight 0).
+template <int DP, int VW>
+__device__ __forceinline__ void sm_load_row(const float* __restrict__ row, int D, float (&v)[DP]) {
+#pragma unroll
+    for (int f = 0; f < DP; f += VW) {
+        if (VW > 1 || f < SteinTile<DP>::PREV + 1 || f < D) {      // only the last few columns of an inexact fit branch
+            if constexpr (VW == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(row + f);
+                v[f] = t.x; v[f + 1] = t.y; v[f + 2] = t.z; v[f + 3] = t.w;
+            } else if constexpr (VW == 2) {
+                const float2 t = *reinterpret_cast<const float2*>(row + f);
+                v[f] = t.x; v[f + 1] = t.y;
+            } else {
+                v[f] = row[f];
+            }
+        } else {
+            v[f] = 0.f;
+        }
+    }
+}
+
+// registers -> feature-major image T[f][lane]: consecutive lanes, consecutive addresses, immediate offsets
+template <int DP, bool EXACT>
+__device__ __forceinline__ void sm_store_rows(float* t, int D, const float (&v)[DP]) {
+#pragma unroll
+    for (int f = 0; f < DP; ++f)
+        if (EXACT || f < SteinTile<DP>::PREV + 1 || f < D) t[f * SM_RS] = v[f];
+}
+
+// VW > 1: the fast instances, D == DP (compile time) and all weights from ld - bg; VW == 1: any D in the class, scalar row
+// loads, own-samples weights on request
+template <int DP, int VW>
+__global__ __launch_bounds__(256, (SteinTile<DP>::MT <= 2 ? 2 : 1))
+void stein_moment_kernel(int K, int D_rt, int N, int wave_range, const float* __restrict__ packed,
+                         const float* __restrict__ X, const float* __restrict__ TG, const float* __restrict__ QG,
+                         const float* __restrict__ ld, const float* __restrict__ bg, const int32_t* __restrict__ mapping,
+                         int map_offset, int own_rt, float* __restrict__ part, float* __restrict__ part_m) {
+    using ST = SteinTile<DP>;
+    constexpr int MT = ST::MT, NT = ST::NT, NB = ST::NB;
+    constexpr bool EXACT = VW > 1;
+    const int D = EXACT ? DP : D_rt;
+    const bool own = EXACT ? false : own_rt != 0;
     extern __shared__ float sm[];
+    __shared__ float sm_m[4][NB];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x;
-    const int n_tiles = gridDim.x;
     const int D1 = D + 1;
-    const int n0 = tile * 256;
-    const int n_here = min(256, N - n0);
-    float* Gs = sm;                                   // [256][LDW]  rows [g;1;0...]
-    float* Ys = sm + 256 * LDW;                       // 4 x [64][LDW] wave-private rows e*[y;1;0...]; first: x staging
-    float* Yw = Ys + wave * 64 * LDW;
-    const bool own_only = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
+    const int k0 = blockIdx.x * NB;
+    const int nb = min(NB, K - k0);
+    const int R = gridDim.y;
+    // wave-private images: Tg rows 0..D-1 = g, row D = 1 (valid samples), row D+1 = 0; Tx rows 0..D-1 = x, row D = 1;
+    // Te rows 0..NB-1 = importance weights, row NB = 0
+    const int rows_g = D1 + 1, rows_x = D1;
+    constexpr int rows_e = NB + 1;
+    const int wave_floats = (rows_g + rows_x + rows_e) * SM_RS;
+    float* Tg = sm + (size_t)wave * wave_floats;
+    float* Tx = Tg + rows_g * SM_RS;
+    float* Te = Tx + rows_x * SM_RS;
+    for (int e = lane; e < SM_RS; e += 64) { Tg[D1 * SM_RS + e] = 0.f; Te[NB * SM_RS + e] = 0.f; Tx[D * SM_RS + e] = 1.f; }
 
-    // ---- stage the x tile (coalesced); every lane keeps its row of each of the four sub-tiles ---------------------------
-    const int ldx = D | 1;
-    constexpr int VMAX = (DP + 3) / 4;
-    stage_rows<VMAX>(X + (size_t)n0 * D, nullptr, n_here * D, D, Ys, ldx, tid);
-    for (int e = tid; e < 256 * LDW; e += 256) Gs[e] = ((e % LDW) == D && e / LDW < n_here) ? 1.f : 0.f;   // [.;1] column
-    __syncthreads();
-    float x[4][DP];
+    // ---- per-lane operand addresses: A rows of the MT row tiles, (x row, e row, mu) of the NT column tiles ---------------
+    const int q = lane >> 4, c16 = lane & 15;
+    int a_off[MT], x_off[NT], e_off[NT], cidx[NT];
+    float mu[NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int i = 0; i < DP; ++i) x[t][i] = (64 * t + lane < n_here && i < D) ? Ys[(64 * t + lane) * ldx + i] : 0.f;
-    __syncthreads();                                   // x rows are in registers: Ys may be reused
-    // g = grad log p~ - grad log q (:248) into the first D columns of Gs
-    stage_rows<VMAX>(TG + (size_t)n0 * D, QG + (size_t)n0 * D, n_here * D, D, Gs, LDW, tid);
-    __syncthreads();
-    for (int c = D1; c < W; ++c) Yw[lane * LDW + c] = 0.f;
-    __syncthreads();
-
-    const int col = lane & 31, half = lane >> 5;
-    const int k_begin = blockIdx.y * chunk;
-    const int k_end = min(K, k_begin + chunk);
-    // per-sample constants of the four sub-tiles; the log-density row of the NEXT component is fetched while the
-    // current one is being worked on (an L2 round trip per sub-tile would otherwise sit in front of every wave_max)
-    float bgv[4], la[4];
-    int mp[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const bool v = 64 * t + lane < n_here;
-        const int n = n0 + 64 * t + lane;
-        bgv[t] = (v && !own_only) ? bg[n] : 0.f;
-        mp[t] = (v && own_only) ? mapping[n] + map_offset : -1;
-        la[t] = (v && !own_only && k_begin + wave < k_end) ? ld[(size_t)(k_begin + wave) * N + n] : 0.f;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = 16 * mt + c16;
+        a_off[mt] = (row < D1 ? row : D1) * SM_RS + 4 * q;
     }
-    for (int k = k_begin + wave; k < k_end; k += 4) {
-        const float* __restrict__ P = packed + (size_t)k * PK::STRIDE;
-        float la_next[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            la_next[t] = (64 * t + lane < n_here && !own_only && k + 4 < k_end) ? ld[(size_t)(k + 4) * N + n0 + 64 * t + lane] : 0.f;
-        AccT acc;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int c = 16 * nt + c16;
+        const int comp = c / D1, j = c - comp * D1;
+        const bool valid = comp < nb;
+        cidx[nt] = valid ? comp : NB;
+        x_off[nt] = (valid ? j : 0) * SM_RS + 4 * q;
+        e_off[nt] = (valid ? comp : NB) * SM_RS + 4 * q;
+        mu[nt] = (valid && j < D) ? packed[(size_t)(k0 + comp) * Pack<DP>::STRIDE + j] : 0.f;
+    }
+    const int w_begin = min(N, (blockIdx.y * 4 + wave) * wave_range);
+    const int w_end = min(N, w_begin + wave_range);
+
+    // log importance weight of (component slot c, sample n0 + lane).  Samples / components beyond the range are CLAMPED to
+    // valid ones and their weight forced to "-inf" by a per-lane upper limit (a min, not a branch: the loads stay
+    // unconditional and in flight together)
+    float c_lim[NB];
 #pragma unroll
-        for (int t = 0; t < NACC; ++t) acc[t] = 0.f;
-        float M = -3.0e38f;
-        if constexpr (SubstAsmPk<DP>::available) {
-            // Sub-tiles substituted in PAIRS: two samples per lane as packed float2 registers, one v_pk_fma_f32 per element of
-            // L for both (subst_asm_gen.h) -- the packed rate is the fp32 peak of the vector unit, the plain v_fma_f32 form
-            // runs at half of it.
-            gmmvi_f32x2 yp[DP];
+    for (int c = 0; c < NB; ++c) c_lim[c] = c < nb ? 3.0e38f : -3.0e38f;
+    auto log_weights = [&](int n0, float (&a)[NB]) {
+        const int n = min(n0 + lane, N - 1);
+        const float lim = (n0 + lane < w_end) ? 3.0e38f : -3.0e38f;
+        if (own) {
+            const int mp = mapping[n] + map_offset;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if ((t & 1) == 0) {
-#pragma unroll
-                    for (int i = 0; i < DP; ++i) { yp[i].x = x[t][i]; yp[i].y = x[t + 1 < 4 ? t + 1 : 3][i]; }
-                    SubstAsmPk<DP>::forward(P, yp);             // z = L^-1 (x - mu); L^-T is applied once, in stein_finalize
-                }
-                const bool vt = 64 * t + lane < n_here;
-                const float a_t = !vt ? -3.0e38f : (own_only ? ((mp[t] == k) ? 0.f : -3.0e38f) : la[t] - bgv[t]);
-                const float m_t = wave_max(a_t);
-                const float Mn = fmaxf(M, m_t);
-                const float f = __expf(M - Mn);                        // 1 when the maximum did not move, 0 at the start
-                M = Mn;
-#pragma unroll
-                for (int r = 0; r < NACC; ++r) acc[r] *= f;
-                const float e = (a_t > -1.0e38f) ? __expf(a_t - M) : 0.f;
-#pragma unroll
-                for (int i = 0; i < DP; ++i)
-                    if (i < D) Yw[lane * LDW + i] = e * ((t & 1) ? yp[i].y : yp[i].x);
-                Yw[lane * LDW + D] = e;
-                WAVE_LDS_SYNC();
-                constexpr int KS = W == 16 ? 4 : 2, NS = 64 / KS;
-                const int fr = W == 16 ? (lane & 15) : col, fk = W == 16 ? (lane >> 4) : half;
-                const float* Gt = Gs + (64 * t + fk) * LDW + fr;
-                const float* Yt = Yw + fk * LDW + fr;
-#pragma unroll
-                for (int s2 = 0; s2 < NS; ++s2) {
-                    if constexpr (W == 16) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Gt[KS * s2 * LDW], Yt[KS * s2 * LDW], acc, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Gt[KS * s2 * LDW], Yt[KS * s2 * LDW], acc, 0, 0, 0);
-                }
-                WAVE_LDS_SYNC();
-            }
+            for (int c = 0; c < NB; ++c) a[c] = fminf((mp == k0 + c) ? 0.f : -3.0e38f, fminf(lim, c_lim[c]));
         } else {
-        // Software pipeline over the four sub-tiles: the substitution of sub-tile t + 1 (VALU, scalar loads) is issued in the
-            // same straight-line region as the 32 MFMAs of sub-tile t, so the matrix pipe works in the shadow of the vector
-            // work of the same wave; the rescale by the running maximum sits between the regions and is branch-free.
-            float yn[DP], a_n;
-            {
-                const bool v0 = lane < n_here;
-                a_n = !v0 ? -3.0e38f : (own_only ? ((mp[0] == k) ? 0.f : -3.0e38f) : la[0] - bgv[0]);
-                if constexpr (SubstAsm<DP>::available) {
+            const float bgv = bg[n];
 #pragma unroll
-                    for (int i = 0; i < DP; ++i) yn[i] = x[0][i];
-                    SubstAsm<DP>::forward(P, yn);                          // hand-scheduled: double-buffered scalar feed
-                } else {
-                    forward_subst_s<DP>(P, x[0], yn);
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                // ---- region B: new running maximum, rescale, publish e * [y; 1] of sub-tile t ---------------------------------
-                const float m_t = wave_max(a_n);
-                const float Mn = fmaxf(M, m_t);
-                const float f = __expf(M - Mn);                            // 1 when the maximum did not move, 0 at the start
-                M = Mn;
-#pragma unroll
-                for (int r = 0; r < NACC; ++r) acc[r] *= f;
-                const float e = (a_n > -1.0e38f) ? __expf(a_n - M) : 0.f;
-#pragma unroll
-                for (int i = 0; i < DP; ++i)
-                    if (i < D) Yw[lane * LDW + i] = e * yn[i];
-                Yw[lane * LDW + D] = e;
-                WAVE_LDS_SYNC();
-                // ---- region A: MFMAs of sub-tile t  ||  substitution of sub-tile t + 1 ---------------------------------------
-                // operand fragments: 32x32x2 -> lane (row/col = l % 32, k = l / 32), 32 steps of 2 samples;
-                //                    16x16x4 -> lane (row/col = l % 16, k = l / 16), 16 steps of 4 samples
-                constexpr int KS = W == 16 ? 4 : 2, NS = 64 / KS;
-                const int fr = W == 16 ? (lane & 15) : col, fk = W == 16 ? (lane >> 4) : half;
-                const float* Gt = Gs + (64 * t + fk) * LDW + fr;
-                const float* Yt = Yw + fk * LDW + fr;
-                float ga[NS], yb[NS];
-#pragma unroll
-                for (int s2 = 0; s2 < NS; ++s2) { ga[s2] = Gt[KS * s2 * LDW]; yb[s2] = Yt[KS * s2 * LDW]; }
-                if (t < 3) {
-                    const bool v1 = 64 * (t + 1) + lane < n_here;
-                    a_n = !v1 ? -3.0e38f : (own_only ? ((mp[t + 1 < 4 ? t + 1 : 3] == k) ? 0.f : -3.0e38f)
-                                                      : la[t + 1 < 4 ? t + 1 : 3] - bgv[t + 1 < 4 ? t + 1 : 3]);
-                    if constexpr (SubstAsm<DP>::available) {
-#pragma unroll
-                        for (int i = 0; i < DP; ++i) yn[i] = x[t + 1 < 4 ? t + 1 : 3][i];
-                        SubstAsm<DP>::forward(P, yn);
-                    } else {
-                        forward_subst_s<DP>(P, x[t + 1 < 4 ? t + 1 : 3], yn);
-                    }
-                }
-#pragma unroll
-                for (int s2 = 0; s2 < NS; ++s2) {
-                    if constexpr (W == 16) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s2], yb[s2], acc, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s2], yb[s2], acc, 0, 0, 0);
-                }
-                WAVE_LDS_SYNC();
-            }
+            for (int c = 0; c < NB; ++c) a[c] = fminf(ld[(size_t)min(k0 + c, K - 1) * N + n] - bgv, fminf(lim, c_lim[c]));
         }
-        float* out = part + ((size_t)k * n_tiles + tile) * (size_t)(D1 * D1);
+    };
+
+    // ---- pass 1: the maximum of the log weights over this wave's samples, per component: the weights of pass 2 are referred
+    // to it from the start, the accumulators never have to be rescaled ------------------------------------------------
+    float M[NB];
 #pragma unroll
-        for (int r = 0; r < NACC; ++r) {
-            const int i = W == 16 ? 4 * (lane >> 4) + r : (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int j = W == 16 ? (lane & 15) : col;
-            if (i < D1 && j < D1) out[i * D1 + j] = acc[r];
-        }
-        if (lane == 0) part_m[(size_t)k * n_tiles + tile] = M;
+    for (int c = 0; c < NB; ++c) M[c] = -3.0e38f;
+    for (int n0 = w_begin; n0 < w_end; n0 += 64) {
+        float a[NB];
+        log_weights(n0, a);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) la[t] = la_next[t];
+        for (int c = 0; c < NB; ++c) M[c] = fmaxf(M[c], a[c]);
     }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) M[c] = wave_max(M[c]);
+
+    // ---- pass 2: chunks of 64 samples, software-pipelined: the rows of chunk i + 1 are fetched into registers while the
+    // matrix cores work on chunk i.  Rows beyond the range are clamped to real rows (finite data) and carry weight 0, so
+    // nothing has to be zeroed.
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][nt][r] = 0.f;
+    float a[NB], xr[DP], tr[DP], qr[DP];
+    auto fetch = [&](int n0) {
+        const size_t row = (size_t)min(n0 + lane, N - 1) * D;
+        log_weights(n0, a);
+        sm_load_row<DP, VW>(X + row, D, xr);
+        sm_load_row<DP, VW>(TG + row, D, tr);
+        sm_load_row<DP, VW>(QG + row, D, qr);
+    };
+    if (w_begin < w_end) fetch(w_begin);
+    for (int n0 = w_begin; n0 < w_end; n0 += 64) {
+        const int n_here = min(64, w_end - n0);
+        sm_store_rows<DP, EXACT>(Tx + lane, D, xr);
+#pragma unroll
+        for (int f = 0; f < DP; ++f) tr[f] -= qr[f];               // g = grad log p~ - grad log q (:248)
+        sm_store_rows<DP, EXACT>(Tg + lane, D, tr);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) Te[c * SM_RS + lane] = (a[c] > -1.0e38f) ? __expf(a[c] - M[c]) : 0.f;
+        Tg[D * SM_RS + lane] = 1.f;
+        WAVE_LDS_SYNC();
+        fetch(n0 + 64);                                            // past the end: clamped rows, never used
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (16 * u < n_here) {
+                f32x4 av[MT], bv[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(Tg + a_off[mt] + 16 * u);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(Tx + x_off[nt] + 16 * u);
+                    const f32x4 ev = *reinterpret_cast<const f32x4*>(Te + e_off[nt] + 16 * u);
+                    bv[nt] = (xv - mu[nt]) * ev;
+                }
+#pragma unroll
+                for (int sp = 0; sp < 4; ++sp)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][sp], bv[nt][sp], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        WAVE_LDS_SYNC();
+    }
+
+    // ---- merge the four waves (common maximum per component, fixed order), one partial per (component, range) ---------
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) sm_m[wave][c] = M[c];
+    }
+    __syncthreads();                                   // also: every wave is done with its images
+    float Mall[NB], fsc[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        Mall[c] = fmaxf(fmaxf(sm_m[0][c], sm_m[1][c]), fmaxf(sm_m[2][c], sm_m[3][c]));
+        fsc[c] = __expf(M[c] - Mall[c]);
+    }
+    constexpr int CW = 16 * NT + 1;
+    float* C = sm;                                     // [16 MT][CW]
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float fs = 1.f;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) fs = (cidx[nt] == c) ? fsc[c] : fs;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float* dst = C + (16 * mt + 4 * q + r) * CW + 16 * nt + c16;
+                        const float v = acc[mt][nt][r] * fs;
+                        *dst = (w == 0) ? v : *dst + v;
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    const int DD = D1 * D1;
+    for (int el = tid; el < nb * DD; el += 256) {
+        const int comp = el / DD, rem = el - comp * DD;
+        const int i = rem / D1, j = rem - i * D1;
+        part[((size_t)(k0 + comp) * R + blockIdx.y) * DD + rem] = C[i * CW + comp * D1 + j];
+    }
+    if (tid < nb) part_m[(size_t)(k0 + tid) * R + blockIdx.y] = Mall[tid];
 }
 
-template <int DP, int W>
-static int launch_stein_wc(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
-                           const float* qgrad, const float* bg, const float* tgrad, const int32_t* mapping, int map_offset,
-                           int flags, float* H_neg, float* g_neg) {
-    constexpr int LDW = W + 1;
+template <int DP, int VW>
+static int launch_stein_moment(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
+                               const float* qgrad, const float* bg, const float* tgrad, const int32_t* mapping,
+                               int map_offset, int flags, float* H_neg, float* g_neg) {
+    using ST = SteinTile<DP>;
     const int D1 = D + 1;
-    const int n_tiles = (N + 255) / 256;
-    // components per workgroup: a multiple of the four waves, ~2 workgroups per CU in flight
-    int chunk = (int)(((long)n_tiles * K + 2L * ctx->num_cus - 1) / (2L * ctx->num_cus));
-    chunk = ((chunk + 3) / 4) * 4;
-    if (chunk < 4) chunk = 4;
-    if (chunk > 16) chunk = 16;
-    static const int env_chunk = getenv("GMMVI_STEIN_CHUNK") ? atoi(getenv("GMMVI_STEIN_CHUNK")) : 0;
-    if (env_chunk > 0) chunk = env_chunk;
-    const int n_chunks = (K + chunk - 1) / chunk;
-    const size_t part_floats = (size_t)K * n_tiles * D1 * D1;
-    int rc = gmmvi_ws_reserve(ctx, (part_floats + (size_t)K * n_tiles) * sizeof(float));
+    const int stacks = (K + ST::NB - 1) / ST::NB;
+    // sample ranges: the grid fits the chip in ONE round of resident workgroups (a few workgroups over that would double the
+    // time), at least 64 samples per wave
+    const int wgs_per_cu = ST::MT <= 2 ? 2 : 1;
+    static const int env_wgs = getenv("GMMVI_STEIN_WGS_PER_CU") ? atoi(getenv("GMMVI_STEIN_WGS_PER_CU")) : 0;
+    int R = ((env_wgs > 0 ? env_wgs : wgs_per_cu) * ctx->num_cus) / stacks;
+    if (R > (N + 255) / 256) R = (N + 255) / 256;
+    if (R < 1) R = 1;
+    int wave_range = (((N + R - 1) / R + 3) / 4 + 3) / 4 * 4;        // multiple of 4 samples (one MFMA k-step)
+    R = (N + 4 * wave_range - 1) / (4 * wave_range);
+    const size_t part_floats = (size_t)K * R * D1 * D1;
+    int rc = gmmvi_ws_reserve(ctx, (part_floats + (size_t)K * R) * sizeof(float));
     if (rc != GMMVI_OK) return rc;
     float* part = (float*)ctx->ws;
     float* part_m = part + part_floats;
-    const size_t shmem = (size_t)(256 + 4 * 64) * LDW * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_wc_kernel<DP, W>,
+    size_t floats = (size_t)4 * (2 * D1 + ST::NB + 2) * SM_RS;
+    if (floats < (size_t)16 * ST::MT * (16 * ST::NT + 1)) floats = (size_t)16 * ST::MT * (16 * ST::NT + 1);
+    const size_t shmem = floats * sizeof(float);
+    static size_t attr = 64 * 1024;
+    if (shmem > attr) {
+        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_moment_kernel<DP, VW>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
+        attr = shmem;
     }
     {
         GMMVI_PROF(ctx, "stein_partial");
-        hipLaunchKernelGGL((stein_wc_kernel<DP, W>), dim3(n_tiles, n_chunks), dim3(256), shmem, ctx->stream, K, D, chunk,
-                           packed, X, tgrad, qgrad, N, ld, bg, mapping, map_offset, flags, part, part_m);
+        hipLaunchKernelGGL((stein_moment_kernel<DP, VW>), dim3(stacks, R), dim3(256), shmem, ctx->stream, K, D, N, wave_range,
+                           packed, X, tgrad, qgrad, ld, bg, mapping, map_offset, (flags & GMMVI_OWN_SAMPLES_ONLY) ? 1 : 0, part,
+                           part_m);
     }
     GMMVI_LAUNCH_CHECK(ctx);
-    return launch_stein_finalize(ctx, K, D, n_tiles, N, flags, part, part_m, H_neg, g_neg, packed);   // z form
+    return launch_stein_finalize<DP>(ctx, K, D, R, N, flags, part, part_m, H_neg, g_neg, packed);
 }
 
-
-template <int DP, int NB>
-static int launch_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
+static int stein_moment(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
                         const float* qgrad, const float* bg, const float* tgrad, const int32_t* mapping, int map_offset,
                         int flags, float* H_neg, float* g_neg) {
-    constexpr int LDW = 32 * NB + 1;
-    const int D1 = D + 1;
-    const int n_tiles = (N + 255) / 256;
-    // components per workgroup: amortise the tile staging, keep >= ~4 workgroups per CU in flight
-    int chunk = (int)(((long)n_tiles * K + 4L * ctx->num_cus - 1) / (4L * ctx->num_cus));
-    if (chunk < 1) chunk = 1;
-    if (chunk > 16) chunk = 16;
-    const int n_chunks = (K + chunk - 1) / chunk;
-    const size_t part_floats = (size_t)K * n_tiles * D1 * D1;
-    const size_t need = (part_floats + (size_t)K * n_tiles) * sizeof(float);
-    int rc = gmmvi_ws_reserve(ctx, need);
-    if (rc != GMMVI_OK) return rc;
-    float* part = (float*)ctx->ws;
-    float* part_m = part + part_floats;
-    const size_t shmem = (size_t)256 * LDW * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && shmem > 64 * 1024) {
-        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_partial_kernel<DP, NB>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
+    const int dp = gmmvi_padded_dim(D);
+    // fast instance: D is exactly the padded dimension, rows aligned to the widest load their length allows, weights from ld - bg
+    const uintptr_t bases = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(tgrad) | reinterpret_cast<uintptr_t>(qgrad);
+    const int vw_nat = (dp % 4 == 0) ? 4 : 2;                         // every padded dimension is even
+    const bool fast = D == dp && !(flags & GMMVI_OWN_SAMPLES_ONLY) && bases % (4 * vw_nat) == 0;
+#define GMMVI_SM(DPV)                                                                                                  \
+    case DPV:                                                                                                          \
+        if (fast)                                                                                                      \
+            return launch_stein_moment<DPV, (DPV % 4 == 0 ? 4 : 2)>(ctx, K, D, packed, X, N, ld, qgrad, bg, tgrad, mapping, \
+                                                                    map_offset, flags, H_neg, g_neg);                   \
+        return launch_stein_moment<DPV, 1>(ctx, K, D, packed, X, N, ld, qgrad, bg, tgrad, mapping, map_offset, flags, H_neg, g_neg)
+    switch (dp) {
+        GMMVI_SM(2); GMMVI_SM(4); GMMVI_SM(8); GMMVI_SM(10); GMMVI_SM(12); GMMVI_SM(16); GMMVI_SM(20); GMMVI_SM(24);
+        GMMVI_SM(32); GMMVI_SM(40); GMMVI_SM(50); GMMVI_SM(64);
+        default: break;
     }
-    {
-        GMMVI_PROF(ctx, "stein_partial");
-        hipLaunchKernelGGL((stein_partial_kernel<DP, NB>), dim3(n_tiles, n_chunks), dim3(256), shmem, ctx->stream, K, D,
-                           chunk, packed, X, tgrad, qgrad, N, ld, bg, mapping, map_offset, flags, part, part_m);
-    }
-    GMMVI_LAUNCH_CHECK(ctx);
-    return launch_stein_finalize(ctx, K, D, n_tiles, N, flags, part, part_m, H_neg, g_neg, packed);   // z form
+#undef GMMVI_SM
+    return gmmvi_fail(ctx, GMMVI_ERR_ARG, "gmmvi_stein: unsupported dimension (D must be <= 63)");
 }
 
 extern "C" int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* X_dev, int N,
@@ -617,52 +473,6 @@ extern "C" int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev
     if (gmmvi_is_blocked_dim(D))
         return gmmvi_blocked_stein(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev, mapping_dev,
                                    map_offset, flags, H_neg_out_dev, g_neg_out_dev);
-    const int dp = gmmvi_padded_dim(D);
-    const bool two = (D + 1) > 32;
-    // Padded dimension 64 below the blocked threshold (only when GMMVI_BLOCKED_ABOVE was raised): the blocked contractions on
-    // L^-1 blocks rebuilt from the packed ones.  Up to 50 the tiled kernel wins since it runs two workgroups per CU (C3 shape:
-    // 407 + 32 us against 29 + 188 + 257 + 18 us); GMMVI_STEIN_TILED=1 forces the tiled kernel.
-    static const bool force_tiled_big = getenv("GMMVI_STEIN_TILED") != nullptr;
-    if (dp >= GMMVI_STEIN_BLOCKED_FROM_DP && !force_tiled_big)
-        return gmmvi_blocked_stein_from_register_pack(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,
-                                                      mapping_dev, map_offset, flags, H_neg_out_dev, g_neg_out_dev);
-    // D <= 24: wave-per-component kernel (GMMVI_STEIN_TILED=1 selects the tiled kernel with its cross-wave merge)
-    static const bool force_tiled = getenv("GMMVI_STEIN_TILED") != nullptr;
-    if (!force_tiled && dp <= 24) {
-        switch (dp) {
-#define GMMVI_STEIN_WC(DPV, WV)                                                                                      \
-    case DPV: return launch_stein_wc<DPV, WV>(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,  \
-                                              mapping_dev, map_offset, flags, H_neg_out_dev, g_neg_out_dev)
-            GMMVI_STEIN_WC(2, 16); GMMVI_STEIN_WC(4, 16); GMMVI_STEIN_WC(8, 16); GMMVI_STEIN_WC(10, 16);
-            GMMVI_STEIN_WC(12, 16);
-            case 16:
-                if (D + 1 <= 16)
-                    return launch_stein_wc<16, 16>(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,
-                                                   mapping_dev, map_offset, flags, H_neg_out_dev, g_neg_out_dev);
-                return launch_stein_wc<16, 32>(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,
-                                               mapping_dev, map_offset, flags, H_neg_out_dev, g_neg_out_dev);
-            GMMVI_STEIN_WC(20, 32); GMMVI_STEIN_WC(24, 32);
-#undef GMMVI_STEIN_WC
-            default: break;
-        }
-    }
-    switch (dp) {
-#define GMMVI_STEIN_CASE(DPV, NBV)                                                                                  \
-    return launch_stein<DPV, NBV>(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev,            \
-                                  mapping_dev, map_offset, flags, H_neg_out_dev, g_neg_out_dev)
-        case 2: GMMVI_STEIN_CASE(2, 1);
-        case 4: GMMVI_STEIN_CASE(4, 1);
-        case 8: GMMVI_STEIN_CASE(8, 1);
-        case 10: GMMVI_STEIN_CASE(10, 1);
-        case 12: GMMVI_STEIN_CASE(12, 1);
-        case 16: GMMVI_STEIN_CASE(16, 1);
-        case 20: GMMVI_STEIN_CASE(20, 1);
-        case 24: GMMVI_STEIN_CASE(24, 1);
-        case 32: if (two) GMMVI_STEIN_CASE(32, 2); else GMMVI_STEIN_CASE(32, 1);
-        case 40: GMMVI_STEIN_CASE(40, 2);
-        case 50: GMMVI_STEIN_CASE(50, 2);
-        case 64: GMMVI_STEIN_CASE(64, 2);
-#undef GMMVI_STEIN_CASE
-        default: return gmmvi_fail(ctx, GMMVI_ERR_ARG, "unsupported dimension for gmmvi_stein (D must be <= 63)");
-    }
+    return stein_moment(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev, mapping_dev, map_offset, flags,
+                        H_neg_out_dev, g_neg_out_dev);
 }

@@ -23,7 +23,10 @@ __device__ __forceinline__ void weight_stepsize_wave(int K, const float* __restr
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
     if (lane == 0) {
-        const float elbo = (float)a;
+        // a proxy still made of the float32.min sentinels of a fresh reward history (every component new: the first
+        // iteration) equals float32.min up to the rounding of sum_k w_k ~ 1: pinned to float32.min itself, so that the first
+        // comparison is "not greater" whatever the precision the weights are kept in (DESIGN.md section 6, Q-elbo)
+        const float elbo = (a <= -3.4028e38) ? -3.402823466e38f : (float)a;
         const float prev = state[1];
         state[0] = (elbo > prev) ? fminf(inc * state[0], mx) : fmaxf(dec * state[0], mn);  // :149-156
         state[1] = elbo;

@@ -76,7 +76,7 @@ int gmmvi_gather_rows(gmmvi_ctx* ctx, const void* src_dev, const int32_t* idx_de
 /* Up to 8 device-to-device copies in ONE launch (the per-iteration SampleDB append of samples, target values,
  * gradients and component snapshots, optimization/sample_db.py:115-124; sizes in bytes, multiples of 4). */
 int gmmvi_copy_batch(gmmvi_ctx* ctx, int n, void* const* dst_dev, const void* const* src_dev, const size_t* nbytes);
-/* De-interleaves an all-gathered buffer: every rank contributed one chunk of chunk_words 4-byte words made of n_seg <= 4
+/* De-interleaves an all-gathered buffer: every rank contributed one chunk of chunk_words 4-byte words made of n_seg <= 8
  * consecutive segments (seg_words[j] words each); dst[j] receives segment j of all ranks back to back,
  * dst[j][r * seg_words[j] + i] = src[r * chunk_words + seg_offset_j + i].  One launch; lets the sharded iteration send
  * several arrays in ONE collective (sharded.py E1-E3). */

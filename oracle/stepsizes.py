@@ -66,8 +66,10 @@ class WeightStepsizeImprovement:
         # (gmm_wrapper.py:72) absorbs the entropy term, so the very first comparison is "not greater".
         # Rounding the proxy to fp32 makes that outcome deterministic for every working precision
         # (DESIGN.md, quirk Q-elbo); the HIP kernel accumulates in fp64 and rounds the same way.
+        # A proxy still made of the sentinels alone (every component fresh: the first iteration) equals float32.min up to
+        # the rounding of sum_k w_k ~ 1; it is pinned to float32.min so that the outcome does not depend on that rounding.
         with np.errstate(over='ignore'):
-            elbo = float(np.float32(elbo))
+            elbo = FLOAT32_MIN if elbo <= -3.4028e38 else float(np.float32(elbo))
         self.elbo_history.append(elbo)
         if self.elbo_history[-1] > self.elbo_history[-2]:
             self.stepsize = min(self.stepsize_inc_factor * self.stepsize, self.max_stepsize)

@@ -122,7 +122,8 @@ class OracleOps:
     def weight_stepsize(self, logw, rewards_last, state, c):
         w = np.exp(logw)
         with np.errstate(over="ignore"):
-            elbo = float(np.float32(np.sum(w * rewards_last) - np.sum(w * logw)))
+            elbo = float(np.sum(w * rewards_last) - np.sum(w * logw))
+            elbo = float(np.finfo(np.float32).min) if elbo <= -3.4028e38 else float(np.float32(elbo))
         if elbo > state[1]:
             state[0] = min(c["stepsize_inc_factor"] * state[0], c["max_stepsize"])
         else:
