@@ -116,7 +116,21 @@ inline int gmmvi_padded_dim(int D) {
         default: return gmmvi_fail(ctx, GMMVI_ERR_ARG, "unsupported dimension (D must be <= 64)"); \
     }
 
+// Padded dimension from which the density sweeps run on the matrix cores with the explicit inverse (density.hip).  Measured at
+// K = 100, N = 10^4 (profiles/r02_notes.md): D = 50 dual sweep 300 -> 112 us, post-update sweep 100 -> 73 us; D = 20 and D = 10
+// are slower there (a 16-sample sub-tile pays the log-sum-exp tail four times as often per pair): they keep the scalar-fed
+// substitution kernel and the smaller block.
+#ifndef GMMVI_MFMA_DENSITY_FROM_DP
+#define GMMVI_MFMA_DENSITY_FROM_DP 32
+#endif
+
 // ---- packed component block layout (floats) ---------------------------------------------------------------
+// [mu | 1/diag L | strict lower triangle of L by rows | the same by columns | log-normaliser | pad | L^-1 as matrix-core
+// operand fragments].  The fragments feed v_mfma_f32_16x16x4_f32 directly (A operand: lane l holds A[i = l & 15][k = l >> 4]),
+// one 64-float fragment per (16-row tile mt, 4-column step s):
+//   forward  z = L^-1 d:    FWD + 64 fwd_index(mt, s) + l  =  Linv[16 mt + (l & 15)][4 s + (l >> 4)],   s < nf(mt)  (lower triangle)
+//   backward y = L^-T z:    BWD + 64 bwd_index(mt, s) + l  =  Linv[4 s + (l >> 4)][16 mt + (l & 15)],   s >= 4 mt
+// (entries outside D x D are zero), so a wave fetches a fragment with one coalesced 256-byte load.
 template <int DP>
 struct Pack {
     static constexpr int T = DP * (DP - 1) / 2;
@@ -125,9 +139,60 @@ struct Pack {
     static constexpr int LROW = 2 * DP;       // strict lower triangle, row-major: (i, j<i) at i(i-1)/2 + j
     static constexpr int LCOL = 2 * DP + T;   // same entries column-major: (j>i, i) at colofs(i) + j-i-1
     static constexpr int CONST = 2 * DP + 2 * T;   // log-normaliser
-    static constexpr int STRIDE = ((2 * DP + 2 * T + 1 + 3) / 4) * 4;
+    static constexpr bool FRAGS = DP >= GMMVI_MFMA_DENSITY_FROM_DP;      // smaller blocks carry no fragments (scalar-fed kernel)
+    static constexpr int MT = (DP + 15) / 16;      // 16-row tiles
+    static constexpr int KS = (DP + 3) / 4;        // 4-column steps
+    __host__ __device__ static constexpr int nf(int mt) { return 4 * mt + 4 < KS ? 4 * mt + 4 : KS; }     // forward steps 0 .. nf-1
+    __host__ __device__ static constexpr int nbk(int mt) { return KS - 4 * mt > 0 ? KS - 4 * mt : 0; }    // backward steps 4 mt .. KS-1
+    __host__ __device__ static constexpr int fwd_base(int mt) { int a = 0; for (int m = 0; m < mt; ++m) a += nf(m); return a; }
+    __host__ __device__ static constexpr int bwd_base(int mt) { int a = 0; for (int m = 0; m < mt; ++m) a += nbk(m); return a; }
+    __host__ __device__ static constexpr int fwd_index(int mt, int s) { return fwd_base(mt) + s; }
+    __host__ __device__ static constexpr int bwd_index(int mt, int s) { return bwd_base(mt) + (s - 4 * mt); }
+    static constexpr int NF = FRAGS ? fwd_base(MT) : 0, NB = FRAGS ? bwd_base(MT) : 0;
+    static constexpr int FWD = FRAGS ? ((CONST + 1 + 63) / 64) * 64 : ((CONST + 1 + 3) / 4) * 4;
+    static constexpr int BWD = FWD + 64 * NF;
+    static constexpr int STRIDE = BWD + 64 * NB;
     __host__ __device__ static constexpr int rowofs(int i) { return i * (i - 1) / 2; }
     __host__ __device__ static constexpr int colofs(int i) { return i * (DP - 1) - i * (i - 1) / 2; }
 };
 
-inline size_t gmmvi_packed_stride_dp(int dp) { return (size_t)((2 * dp + dp * (dp - 1) + 1 + 3) / 4) * 4; }
+// (run-time twin of Pack<DP>::STRIDE / ::FWD / ::BWD for code that takes the padded dimension as an argument)
+struct PackDims { int fwd, bwd, stride, mt, ks, nf_total, nb_total; };
+inline __host__ __device__ PackDims gmmvi_pack_dims(int dp) {
+    PackDims d{};
+    const int T = dp * (dp - 1) / 2;
+    d.mt = (dp + 15) / 16; d.ks = (dp + 3) / 4;
+    const bool frags = dp >= GMMVI_MFMA_DENSITY_FROM_DP;
+    for (int m = 0; frags && m < d.mt; ++m) {
+        d.nf_total += 4 * m + 4 < d.ks ? 4 * m + 4 : d.ks;
+        d.nb_total += d.ks - 4 * m > 0 ? d.ks - 4 * m : 0;
+    }
+    d.fwd = frags ? ((2 * dp + 2 * T + 1 + 63) / 64) * 64 : ((2 * dp + 2 * T + 1 + 3) / 4) * 4;
+    d.bwd = d.fwd + 64 * d.nf_total;
+    d.stride = d.bwd + 64 * d.nb_total;
+    return d;
+}
+inline size_t gmmvi_packed_stride_dp(int dp) { return (size_t)gmmvi_pack_dims(dp).stride; }
+
+// The L^-1 fragments of one block from a dense row-major inverse Linv[i * ld + j] (rows / columns >= D read as zero), written
+// by the calling threads tid, tid + nthreads, ...
+__device__ __forceinline__ void gmmvi_write_inverse_fragments(float* __restrict__ out, int dp, int D, const float* Linv, int ld,
+                                                              int tid, int nthreads) {
+    const PackDims pd = gmmvi_pack_dims(dp);
+    for (int e = tid; e < 64 * (pd.nf_total + pd.nb_total); e += nthreads) {
+        const int f = e >> 6, l = e & 63;
+        int mt = 0, s = 0, row, col;
+        if (f < pd.nf_total) {
+            int rem = f;
+            for (;; ++mt) { const int n = 4 * mt + 4 < pd.ks ? 4 * mt + 4 : pd.ks; if (rem < n) break; rem -= n; }
+            s = rem;
+            row = 16 * mt + (l & 15); col = 4 * s + (l >> 4);
+        } else {
+            int rem = f - pd.nf_total;
+            for (;; ++mt) { const int n = pd.ks - 4 * mt; if (rem < n) break; rem -= n; }
+            s = 4 * mt + rem;
+            row = 4 * s + (l >> 4); col = 16 * mt + (l & 15);
+        }
+        out[pd.fwd + e] = (row < D && col <= row) ? Linv[row * ld + col] : 0.f;
+    }
+}

@@ -45,25 +45,33 @@ __global__ __launch_bounds__(64) void pack_kernel(int family, float nu, int K, i
         else
             c = lgammaf(0.5f * (nu + D)) - lgammaf(0.5f * nu) - 0.5f * D * logf(nu * 3.14159265358979f) - s;
         out[P::CONST] = c;
-        for (int i = P::CONST + 1; i < P::STRIDE; ++i) out[i] = 0.f;
+        for (int i = P::CONST + 1; i < P::FWD; ++i) out[i] = 0.f;
     }
-    if (inv_chols != nullptr && t < D) {
-        // column t of L^-1 by forward substitution: L x = e_t
-        float* inv = inv_chols + (size_t)k * D * D;
+    // L^-1: lane t solves L x = e_t (column t) by forward substitution; the dense inverse is staged in LDS, from where the
+    // matrix-core fragments of the block (common.h) and the optional explicit inverse (sample_db.py:121) are written
+    __shared__ float Li[DP * DP];
+    if (P::FRAGS || inv_chols != nullptr) {
         float x[DP];
 #pragma unroll
         for (int i = 0; i < DP; ++i) {
-            float s = (i == t) ? 1.f : 0.f;
-            if (i < D) {
-                for (int j = 0; j < i; ++j) s -= L[i * D + j] * x[j];
-                x[i] = s / L[i * D + i];
+            float sacc = (i == t) ? 1.f : 0.f;
+            if (i < D && t < D) {
+                for (int j = 0; j < i; ++j) sacc -= L[i * D + j] * x[j];
+                x[i] = sacc / L[i * D + i];
             } else {
                 x[i] = 0.f;
             }
         }
+        if (t < DP) {
 #pragma unroll
-        for (int i = 0; i < DP; ++i)
-            if (i < D) inv[i * D + t] = (i >= t) ? x[i] : 0.f;
+            for (int i = 0; i < DP; ++i) Li[i * DP + t] = (i >= t) ? x[i] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (P::FRAGS) gmmvi_write_inverse_fragments(out, DP, D, Li, DP, t, 64);
+    if (inv_chols != nullptr) {
+        float* inv = inv_chols + (size_t)k * D * D;
+        for (int e = t; e < D * D; e += 64) inv[e] = Li[(e / D) * DP + (e % D)];
     }
 }
 
@@ -259,11 +267,334 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// mixture_eval on the matrix cores
+// ---------------------------------------------------------------------------------------------------------------
+// z = L^-1 (x - mu) and y = L^-T z as dense contractions with the explicit inverse (operand fragments in the packed block,
+// common.h): v_mfma_f32_16x16x4_f32 with A = a 16-row tile of L^-1 (coalesced 256-byte fragment loads, nothing on the scalar
+// path), B = 16 samples x 4 dimensions of (x - mu).  A wave owns NTS sub-tiles of 16 samples (x fragments in registers for
+// the whole launch) and walks a strided subset of the components; lane (g = l >> 4, n = l & 15) holds B[k = g][sample n] and
+// receives rows 4 g + r of every 16-row tile of the result for sample n.  |z|^2 is completed across the four lane groups by
+// two cross-lane adds; for the gradient z goes through a wave-private LDS image ([sample][dimension], permuted so that a
+// lane's k-steps are contiguous) to become the B operand of the transposed contraction.  Structural zeros of the triangle
+// are skipped per 16 x 4 fragment.  The log-sum-exp over the components, the K split over blockIdx.y and the merge of the
+// workgroup's waves are those of the scalar-fed kernel.
+typedef float me_f32x4 __attribute__((ext_vector_type(4)));
+
+#define ME_WAVE_LDS_SYNC()                                     \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_wave_barrier();                       \
+    } while (0)
+
+template <int DP, int FAMILY, bool GRAD, int NTS>
+__global__ __launch_bounds__(512) void mixture_eval_mfma_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
+                                                                const float* __restrict__ logw, const float* __restrict__ X,
+                                                                int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
+                                                                float* __restrict__ grad_out, const float* __restrict__ logw2,
+                                                                float* __restrict__ lp2_out) {
+    using PK = Pack<DP>;
+    constexpr int MT = PK::MT, KS = PK::KS;
+    constexpr int TS = 16 * NTS;                       // samples per workgroup tile
+    constexpr int KSP = ((KS + 3) / 4) * 4;            // k-steps per lane in the z image, padded to 16-byte reads
+    constexpr int ZW = 4 * KSP + 4;                    // row stride of the z image
+    extern __shared__ __align__(16) float sm[];
+    const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
+    const int k_lo = blockIdx.y * kchunk;
+    const int K = min(K_total, k_lo + kchunk);
+    if (gridDim.y > 1) {
+        if (lp_out) lp_out += (size_t)blockIdx.y * N;
+        if (lp2_out) lp2_out += (size_t)blockIdx.y * N;
+        if (GRAD && grad_out) grad_out += (size_t)blockIdx.y * N * D;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int g = lane >> 4, n16 = lane & 15;
+    const int n0 = blockIdx.x * TS;
+    const int n_here = min(TS, N - n0);
+    // LDS: [nwaves][NTS][16][ZW] wave-private z images (gradient only), then the staging / merge area
+    float* Zw = sm + (size_t)wave * (GRAD ? NTS * 16 * ZW : 0);
+    float* sm_merge = sm + (size_t)nwaves * (GRAD ? NTS * 16 * ZW : 0);
+
+    // ---- x tile: coalesced load staged through LDS; lane (g, n) keeps x[n][4 s + g] of its NTS sub-tiles -----------------
+    const int ldx = D | 1;
+    for (int e = threadIdx.x; e < n_here * D; e += blockDim.x) sm_merge[(e / D) * ldx + (e % D)] = X[(size_t)n0 * D + e];
+    __syncthreads();
+    float xb[NTS][KS];
+#pragma unroll
+    for (int t = 0; t < NTS; ++t)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            xb[t][s] = (16 * t + n16 < n_here && 4 * s + g < D) ? sm_merge[(16 * t + n16) * ldx + 4 * s + g] : 0.f;
+    __syncthreads();
+
+    float m[NTS], sv[NTS], m2[NTS], s2[NTS];
+#pragma unroll
+    for (int t = 0; t < NTS; ++t) { m[t] = -3.0e38f; sv[t] = 0.f; m2[t] = -3.0e38f; s2[t] = 0.f; }
+    const bool dual = logw2 != nullptr;
+    me_f32x4 acc[GRAD ? NTS : 1][GRAD ? MT : 1];
+    if (GRAD) {
+#pragma unroll
+        for (int t = 0; t < NTS; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][mt][r] = 0.f;
+    }
+    const float nud = nu + (float)D;
+
+    for (int k = k_lo + wave; k < K; k += nwaves) {
+        const float* __restrict__ Pk = packed + (size_t)k * PK::STRIDE;
+        float af[PK::NF], ab[GRAD ? PK::NB : 1], mus[KS];
+#pragma unroll
+        for (int f = 0; f < PK::NF; ++f) af[f] = Pk[PK::FWD + 64 * f + lane];
+        if (GRAD) {
+#pragma unroll
+            for (int f = 0; f < PK::NB; ++f) ab[f] = Pk[PK::BWD + 64 * f + lane];
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) mus[s] = (4 * s + g < DP) ? Pk[PK::MU + 4 * s + g] : 0.f;
+        const float cst = Pk[PK::CONST];
+        const float lw = logw[k];
+        const float lw2 = dual ? logw2[k] : 0.f;
+        me_f32x4 z[NTS][MT];
+        float ldv[NTS], ev[NTS], scv[NTS], cfv[NTS];
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) {
+            float b[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) b[s] = xb[t][s] - mus[s];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[t][mt][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < PK::nf(mt); ++s)
+                    z[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[PK::fwd_index(mt, s)], b[s], z[t][mt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) {
+            float q = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q = fmaf(z[t][mt][r], z[t][mt][r], q);
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            float ld, coef;
+            if (FAMILY == GMMVI_GAUSS) {
+                ld = fmaf(-0.5f, q, cst);
+                coef = -1.f;
+            } else {
+                ld = cst - 0.5f * nud * log1pf(q / nu);
+                coef = -nud / (nu + q);
+            }
+            ldv[t] = ld;
+            const float a = ld + lw;
+            const float mn = fmaxf(m[t], a);
+            const float sc = __expf(m[t] - mn);
+            const float e = __expf(a - mn);
+            sv[t] = fmaf(sv[t], sc, e);
+            m[t] = mn;
+            ev[t] = e; scv[t] = sc; cfv[t] = coef;
+            if (dual) {
+                const float a2 = ld + lw2;
+                const float mn2 = fmaxf(m2[t], a2);
+                s2[t] = fmaf(s2[t], __expf(m2[t] - mn2), __expf(a2 - mn2));
+                m2[t] = mn2;
+            }
+        }
+        if (ld_out != nullptr) {
+            // lane group g stores sub-tile g: one instruction writes 16 NTS consecutive floats of row k
+            float v = ldv[0];
+#pragma unroll
+            for (int t = 1; t < NTS; ++t) v = (g == t) ? ldv[t] : v;
+            if (g < NTS && 16 * g + n16 < n_here) ld_out[(size_t)k * N + n0 + 16 * g + n16] = v;
+        }
+        if (GRAD) {
+            // z -> wave-private image Zs[t][n][p(i)], p(i) = (i & 3) KSP + (i >> 2): lane (g, n) holds i = 16 mt + 4 g + r
+#pragma unroll
+            for (int t = 0; t < NTS; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * mt + g < KSP) Zw[(t * 16 + n16) * ZW + r * KSP + 4 * mt + g] = z[t][mt][r];
+            ME_WAVE_LDS_SYNC();
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) {
+                float bz[KSP];
+#pragma unroll
+                for (int q4 = 0; q4 < KSP / 4; ++q4) {
+                    const me_f32x4 v4 = *reinterpret_cast<const me_f32x4*>(Zw + (t * 16 + n16) * ZW + g * KSP + 4 * q4);
+                    bz[4 * q4] = v4[0]; bz[4 * q4 + 1] = v4[1]; bz[4 * q4 + 2] = v4[2]; bz[4 * q4 + 3] = v4[3];
+                }
+                const float ec = ev[t] * cfv[t];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    me_f32x4 y;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = 0.f;
+#pragma unroll
+                    for (int s = 4 * mt; s < KS; ++s)
+                        y = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[PK::bwd_index(mt, s)], bz[s], y, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][mt][r] = fmaf(acc[t][mt][r], scv[t], ec * y[r]);
+                }
+            }
+            ME_WAVE_LDS_SYNC();
+        }
+    }
+    if (lp_out == nullptr && !GRAD) return;
+
+    // merge the W waves' partials: sm_m[w][sample], sm_s[w][sample], sm_acc[w][i][sample]  (sample = 16 t + n)
+    float* sm_m = sm_merge;
+    float* sm_s = sm_merge + nwaves * TS;
+    float* sm_acc = sm_merge + 2 * nwaves * TS;
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) { sm_m[wave * TS + 16 * t + n16] = m[t]; sm_s[wave * TS + 16 * t + n16] = sv[t]; }
+    }
+    if (GRAD) {
+#pragma unroll
+        for (int t = 0; t < NTS; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * mt + 4 * g + r;
+                    if (i < DP) sm_acc[(wave * DP + i) * TS + 16 * t + n16] = acc[t][mt][r];
+                }
+    }
+    __syncthreads();
+    // sample si = threadIdx.x (one thread per sample for the log values)
+    float M = -3.0e38f, S = 1.f;
+    const int si = threadIdx.x;
+    if (si < TS) {
+        for (int w = 0; w < nwaves; ++w) M = fmaxf(M, sm_m[w * TS + si]);
+        S = 0.f;
+        for (int w = 0; w < nwaves; ++w) S += sm_s[w * TS + si] * __expf(sm_m[w * TS + si] - M);
+        if (si < n_here && lp_out != nullptr) lp_out[n0 + si] = M + __logf(S);
+    }
+    if (dual) {
+        float* sm_m2 = sm_merge + (size_t)nwaves * TS * ((GRAD ? DP : 0) + 2) + (GRAD ? TS * ldx : 0);
+        float* sm_s2 = sm_m2 + nwaves * TS;
+        if (g == 0) {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) { sm_m2[wave * TS + 16 * t + n16] = m2[t]; sm_s2[wave * TS + 16 * t + n16] = s2[t]; }
+        }
+        __syncthreads();
+        if (si < n_here && lp2_out != nullptr) {
+            float M2 = -3.0e38f;
+            for (int w = 0; w < nwaves; ++w) M2 = fmaxf(M2, sm_m2[w * TS + si]);
+            float S2 = 0.f;
+            for (int w = 0; w < nwaves; ++w) S2 += sm_s2[w * TS + si] * __expf(sm_m2[w * TS + si] - M2);
+            lp2_out[n0 + si] = M2 + __logf(S2);
+        }
+    }
+    if (GRAD && grad_out != nullptr) {
+        // thread (dimension i, sample si2) pairs spread over the workgroup; results go to a [TS][ldx] tile and leave coalesced
+        float* outt = sm_acc + (size_t)nwaves * DP * TS;
+        for (int e = threadIdx.x; e < D * TS; e += blockDim.x) {
+            const int i = e / TS, s_i = e - i * TS;
+            float Ms = -3.0e38f;
+            for (int w = 0; w < nwaves; ++w) Ms = fmaxf(Ms, sm_m[w * TS + s_i]);
+            float Ss = 0.f, gsum = 0.f;
+            for (int w = 0; w < nwaves; ++w) {
+                const float f = __expf(sm_m[w * TS + s_i] - Ms);
+                Ss = fmaf(sm_s[w * TS + s_i], f, Ss);
+                gsum = fmaf(sm_acc[(w * DP + i) * TS + s_i], f, gsum);
+            }
+            outt[s_i * ldx + i] = gsum / Ss;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n_here * D; e += blockDim.x)
+            grad_out[(size_t)n0 * D + e] = outt[(e / D) * ldx + (e % D)];
+    }
+}
+
+template <int DP, int NTS>
+static int launch_mixture_eval_mfma(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
+                                    const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
+                                    const float* logw2, float* lp2) {
+    using PK = Pack<DP>;
+    constexpr int TS = 16 * NTS, KSP = ((PK::KS + 3) / 4) * 4, ZW = 4 * KSP + 4;
+    const bool want_grad = grad != nullptr;
+    const bool want_merge = want_grad || lp != nullptr;
+    static const int env_nw = getenv("GMMVI_ME_NW") ? atoi(getenv("GMMVI_ME_NW")) : 0;
+    static const int env_ky = getenv("GMMVI_ME_KY") ? atoi(getenv("GMMVI_ME_KY")) : 0;
+    auto lds_floats = [&](int nw) {
+        size_t merge = (size_t)nw * TS * ((want_grad ? DP : 0) + 2) + (want_grad ? TS * (size_t)(D | 1) : 0) +
+                       (logw2 ? (size_t)nw * 2 * TS : 0);
+        size_t stage = TS * (size_t)(D | 1);
+        return (want_grad ? (size_t)nw * NTS * 16 * ZW : 0) + (merge > stage ? merge : stage);
+    };
+    const int tiles = (N + TS - 1) / TS;
+    // geometry as for the scalar-fed kernel: ky chunks of components over blockIdx.y (partials merged by combine_partials) so
+    // that ~2 workgroups of 8 waves per CU are in flight when there are few sample tiles
+    int ky = 1, nw = K < 8 ? K : 8;
+    if (env_ky > 0) ky = env_ky < K ? env_ky : K;
+    else if (K >= 16 && 2L * tiles <= 3L * ctx->num_cus) {
+        ky = (int)((2L * ctx->num_cus + tiles / 2) / tiles);
+        if (ky > K / 8) ky = K / 8;
+        if (ky < 1) ky = 1;
+    }
+    const int kchunk = (K + ky - 1) / ky;
+    ky = (K + kchunk - 1) / kchunk;
+    if (nw > kchunk) nw = kchunk;
+    if (env_nw > 0) nw = env_nw < kchunk ? env_nw : kchunk;
+    if (nw > 8) nw = 8;
+    while (nw > 1 && lds_floats(nw) * 4 > 64 * 1024) --nw;
+    size_t shmem = lds_floats(nw) * 4;
+    float* lp_k = lp;
+    float* grad_k = grad;
+    float* lp2_k = lp2;
+    if (ky > 1 && want_merge) {
+        size_t need = ((size_t)ky * N * (logw2 ? 2 : 1) + (want_grad ? (size_t)ky * N * D : 0)) * sizeof(float);
+        int rc = gmmvi_ws_reserve(ctx, need);
+        if (rc != GMMVI_OK) return rc;
+        lp_k = (float*)ctx->ws;
+        lp2_k = logw2 ? lp_k + (size_t)ky * N : nullptr;
+        grad_k = want_grad ? lp_k + (size_t)ky * N * (logw2 ? 2 : 1) : nullptr;
+    }
+    dim3 grid(tiles, ky), block(nw * 64);
+    {
+        GMMVI_PROF_UNITS(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval", (double)N * K);
+#define GMMVI_LAUNCH_MM(FAM, G)                                                                                     \
+    do {                                                                                                            \
+        if (shmem > 64 * 1024)                                                                                      \
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_mfma_kernel<DP, FAM, G, NTS>,        \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
+        hipLaunchKernelGGL((mixture_eval_mfma_kernel<DP, FAM, G, NTS>), grid, block, shmem, ctx->stream, nu, K, D,  \
+                           packed, logw, X, N, ld, lp_k, grad_k, logw2, lp2_k);                                      \
+    } while (0)
+        if (family == GMMVI_GAUSS) {
+            if (want_grad) GMMVI_LAUNCH_MM(GMMVI_GAUSS, true); else GMMVI_LAUNCH_MM(GMMVI_GAUSS, false);
+        } else {
+            if (want_grad) GMMVI_LAUNCH_MM(GMMVI_STUDENT_T, true); else GMMVI_LAUNCH_MM(GMMVI_STUDENT_T, false);
+        }
+#undef GMMVI_LAUNCH_MM
+    }
+    GMMVI_LAUNCH_CHECK(ctx);
+    if (ky > 1 && want_merge) {
+        GMMVI_PROF(ctx, "mixture_combine");
+        int rc = gmmvi_combine_partials_internal(ctx, ky, N, D, lp_k, grad_k, lp, grad, lp2_k, lp2);
+        if (rc != GMMVI_OK) return rc;
+    }
+    return GMMVI_OK;
+}
+
 template <int DP>
 static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
                                const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
                                const float* logw2 = nullptr, float* lp2 = nullptr) {
     using PK = Pack<DP>;
+    if constexpr (PK::FRAGS) {
+        if constexpr (DP >= 40) return launch_mixture_eval_mfma<DP, 2>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
+        else return launch_mixture_eval_mfma<DP, 4>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
+    }
     const bool want_grad = grad != nullptr;
     const bool want_merge = want_grad || lp != nullptr;
     static const int env_feed = getenv("GMMVI_ME_FEED") ? atoi(getenv("GMMVI_ME_FEED")) : 0;
@@ -310,7 +641,7 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     }
     dim3 grid(tiles, ky), block(nw * 64);
     {
-        GMMVI_PROF(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval");
+        GMMVI_PROF_UNITS(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval", (double)N * K);
 #define GMMVI_LAUNCH_ME(FAM, G, F)                                                                                  \
     do {                                                                                                            \
         if (shmem > 64 * 1024)                                                                                      \

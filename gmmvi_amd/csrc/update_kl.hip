@@ -515,7 +515,8 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
         const float* Lf = success ? s.M : s.L;                      // final factor (lower triangle), stride ld
         const float mu_f = (t < D) ? (success ? mug[t] : s.mu[t]) : 0.f;
         const int T = DPk * (DPk - 1) / 2;
-        const int stride = ((2 * DPk + 2 * T + 1 + 3) / 4) * 4;
+        const PackDims pd = gmmvi_pack_dims(DPk);
+        const int stride = pd.stride;
         float* out = packed_out + (size_t)k * stride;
         for (int i = t; i < DPk; i += 64) {
             out[i] = (i < D) ? mu_f : 0.f;
@@ -532,8 +533,33 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
         const float lsum = wsum((t < D) ? __logf(Lf[t * ld + t]) : 0.f);
         if (t == 0) {
             out[2 * DPk + 2 * T] = -lsum - 0.5f * D * 1.8378770664093453f;
-            for (int i = 2 * DPk + 2 * T + 1; i < stride; ++i) out[i] = 0.f;
+            for (int i = 2 * DPk + 2 * T + 1; i < pd.fwd; ++i) out[i] = 0.f;
         }
+        // L^-1 of the final factor for the matrix-core fragments of the block: lane t solves L x = e_t (column t) from the
+        // LDS image of L (every lane reads the same element: broadcast), the dense inverse goes through Mc
+        __syncthreads();
+        if (pd.nf_total > 0 && t < D) {
+            if constexpr (DC > 0) {
+                float x[DC > 0 ? DC : 1];
+#pragma unroll
+                for (int i = 0; i < DC; ++i) {
+                    float a = (i == t) ? 1.f : 0.f;
+#pragma unroll
+                    for (int j = 0; j < i; ++j) a = fmaf(-Lf[i * ld + j], x[j], a);       // x_j = 0 for j < t
+                    x[i] = (i >= t) ? a / Lf[i * ld + i] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < DC; ++i) s.Mc[i * ld + t] = x[i];
+            } else {
+                for (int i = 0; i < D; ++i) {
+                    float a = (i == t) ? 1.f : 0.f;
+                    for (int j = t; j < i; ++j) a = fmaf(-Lf[i * ld + j], s.Mc[j * ld + t], a);
+                    s.Mc[i * ld + t] = (i >= t) ? a / Lf[i * ld + i] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (pd.nf_total > 0) gmmvi_write_inverse_fragments(out, DPk, D, s.Mc, ld, t, 64);
     }
     if (t == 0) {
         last_eta[k] = success ? eta_star : -1.f;                                           // :504,:511,:524
