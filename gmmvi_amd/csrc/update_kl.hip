@@ -19,6 +19,19 @@
 
 namespace {
 
+// hand-over through LDS inside the one wavefront that runs the chain phases: with several wavefronts in the workgroup only
+// that wave's LDS queue has to drain (the others must not be waited for); a single-wave workgroup keeps the plain barrier
+// (measured at D = 20: 37.9 us against 42.3 us with the wave-local form)
+#define UKL_WSYNC()                                                \
+    do {                                                           \
+        if constexpr (NW == 1) {                                   \
+            __syncthreads();                                       \
+        } else {                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+            __builtin_amdgcn_wave_barrier();                       \
+        }                                                          \
+    } while (0)
+
 __device__ __forceinline__ float wsum(float v) { return gmmvi_wave_sum(v); }
 
 struct Ws {
@@ -85,8 +98,8 @@ __device__ __forceinline__ float kl_tridiag(const Ws& s, float eta) {
 }
 
 // DC > 0: dimension known at compile time (inner loops unrolled, LDS reads issued in batches); DC == 0: generic.
-template <int DC>
-__global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __restrict__ means, float* __restrict__ chols,
+template <int DC, int NW>
+__global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float* __restrict__ means, float* __restrict__ chols,
                                                             const float* __restrict__ H_neg, const float* __restrict__ g_neg,
                                                             const float* __restrict__ stepsizes, float temperature,
                                                             float l2_init, float* __restrict__ last_eta, float* __restrict__ l2,
@@ -98,12 +111,13 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
     Ws s;
     carve(s, sm, D);
     const int k = blockIdx.x, t = threadIdx.x, ld = D + 1;
+    constexpr int NTH = 64 * NW;
     float* Lg = chols + (size_t)k * D * D;
     float* mug = means + (size_t)k * D;
     const float* Rg = H_neg + (size_t)k * D * D;
 
     // ---- load: L, R_sym (lower triangle mirrored, as tf.linalg.cholesky reads only the lower part) into M -----------
-    for (int e = t; e < D * D; e += 64) {
+    for (int e = t; e < D * D; e += NTH) {
         const int i = e / D, j = e % D;
         s.L[i * ld + j] = (j <= i) ? Lg[e] : 0.f;
         s.M[i * ld + j] = (j <= i) ? Rg[e] : Rg[j * D + i];
@@ -117,7 +131,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
     }
     __syncthreads();
     // ---- T1 = R_sym L (into Mc), M = L^T T1, w = L^T g~ : the D^2 outputs are spread over all 64 lanes ---------------------
-    for (int o = t; o < D * D; o += 64) {
+    for (int o = t; o < D * D; o += NTH) {
         const int i = o / D, j = o % D;
         float a = 0.f;
 #pragma unroll
@@ -125,7 +139,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
         s.Mc[i * ld + j] = a;
     }
     __syncthreads();
-    for (int o = t; o < D * D; o += 64) {
+    for (int o = t; o < D * D; o += NTH) {
         const int i = o / D, j = o % D;
         float a = 0.f;
 #pragma unroll
@@ -140,7 +154,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
         s.wt[t] = a;
     }
     __syncthreads();
-    for (int o = t; o < D * D; o += 64) {          // exact symmetry for the reflectors; keep a copy for the final step
+    for (int o = t; o < D * D; o += NTH) {          // exact symmetry for the reflectors; keep a copy for the final step
         const int i = o / D, j = o % D;
         if (j < i) {
             const float m = 0.5f * (s.M[i * ld + j] + s.M[j * ld + i]);
@@ -152,6 +166,12 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
     }
     __syncthreads();
 
+    // ---- from here to the accepted factor one wavefront works alone (lane = row / tree node; the phases are chains of D
+    // dependent steps): its LDS hand-overs only need the wave's own queue drained, the other waves wait at the barrier below
+    bool success_w = false;
+    float eta_w = 0.f, kl_w = -1.f;
+    int probes_w = 0;
+    if (NW == 1 || __builtin_amdgcn_readfirstlane(t >> 6) == 0) {          // wave-uniform: the region keeps its scalar branches
     // ---- Householder tridiagonalisation of M, reflectors applied to wt.  Every lane forms the column norm and the two dot
     // products itself from broadcast LDS vectors: no cross-lane reduction chains on the critical path.  With a static D the
     // lane keeps its row of M (and a replica of wt) in registers, so a step costs ~20 LDS operations instead of ~200 --
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
 #pragma unroll
             for (int j = 0; j < DR; ++j) mc = (j == c) ? mrow[j] : mc;
             if (t < DR) xv[t] = mc;
-            __syncthreads();
+            UKL_WSYNC();
             float x[4 * D4];
 #pragma unroll
             for (int q4 = 0; q4 < D4; ++q4) {
@@ -188,7 +208,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             }
             if (!(tail > 0.f)) {                    // column already tridiagonal (also covers NaN: handled later)
                 if (t == 0) s.te[c] = x1;
-                __syncthreads();
+                UKL_WSYNC();
                 continue;                           // uniform: every lane computed the same tail
             }
             const float nrm = __builtin_amdgcn_sqrtf(tail + x1 * x1);       // v_sqrt_f32 / v_rcp_f32 (1 ulp): the reflector only
@@ -205,7 +225,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             p = act ? p * beta : 0.f;
             vv = act ? vv : 0.f;
             if (t < DR) pv[t] = p;
-            __syncthreads();
+            UKL_WSYNC();
             float pj[4 * D4];
 #pragma unroll
             for (int q4 = 0; q4 < D4; ++q4) {
@@ -225,7 +245,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             }
             if (t == 0) s.te[c] = alpha;
         }
-        __syncthreads();
+        UKL_WSYNC();
         if (t < DR) {
             float dd = 0.f, sub = 0.f, wme = 0.f;
 #pragma unroll
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             s.wt[t] = wme;
             if (t == DR - 1 && DR >= 2) s.te[DR - 2] = sub;
         }
-        __syncthreads();
+        UKL_WSYNC();
     } else {
     for (int c = 0; c + 2 < D; ++c) {
             const float x1 = s.M[(c + 1) * ld + c];
@@ -255,7 +275,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             const bool act = (t > c) && (t < D);
             const float vv = act ? (t == c + 1 ? x1 - alpha : s.M[t * ld + c]) : 0.f;
             if (t < D) s.v[t] = vv;
-            __syncthreads();
+            UKL_WSYNC();
             float p = 0.f;
             if (act) {
 #pragma unroll
@@ -263,7 +283,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
                 p *= beta;
             }
             if (t < D) s.q[t] = p;                                                             // p_j = 0 for j <= c
-            __syncthreads();
+            UKL_WSYNC();
             float kk = 0.f, wdot = 0.f;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
@@ -274,7 +294,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             kk *= 0.5f * beta;
             wdot *= beta;
             const float qq = p - kk * vv;
-            __syncthreads();                            // everyone has read wt / q before they change
+            UKL_WSYNC();                            // everyone has read wt / q before they change
             if (act) {
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
@@ -284,11 +304,11 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
                 s.wt[t] -= wdot * vv;
             }
             if (t == 0) s.te[c] = alpha;
-            __syncthreads();
+            UKL_WSYNC();
         }
         if (t < D) s.td[t] = s.M[t * ld + t];
         if (t == 0 && D >= 2) s.te[D - 2] = s.M[(D - 1) * ld + (D - 2)];
-        __syncthreads();
+        UKL_WSYNC();
     }
 
     // ---- speculative bisection: 63 tree nodes (6 levels) per round, one lane per node ------------------------------------
@@ -361,7 +381,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
                 const float d = sqrtf(p);
                 const float u = (t == j) ? d : (t < j ? bj / d : 0.f);
                 if (t < DR) { uv[t] = u; Us[t * LU + j] = u; }
-                __syncthreads();
+                UKL_WSYNC();
                 float uc[LU];
 #pragma unroll
                 for (int q4 = 0; q4 < LU / 4; ++q4) {
@@ -370,7 +390,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
                 }
 #pragma unroll
                 for (int c = 0; c < DR; ++c) xr[c] = (c < j && c >= t) ? fmaf(-u, uc[c], xr[c]) : xr[c];
-                __syncthreads();
+                UKL_WSYNC();
             }
         }
         if (success) {
@@ -404,7 +424,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             new_mu = s.mu[t < DR ? t : 0] - acc * inv;
             bad |= !(new_mu == new_mu);
             success = (__any(bad && t < DR) == 0);                                         // :493 is_nan(new_chol)
-            __syncthreads();                                       // all reads of the U image are done: M becomes L'
+            UKL_WSYNC();                                       // all reads of the U image are done: M becomes L'
             if (success && t < DR) {
 #pragma unroll
                 for (int c = 0; c < DR; ++c) {
@@ -421,7 +441,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             const int i = o / D, j = o % D;
             if (j >= i) s.M[i * ld + j] = (j == i ? 1.f : 0.f) + s.Mc[i * ld + j] * inv;
         }
-        __syncthreads();
+        UKL_WSYNC();
         for (int j = D - 1; j >= 0 && success; --j) {
             float a = 0.f;
             if (t <= j) {
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             const float d = sqrtf(p);
             if (t == j) s.M[t * ld + j] = d;                  // column j only: nobody reads it in this step
             else if (t < j) s.M[t * ld + j] = a / d;
-            __syncthreads();
+            UKL_WSYNC();
         }
     }
     if (success) {
@@ -459,7 +479,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
                 s.Mc[i * ld + t] = (i <= t) ? a / s.M[i * ld + i] : 0.f;
             }
         }
-        __syncthreads();
+        UKL_WSYNC();
         // z = Uinv w ; y = Uinv^T z = B^-1 w
         if (t < D) {
             float a = 0.f;
@@ -467,14 +487,14 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             for (int c = 0; c < D; ++c) a = fmaf(s.Mc[t * ld + c], s.w[c], a);            // Uinv[t][c] = 0 for c < t
             s.z[t] = a;
         }
-        __syncthreads();
+        UKL_WSYNC();
         if (t < D) {
             float a = 0.f;
 #pragma unroll
             for (int c = 0; c < D; ++c) a = fmaf(s.Mc[c * ld + t], s.z[c], a);            // Uinv[c][t] = 0 for c > t
             s.y[t] = a;
         }
-        __syncthreads();
+        UKL_WSYNC();
         // new mean mu' = mu - L y / eta* ; new factor L' = L Uinv^T, its D(D+1)/2 entries spread over the 64 lanes,
         // written to M (U no longer needed)
         float new_mu = 0.f;
@@ -486,7 +506,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             new_mu = s.mu[t] - a * inv;
             bad = !(new_mu == new_mu);
         }
-        __syncthreads();
+        UKL_WSYNC();
         for (int o = t; o < D * D; o += 64) {
             const int i = o / D, j = o % D;
             if (j <= i) {
@@ -499,7 +519,7 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             }
         }
         success = (__any(bad) == 0);                                                       // :493 is_nan(new_chol)
-        __syncthreads();
+        UKL_WSYNC();
         if (success) {
             for (int e = t; e < D * D; e += 64) {
                 const int i = e / D, j = e % D;
@@ -509,6 +529,12 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
         }
     }
     }
+    success_w = success; eta_w = eta_star; kl_w = kl_val; probes_w = probes;
+    }
+    __shared__ int sh_success;
+    if (t == 0) sh_success = success_w ? 1 : 0;
+    __syncthreads();
+    const bool success = sh_success != 0;
     if (packed_out != nullptr) {
         // packed parameter block of the (new or kept) component for the density kernels: layout of common.h Pack<DP>
         __syncthreads();
@@ -518,11 +544,11 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
         const PackDims pd = gmmvi_pack_dims(DPk);
         const int stride = pd.stride;
         float* out = packed_out + (size_t)k * stride;
-        for (int i = t; i < DPk; i += 64) {
+        for (int i = t; i < DPk; i += NTH) {
             out[i] = (i < D) ? mu_f : 0.f;
             out[DPk + i] = (i < D) ? 1.f / Lf[i * ld + i] : 1.f;
         }
-        for (int e = t; e < DPk * DPk; e += 64) {
+        for (int e = t; e < DPk * DPk; e += NTH) {
             const int i = e / DPk, j = e % DPk;
             if (j < i) {
                 const float v = (i < D) ? Lf[i * ld + j] : 0.f;
@@ -559,12 +585,12 @@ __global__ __launch_bounds__(64) void update_kl_fast_kernel(int Drt, float* __re
             }
         }
         __syncthreads();
-        if (pd.nf_total > 0) gmmvi_write_inverse_fragments(out, DPk, D, s.Mc, ld, t, 64);
+        if (pd.nf_total > 0) gmmvi_write_inverse_fragments(out, DPk, D, s.Mc, ld, t, NTH);
     }
     if (t == 0) {
-        last_eta[k] = success ? eta_star : -1.f;                                           // :504,:511,:524
-        if (kl_out) kl_out[k] = success ? kl_val : -1.f;
-        if (nprobes_out) nprobes_out[k] = probes;
+        last_eta[k] = success ? eta_w : -1.f;                                              // :504,:511,:524
+        if (kl_out) kl_out[k] = success ? kl_w : -1.f;
+        if (nprobes_out) nprobes_out[k] = probes_w;
         const float old = l2[k];
         l2[k] = success ? fmaxf(0.5f * old, l2_init) : fminf(1e-6f, 10.f * old);           // :520-523 (min on failure)
         num_updates[k] += 1.f;                                                             // :519
@@ -588,23 +614,28 @@ extern "C" int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* m
                                        n_probes_out_dev, packed_out_dev);
     size_t shmem = lds_bytes(D);
     GMMVI_PROF(ctx, "update_kl");
-#define GMMVI_UKL(DCV)                                                                                             \
+#define GMMVI_UKL(DCV, NWV)                                                                                        \
     do {                                                                                                           \
         if (shmem > 64 * 1024)                                                                                     \
-            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)update_kl_fast_kernel<DCV>,                      \
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)update_kl_fast_kernel<DCV, NWV>,                 \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));     \
-        hipLaunchKernelGGL((update_kl_fast_kernel<DCV>), dim3(K), dim3(64), shmem, ctx->stream, D, means_dev,      \
-                           chols_dev, H_neg_dev, g_neg_dev, stepsizes_dev, temperature, l2_init, last_eta_dev,     \
-                           l2_dev, num_received_updates_dev, success_out_dev, kl_out_dev, n_probes_out_dev,        \
-                           packed_out_dev, gmmvi_padded_dim(D));                                                   \
+        hipLaunchKernelGGL((update_kl_fast_kernel<DCV, NWV>), dim3(K), dim3(64 * NWV), shmem, ctx->stream, D,      \
+                           means_dev, chols_dev, H_neg_dev, g_neg_dev, stepsizes_dev, temperature, l2_init,        \
+                           last_eta_dev, l2_dev, num_received_updates_dev, success_out_dev, kl_out_dev,            \
+                           n_probes_out_dev, packed_out_dev, gmmvi_padded_dim(D));                                 \
     } while (0)
-    switch (D) {                       // dimensions of the BASELINE configurations get unrolled instances
-        case 4: GMMVI_UKL(4); break;
-        case 10: GMMVI_UKL(10); break;
-        case 20: GMMVI_UKL(20); break;
-        case 32: GMMVI_UKL(32); break;
-        case 50: GMMVI_UKL(50); break;
-        default: GMMVI_UKL(0); break;
+    // dimensions of the BASELINE configurations get unrolled instances; from D = 32 four wavefronts share the D^3 products,
+    // the load / pack phases and the fragment writes (the chains in between stay on one)
+    switch (D) {
+        case 4: GMMVI_UKL(4, 1); break;
+        case 10: GMMVI_UKL(10, 1); break;
+        case 20: GMMVI_UKL(20, 1); break;
+        case 32: GMMVI_UKL(32, 4); break;
+        case 40: GMMVI_UKL(40, 4); break;
+        case 50: GMMVI_UKL(50, 4); break;
+        default:
+            if (D > 24) GMMVI_UKL(0, 4); else GMMVI_UKL(0, 1);
+            break;
     }
 #undef GMMVI_UKL
     GMMVI_LAUNCH_CHECK(ctx);
