@@ -47,14 +47,13 @@ WORKLOADS = {
 
 
 def kernel_flops(name, n, k, d):
-    """Algorithmic FLOPs of one launch (DESIGN.md section 'kernels'): pairs P = n*k."""
+    """Algorithmic FLOPs of one launch: SURVEY.md 8(d)'s per-pair figures (pairs P = n*k) -- the work the reference's
+    algorithm needs for that step, whatever route the kernel takes."""
     p = float(n) * k
     return {
         "mixture_eval": p * (d * d + 4 * d),              # forward substitution + square-sum + LSE
         "mixture_eval_grad": p * (2 * d * d + 8 * d),     # + backward substitution + responsibility-weighted gradient
-        # moment form (csrc/stein.hip): rank-1 accumulate of [g;1][x - mu;1]^T (2 (D+1)^2) + centring / weighting (3D); the
-        # per-sample substitution of SURVEY.md 8d's 4D^2 figure is gone (Sigma^-1 is applied once per component afterwards)
-        "stein_partial": p * (2 * (d + 1) * (d + 1) + 3 * d),
+        "stein_partial": p * (4 * d * d + 6 * d),         # SURVEY 8d, a9: y per sample (2D^2) + rank-1 accumulate (2D^2)
         # MORE: lower triangle of the (F+1)x(F+1) Gram matrix of [phi; reward], F = D(D+1)/2 + D + 1 (2 flop per MAC)
         "more_gram": p * ((d * (d + 1) // 2 + d + 2) * (d * (d + 1) // 2 + d + 3) + d * d),
         # blocked path (D > 64): triangular whitening Z = (X - mu) L^-T, gradient sum_k r Z L^-1, Stein sum e [g;1][z;1]^T
@@ -62,6 +61,14 @@ def kernel_flops(name, n, k, d):
         "blocked_grad": p * (d * d + d),
         "blocked_stein_accumulate": p * 2 * (d + 1) * (d + 1),
     }.get(name)
+
+
+def kernel_flops_executed(name, n, k, d):
+    """FLOPs the kernel actually executes where that is LESS than the algorithmic figure (reported beside it, never instead):
+    the Stein estimate in moment form accumulates [g;1][x - mu;1]^T (2 (D+1)^2 + 3D per pair) and applies Sigma^-1 once
+    per component afterwards -- the per-sample substitution is gone."""
+    p = float(n) * k
+    return {"stein_partial": p * (2 * (d + 1) * (d + 1) + 3 * d)}.get(name, kernel_flops(name, n, k, d))
 
 
 def spec(workload, n_gpus, seed=0):
@@ -274,15 +281,24 @@ def main():
                for name, (c, ms, pr) in prof.items()}
     k_local = w["k_total"] // n_gpus
     dominant = max(kernels, key=lambda nme: kernels[nme]["avg_us"] * kernels[nme]["launches_per_step"])
-    roof_name = max((nme for nme in kernels if kernel_flops(nme, 1, 1, 1) is not None),
-                    key=lambda nme: kernels[nme]["avg_us"] * kernels[nme]["launches_per_step"])
-    # kernels that report the pairs they processed (launches of different sizes share a name on the blocked path: the target
-    # has one component, the model 64) are priced on those pairs; the others on the workload's N x K
-    if "pairs_per_launch" in kernels[roof_name]:
-        fl = kernel_flops(roof_name, kernels[roof_name]["pairs_per_launch"], 1, w["d"])
-    else:
-        fl = kernel_flops(roof_name, w["n_total"], k_local, w["d"])
+    # kernels that report the pairs they processed (launches of different sizes share a name: the target has 10 components,
+    # the model 100) are priced on those pairs; the others on the workload's N x K
+    def launch_flops(nme, fn=kernel_flops):
+        if "pairs_per_launch" in kernels[nme]:
+            return fn(nme, kernels[nme]["pairs_per_launch"], 1, w["d"])
+        return fn(nme, w["n_total"], k_local, w["d"])
+    priced = [nme for nme in kernels if kernel_flops(nme, 1, 1, 1) is not None]
+    # roofline kernel: the FLOP-heaviest launch of the step (algorithmic FLOPs); every priced kernel is listed in kernel_roofline
+    roof_name = max(priced, key=lambda nme: launch_flops(nme) * kernels[nme]["launches_per_step"])
+    fl = launch_flops(roof_name)
     achieved = fl / (kernels[roof_name]["avg_us"] * 1e-6) / 1e12
+    kernel_roofline = {}
+    for nme in priced:
+        pk = PEAK_FP64_MFMA_TFLOPS if nme == "more_gram" else PEAK_FP32_TFLOPS
+        t = kernels[nme]["avg_us"] * 1e-6
+        kernel_roofline[nme] = {"avg_us": kernels[nme]["avg_us"], "launches_per_step": kernels[nme]["launches_per_step"],
+                                "flops_alg_per_launch": launch_flops(nme), "frac": launch_flops(nme) / t / 1e12 / pk,
+                                "frac_executed": launch_flops(nme, kernel_flops_executed) / t / 1e12 / pk}
     roof_peak = PEAK_FP64_MFMA_TFLOPS if roof_name == "more_gram" else PEAK_FP32_TFLOPS
     d, n_tot, k_tot = w["d"], w["n_total"], w["k_total"]
     f_alg_iter = float(n_tot) * k_tot * (8 * d * d + 12 * d)                   # SURVEY.md 8d (probes reported apart)
@@ -312,9 +328,13 @@ def main():
         "roofline": {"kernel": roof_name, "bound": "mfma", "achieved": achieved, "peak": roof_peak,
                      "unit": "TFLOP/s", "frac": achieved / roof_peak, "traffic": traffic,
                      "avg_us": kernels[roof_name]["avg_us"], "flops_per_launch": fl,
-                     "note": "fp32 FMA path (vector substitution + f32 MFMA contraction); peak = fp32 vector == f32 "
-                             "MFMA rate. Algorithmic HBM bytes per iteration are tiny (see iter_roofline): the "
-                             "north star's >=50% HBM roofline is unreachable on algorithmic bytes (SURVEY.md 8d)."},
+                     "flops_executed_per_launch": launch_flops(roof_name, kernel_flops_executed),
+                     "note": "achieved = SURVEY.md 8(d) algorithmic FLOPs of the launch / its mean HIP-event duration; peak = "
+                             "fp32 vector == f32 MFMA rate. The Stein kernel (moment form) executes fewer FLOPs than the "
+                             "algorithmic figure (flops_executed_per_launch; kernel_roofline.frac_executed). Algorithmic HBM "
+                             "bytes per iteration are tiny (see iter_roofline): the north star's >=50% HBM roofline is "
+                             "unreachable on algorithmic bytes (SURVEY.md 8d)."},
+        "kernel_roofline": kernel_roofline,
         "iter_roofline": {"flops_alg": f_alg_iter, "bytes_alg": b_alg_iter,
                           "frac_fp32_peak": f_alg_iter / (elapsed / args.steps) / (PEAK_FP32_TFLOPS * 1e12 * n_gpus),
                           "frac_hbm_peak": b_alg_iter / (elapsed / args.steps) / (PEAK_HBM_GBS * 1e9 * n_gpus)},

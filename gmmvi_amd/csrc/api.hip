@@ -7,10 +7,7 @@ std::string g_gmmvi_global_err;
 int gmmvi_ws_reserve(gmmvi_ctx* ctx, size_t nbytes) {
     ++ctx->ws_epoch;
     if (nbytes <= ctx->ws_bytes) return GMMVI_OK;
-    // A grow frees the old block; earlier kernels on the stream may still read it, so drain first.  The whitened samples a
-    // density sweep left in the old block are gone with it (hipMalloc may hand back the same address, so comparing the
-    // pointer is not enough): drop the hand-over.
-    ctx->zc.valid = false;
+    // A grow frees the old block; earlier kernels on the stream may still read it, so drain first.
     GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->ws) GMMVI_HIP_CHECK(ctx, hipFree(ctx->ws));
     ctx->ws = nullptr;
@@ -61,7 +58,6 @@ void gmmvi_ctx_destroy(gmmvi_ctx* ctx) {
     }
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->arena) (void)hipFree(ctx->arena);
-    if (ctx->zc_hash) (void)hipFree(ctx->zc_hash);
     delete ctx;
 }
 

@@ -38,6 +38,7 @@ struct BG {
     const float* a_sub; long long s_asub;        // [Kd]  A(m, k) -= a_sub[k]
     const float* a_kscale; long long s_aks;      // [Kd]  A(m, k) *= a_kscale[k]
     const float* a_rscale; long long s_ars;      // [M]   A(m, k) *= a_rscale[m]
+    const float* a_rsub; long long s_arsub;      // [M]   with a_kscale (k-major A only): A(m, k) = (A(m, k) - a_rsub[m]) * a_kscale[k]
     const float* c_bias; long long s_cb;         // [N]   C(m, n) += c_bias[n]
     const int32_t* row_off;          // optional [batches + 1]: batch b owns rows [row_off[b], row_off[b+1]) of A and C (M = bound)
     int inner;                       // > 0: workgroup z accumulates the batches [z * inner, min((z+1) * inner, inner_total)) into slab z of C
@@ -45,7 +46,6 @@ struct BG {
     int tri;                         // 1: opB(k, n) = 0 for k > n   2: opB(k, n) = 0 for k < n
     int accumulate;                  // C += result
     int ksplit;                      // > 1: grid.z = batches * ksplit, slab z of C receives the partial sum over its k range
-    const int* skip;                 // optional device flag: non-zero = the result is already in place, do nothing
     float alpha;
     // optional: per-row sums of squares of this workgroup's result columns, rowsq[blockIdx.x * rs_tile + blockIdx.z * rs_batch +
     // row] (one partial per column tile; the caller adds the tiles).  no_store: the result itself is not written.
@@ -68,7 +68,7 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
 __device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // NT: 32-column MFMA tiles per wave; AK / BKM: operand is k-major in memory; PRO: prologue on A (0 none, 1 subtract a
-// vector along k, 2 scale rows, 3 scale along k).  Every step takes one of two routes, chosen uniformly: the fast route
+// vector along k, 2 scale rows, 3 scale along k, 4 subtract a vector along the rows, then scale along k: k-major A only).  Every step takes one of two routes, chosen uniformly: the fast route
 // (aligned operands, a full 16-wide k step, every 16-byte piece entirely valid or entirely void -- decided once per thread)
 // issues all loads back to back without a branch; the edge route handles ragged ends element by element.
 template <int NT, int AK, int BKM, int PRO>
@@ -77,7 +77,6 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void bgemm_kernel(BG g) {
     constexpr int NVB = (BN * BK / 4 + 255) / 256;          // 16-byte pieces of the B tile per thread
     __shared__ __align__(16) float As[2][BK * LDA_S];
     __shared__ __align__(16) float Bs[2][BK * LDB_S];
-    if (g.skip != nullptr && *g.skip != 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
@@ -100,13 +99,14 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void bgemm_kernel(BG g) {
     const int nb = g.inner > 0 ? min(g.inner, g.inner_total - bz * g.inner) : 1;
     const int total = nb * spb;
     const float* A0 = g.A + (AK ? rowbase : rowbase * g.lda);
-    const float* pro = PRO == 1 ? g.a_sub : (PRO == 2 ? g.a_rscale : (PRO == 3 ? g.a_kscale : nullptr));
-    const long long s_pro = PRO == 1 ? g.s_asub : (PRO == 2 ? g.s_ars : (PRO == 3 ? g.s_aks : 0));
+    const float* pro = PRO == 1 ? g.a_sub : (PRO == 2 ? g.a_rscale : (PRO >= 3 ? g.a_kscale : nullptr));
+    const long long s_pro = PRO == 1 ? g.s_asub : (PRO == 2 ? g.s_ars : (PRO >= 3 ? g.s_aks : 0));
+    const bool vecR = PRO != 4 || (al16(g.a_rsub) && (g.s_arsub & 3) == 0);
     const bool vecA = al16(A0) && ((g.lda | g.sA) & 3) == 0;
     const bool vecB = al16(g.B) && ((g.ldb | g.sB) & 3) == 0;
     const bool vecP = PRO == 0 || (al16(pro) && (s_pro & 3) == 0);
     // fast route: no 16-byte piece may straddle the end of its operand
-    const bool fast_ok = vecA && vecB && (PRO != 1 || vecP) && (!AK || (Mb & 3) == 0 || m0 + BM <= Mb) &&
+    const bool fast_ok = vecA && vecB && (PRO != 1 || vecP) && vecR && (!AK || (Mb & 3) == 0 || m0 + BM <= Mb) &&
                          (!BKM || (g.N & 3) == 0 || n0 + BN <= g.N);
 
     // per-thread pieces: A tile = 512 pieces (2 per thread), B tile = 4 BN pieces
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void bgemm_kernel(BG g) {
         b_off[u] = b_ok[u] ? (BKM ? b_k[u] * g.ldb + n0 + b_c[u] : (n0 + b_c[u]) * g.ldb + b_k[u]) : 0;
     }
 
-    float4 ra[2], rb[NVB], pv[2];
+    float4 ra[2], rb[NVB], pv[2], pw[2];
     bool pending = false;                   // fast route: prologue / masking of the staged pieces still to be applied
     auto gload = [&](int step) {
         pending = false;
@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void bgemm_kernel(BG g) {
         const float* Ab = A0 + b * g.sA;
         const float* Bb = g.B + b * g.sB;
         const float* pb = PRO ? pro + b * s_pro : nullptr;
+        const float* pr = PRO == 4 ? g.a_rsub + b * g.s_arsub : nullptr;
         if (fast_ok && k0 + BK <= ke) {
             const float* Ak = Ab + (AK ? (long long)k0 * g.lda : (long long)k0);
             const float* Bk = Bb + (BKM ? (long long)k0 * g.ldb : (long long)k0);
@@ -161,6 +162,10 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void bgemm_kernel(BG g) {
                 } else if (PRO == 3) {
                     if (AK) { const float s = pb[k0 + a_k[u]]; pv[u] = make_float4(s, s, s, s); }
                     else pv[u] = ld4(pb + k0 + a_k[u], 4, vecP);
+                } else if (PRO == 4) {
+                    const float s = pb[k0 + a_k[u]];
+                    pv[u] = make_float4(s, s, s, s);
+                    pw[u] = *reinterpret_cast<const float4*>(pr + (a_ok[u] ? m0 + a_r[u] : 0));
                 }
             }
             pending = true;
@@ -177,6 +182,11 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void bgemm_kernel(BG g) {
                     if (PRO == 1) { const float s = pb[gk]; v.x -= s; v.y -= s; v.z -= s; v.w -= s; }
                     if (PRO == 3) { const float s = pb[gk]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
                     if (PRO == 2) { const float4 s = ld4(pb + gm, nv, vecP); v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w; }
+                    if (PRO == 4) {
+                        const float4 r4 = ld4(pr + gm, nv, vecR);
+                        const float s = pb[gk];
+                        v.x = (v.x - r4.x) * s; v.y = (v.y - r4.y) * s; v.z = (v.z - r4.z) * s; v.w = (v.w - r4.w) * s;
+                    }
                     if (nv < 4) { if (nv < 2) v.y = 0.f; if (nv < 3) v.z = 0.f; v.w = 0.f; }
                 }
             } else {                                            // 4 consecutive k of one row
@@ -209,6 +219,7 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void bgemm_kernel(BG g) {
             for (int u = 0; u < 2; ++u) {
                 float4 v = ra[u];
                 if (PRO == 1) { v.x -= pv[u].x; v.y -= pv[u].y; v.z -= pv[u].z; v.w -= pv[u].w; }
+                if (PRO == 4) { v.x -= pw[u].x; v.y -= pw[u].y; v.z -= pw[u].z; v.w -= pw[u].w; }
                 if (PRO >= 2) { v.x *= pv[u].x; v.y *= pv[u].y; v.z *= pv[u].z; v.w *= pv[u].w; }
                 ra[u] = a_ok[u] ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -364,14 +375,15 @@ int bgemm_launch(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
 // the operand layouts / prologues the callers below use
 int bgemm(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
     if (g.M <= 0 || g.N <= 0 || batches_outer <= 0) return GMMVI_OK;
-    const int pro = g.a_sub ? 1 : (g.a_rscale ? 2 : (g.a_kscale ? 3 : 0));
+    const int pro = g.a_sub ? 1 : (g.a_rscale ? 2 : (g.a_kscale ? (g.a_rsub ? 4 : 3) : 0));
     const int key = g.a_kmajor * 100 + g.b_kmajor * 10 + pro;
     switch (key) {
         case 1: return bgemm_launch<0, 0, 1>(ctx, g, batches_outer);      // whitening: (X - mu) L^-T
         case 0: return bgemm_launch<0, 0, 0>(ctx, g, batches_outer);      // sampling: eps L^T
         case 12: return bgemm_launch<0, 1, 2>(ctx, g, batches_outer);     // gradient: (r Z) L^-1
         case 10: return bgemm_launch<0, 1, 0>(ctx, g, batches_outer);     // A L^-1, R L
-        case 113: return bgemm_launch<1, 1, 3>(ctx, g, batches_outer);    // Stein: G1^T diag(e) Z1
+        case 114: return bgemm_launch<1, 1, 4>(ctx, g, batches_outer);    // Stein: (X1 - mu1)^T diag(e) G1
+        case 100: return bgemm_launch<1, 0, 0>(ctx, g, batches_outer);    // C^T L^-T
         case 110: return bgemm_launch<1, 1, 0>(ctx, g, batches_outer);    // L^T (R L)
         default: return gmmvi_fail(ctx, GMMVI_ERR_ARG, "bgemm: operand layout not instantiated");
     }
@@ -706,52 +718,20 @@ size_t z_budget_floats() {
     return e ? (size_t)atoll(e) / 4 : ((size_t)4 << 30) / 4;
 }
 
-// order-sensitive 64-bit content hash of n words: sum_i bits_i * odd(i) mod 2^64 (integer atomics: order-independent result)
-__global__ __launch_bounds__(256) void blk_hash_kernel(const uint32_t* __restrict__ data, size_t n, unsigned long long* out) {
-    __shared__ unsigned long long red[256];
-    unsigned long long h = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        h += (unsigned long long)data[i] * ((0x9E3779B97F4A7C15ull * (i + 1)) | 1ull);
-    red[threadIdx.x] = h;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) atomicAdd(out, red[0]);
-}
-
-__global__ void blk_hash_match_kernel(unsigned long long* h) {
-    reinterpret_cast<int*>(h + 4)[0] = (h[0] == h[2] && h[1] == h[3]) ? 1 : 0;
-}
-
-// hashes of (component blocks, samples) into h[slot], h[slot + 1]
-int blk_hash_inputs(gmmvi_ctx* ctx, const float* packed, size_t n_packed, const float* X, size_t n_x, int slot) {
-    if (ctx->zc_hash == nullptr) GMMVI_HIP_CHECK(ctx, hipMalloc((void**)&ctx->zc_hash, 8 * sizeof(unsigned long long)));
-    GMMVI_HIP_CHECK(ctx, hipMemsetAsync(ctx->zc_hash + slot, 0, 2 * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(blk_hash_kernel, dim3(512), dim3(256), 0, ctx->stream, reinterpret_cast<const uint32_t*>(packed), n_packed,
-                       ctx->zc_hash + slot);
-    hipLaunchKernelGGL(blk_hash_kernel, dim3(512), dim3(256), 0, ctx->stream, reinterpret_cast<const uint32_t*>(X), n_x,
-                       ctx->zc_hash + slot + 1);
-    GMMVI_LAUNCH_CHECK(ctx);
-    return GMMVI_OK;
-}
-
 // Z[kb][n][0:D] = (x_n - mu_k) L_k^-T for the components k0 .. k0 + kn - 1 (row stride ldz)
 // qpart != nullptr: the launch also leaves |z|^2 partials, one per column tile: qpart[tile * kn * N + kb * N + n];
-// store_z = false: Z itself is not written (a density pass that needs neither the gradient nor the Stein hand-over)
+// store_z = false: Z itself is not written (a density pass that does not need the gradient)
 int blk_forward(gmmvi_ctx* ctx, int D, const float* packed, int k0, int kn, const float* X, int N, float* Z, int ldz,
-                const int* skip = nullptr, float* qpart = nullptr, bool store_z = true) {
+                float* qpart = nullptr, bool store_z = true) {
     const size_t ps = gmmvi_blocked_stride(D);
     BG g = bg_zero();
     g.A = X; g.lda = D; g.sA = 0; g.a_kmajor = 0;
     g.a_sub = packed + (size_t)k0 * ps; g.s_asub = (long long)ps;
     g.B = packed + (size_t)k0 * ps + gmmvi_blocked_linv_ofs(D); g.ldb = D; g.sB = (long long)ps; g.b_kmajor = 0;
     g.C = Z; g.ldc = ldz; g.sC = (long long)N * ldz;
-    g.M = N; g.N = D; g.Kd = D; g.tri = 1; g.skip = skip;
+    g.M = N; g.N = D; g.Kd = D; g.tri = 1;
     g.rowsq = qpart; g.rs_tile = (long long)kn * N; g.rs_batch = N; g.no_store = store_z ? 0 : 1;
-    // a launch that may find Z in place (skip flag) is timed under its own name: it is not a whitening pass
-    GMMVI_PROF_UNITS(ctx, skip ? "blocked_forward_or_reuse" : "blocked_forward", skip ? 0.0 : (double)kn * N);
+    GMMVI_PROF_UNITS(ctx, "blocked_forward", (double)kn * N);
     return bgemm(ctx, g, kn);
 }
 
@@ -834,7 +814,7 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     };
     for (int c = 0; c < nchunks; ++c) {
         const int k0 = c * Kc, kn = (K - k0 < Kc) ? K - k0 : Kc;
-        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP, nullptr, qpart, store_z));
+        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP, qpart, store_z));
         rowsq(k0, kn, true);
         GMMVI_LAUNCH_CHECK(ctx);
     }
@@ -847,7 +827,7 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         for (int c = 0; c < nchunks; ++c) {
             const int k0 = c * Kc, kn = (K - k0 < Kc) ? K - k0 : Kc;
             if (nchunks > 1) {
-                BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP, nullptr, qpart, true));
+                BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP, qpart, true));
                 rowsq(k0, kn, false);
                 GMMVI_LAUNCH_CHECK(ctx);
             }
@@ -874,14 +854,6 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
                 BLK_TRY(bgemm(ctx, g, 1));
             }
         }
-    }
-    // hand-over to the Stein estimate of the same iteration (gmmvi_stein takes ld / qgrad "from gmmvi_mixture_eval on the same
-    // X"): Z of all components is at the start of the scratch; remember what it was computed from
-    ctx->zc.valid = false;
-    if (nchunks == 1 && ld_out != nullptr && grad != nullptr) {
-        BLK_TRY(blk_hash_inputs(ctx, packed, (size_t)K * ps, X, gslab, 0));
-        ctx->zc.valid = true; ctx->zc.epoch = ctx->ws_epoch; ctx->zc.ws = ctx->ws;
-        ctx->zc.K = K; ctx->zc.N = N; ctx->zc.D = D; ctx->zc.ldz = LP;
     }
     return GMMVI_OK;
 }
@@ -918,25 +890,31 @@ int gmmvi_blocked_sample(gmmvi_ctx* ctx, int K, int D, const float* means, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Stein estimate (gmmvi_modules/ng_estimator.py:146-263): A_k = sum_n e_kn [g_n; 1] [z_kn; 1]^T as one contraction over the
-// samples per component, then H = sym(A[:D,:D] L^-1) / sum e  (y = L^-T z applied once per component, as in stein.hip)
+// Stein estimate (gmmvi_modules/ng_estimator.py:146-263), moment form as in stein.hip: the estimate is linear in
+// y = Sigma^-1 (x - mu), so C_k = sum_n e_kn [x_n - mu_k; 1] [g_n; 1]^T is ONE contraction over the samples per component with
+// operands shared by all components (rows [x; 1] and [g; 1]; centring and importance weight enter as the A prologue) --
+// nothing whitened is read or kept -- and Sigma_k^-1 = L^-T L^-1 is applied once per component by two triangular contractions:
+// H = sym((C[:D,:D]^T L^-T) L^-1) / sum e.
 // ---------------------------------------------------------------------------------------------------------------------------
 namespace {
 
-// rows [g_n; 1; 0..] with the row stride LP = D + 1 rounded up to a multiple of 4 (16-byte aligned rows)
-__global__ __launch_bounds__(256) void blk_stein_g_kernel(int N, int D, int LP, const float* __restrict__ tgrad,
-                                                          const float* __restrict__ qgrad, float* __restrict__ G1) {
+// rows [g_n; 1; 0..] and [x_n; 1; 0..] with the row stride LP = D + 1 rounded up to a multiple of 4 (16-byte aligned rows)
+__global__ __launch_bounds__(256) void blk_stein_rows_kernel(int N, int D, int LP, const float* __restrict__ X,
+                                                             const float* __restrict__ tgrad, const float* __restrict__ qgrad,
+                                                             float* __restrict__ X1, float* __restrict__ G1) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long long)N * LP) return;
     const int n = (int)(e / LP), i = (int)(e % LP);
-    G1[e] = (i < D) ? tgrad[(size_t)n * D + i] - qgrad[(size_t)n * D + i] : (i == D ? 1.f : 0.f);
+    const float one = (i == D) ? 1.f : 0.f;
+    G1[e] = (i < D) ? tgrad[(size_t)n * D + i] - qgrad[(size_t)n * D + i] : one;
+    X1[e] = (i < D) ? X[(size_t)n * D + i] : one;
 }
 
-// columns D .. LP-1 of the whitened rows: [.; 1; 0..]
-__global__ __launch_bounds__(256) void blk_fill_col_kernel(long long rows, int D, int LP, float* __restrict__ Z) {
-    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (r >= rows) return;
-    for (int c = D; c < LP; ++c) Z[r * LP + c] = (c == D) ? 1.f : 0.f;
+// rows [mu_k; 0; 0..] (the "1" column is not centred)
+__global__ __launch_bounds__(256) void blk_stein_mu_kernel(int D, int LP, size_t ps, const float* __restrict__ packed,
+                                                           float* __restrict__ mu1) {
+    const int kb = blockIdx.x;
+    for (int i = threadIdx.x; i < LP; i += 256) mu1[(size_t)kb * LP + i] = (i < D) ? packed[(size_t)kb * ps + i] : 0.f;
 }
 
 // importance weights of one component over all samples, referred to their maximum: e[kb][n] = exp(a_n - M), Mk[kb] = M
@@ -960,24 +938,25 @@ __global__ __launch_bounds__(1024) void blk_stein_weights_kernel(int N, int k0, 
     if (threadIdx.x == 0) Mk[kb] = M;
 }
 
-__global__ __launch_bounds__(256) void blk_stein_finalize_kernel(int D, int N, int flags, const float* __restrict__ Araw,
+// C[b][a] = sum e d_b g'_a (row D of C: sum e g'_a), T = sum e g y^T
+__global__ __launch_bounds__(256) void blk_stein_finalize_kernel(int D, int N, int flags, const float* __restrict__ Craw,
                                                                  const float* __restrict__ T, const float* __restrict__ Mk,
                                                                  float* __restrict__ H_neg, float* __restrict__ g_neg) {
     const int kb = blockIdx.x, D1 = ((D + 1 + 3) / 4) * 4;          // row stride of the augmented matrix
-    const float* A = Araw + (size_t)kb * D1 * D1;
+    const float* C = Craw + (size_t)kb * D1 * D1;
     const float* Tk = T + (size_t)kb * D * D;
     const bool snis = (flags & GMMVI_SELF_NORMALIZED) != 0;
     // own samples only: the divisor is the number of own samples = sum e (weights exp(0), ng_estimator.py:110-118,146-152)
     const bool own = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
     // (an empty own-sample set: zeros in the self-normalised branch, NaN in the plain one, as upstream's reductions give)
-    const float se = A[(size_t)D * D1 + D];
+    const float se = C[(size_t)D * D1 + D];
     const float scale = snis ? (se > 0.f ? 1.f / se : 0.f) : (own ? 1.f / se : __expf(Mk[kb]) / (float)N);
     for (int e = threadIdx.x; e < D * D; e += 256) {
         const int i = e / D, j = e % D;
         const float v = snis ? 0.5f * (Tk[e] + Tk[(size_t)j * D + i]) : Tk[e];
         H_neg[(size_t)kb * D * D + e] = -v * scale;
     }
-    for (int i = threadIdx.x; i < D; i += 256) g_neg[(size_t)kb * D + i] = -A[(size_t)i * D1 + D] * scale;
+    for (int i = threadIdx.x; i < D; i += 256) g_neg[(size_t)kb * D + i] = -C[(size_t)D * D1 + i] * scale;
 }
 
 }  // namespace
@@ -987,11 +966,11 @@ int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
                         int flags, float* H_neg, float* g_neg) {
     const int LP = ((D + 1 + 3) / 4) * 4;                  // augmented width D + 1, padded to 16-byte rows (pad columns zero)
     const size_t ps = gmmvi_blocked_stride(D);
-    const size_t zrow = (size_t)N * LP;
-    size_t kc = z_budget_floats() / zrow;
+    const size_t rows = (size_t)N * LP;
+    // component chunks only bound the scratch of the weights and the per-component matrices (default budget 4 GiB)
+    const size_t per_k = (size_t)N + 2 * (size_t)LP * LP + 2 * (size_t)D * D + LP + 4;
+    size_t kc = z_budget_floats() / per_k;
     const int Kc = (int)(kc < 1 ? 1 : (kc > (size_t)K ? (size_t)K : kc));
-    const size_t f_z = (size_t)Kc * zrow, f_g = zrow, f_e = (size_t)Kc * N, f_m = ((size_t)Kc + 3) / 4 * 4;
-    const size_t f_a = (size_t)Kc * LP * LP, f_t = (size_t)Kc * D * D;
     // the contraction over the samples is split into S ranges per component so that the launch has ~8 workgroups per CU
     // (a component alone has only ceil(LP/128) * ceil(LP/160) output tiles); the partial matrices are summed in fixed order
     const int tiles = ((LP + 127) / 128) * ((LP + 159) / 160);
@@ -999,63 +978,66 @@ int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
     if (S > N / 256) S = N / 256;
     if (S > 16) S = 16;
     if (S < 1) S = 1;
+    const size_t f_x = rows, f_g = rows, f_e = (size_t)Kc * N, f_m = ((size_t)Kc + 3) / 4 * 4, f_mu = (size_t)Kc * LP;
+    const size_t f_c = (size_t)Kc * LP * LP, f_w = (size_t)Kc * D * D, f_t = (size_t)Kc * D * D;
     const size_t f_p = S > 1 ? (size_t)Kc * S * LP * LP : 0;
-    BLK_TRY(gmmvi_ws_reserve(ctx, (f_z + f_g + f_e + f_m + f_a + f_t + f_p) * sizeof(float)));
-    float* Z = (float*)ctx->ws;
-    float* G1 = Z + f_z;
+    BLK_TRY(gmmvi_ws_reserve(ctx, (f_x + f_g + f_e + f_m + f_mu + f_c + f_w + f_t + f_p) * sizeof(float)));
+    float* X1 = (float*)ctx->ws;
+    float* G1 = X1 + f_x;
     float* e = G1 + f_g;
     float* Mk = e + f_e;
-    float* Araw = Mk + f_m;
-    float* T = Araw + f_a;
-    float* Apart = T + f_t;
-    // Z may still be in place from the density sweep that produced ld / qgrad: same scratch block, nothing reserved in
-    // between, same shapes -- and, decided on the device, identical content hashes of the component blocks and the samples
-    const int* skip = nullptr;
-    if (ctx->zc.valid && ctx->zc.epoch + 1 == ctx->ws_epoch && ctx->zc.ws == ctx->ws && ctx->zc.K == K && ctx->zc.N == N &&
-        ctx->zc.D == D && ctx->zc.ldz == LP && Kc == K) {
-        BLK_TRY(blk_hash_inputs(ctx, packed, (size_t)K * ps, X, (size_t)N * D, 2));
-        hipLaunchKernelGGL(blk_hash_match_kernel, dim3(1), dim3(1), 0, ctx->stream, ctx->zc_hash);
-        GMMVI_LAUNCH_CHECK(ctx);
-        skip = reinterpret_cast<const int*>(ctx->zc_hash + 4);
-    }
-    ctx->zc.valid = false;
-    hipLaunchKernelGGL(blk_stein_g_kernel, dim3((unsigned)((zrow + 255) / 256)), dim3(256), 0, ctx->stream, N, D, LP, tgrad, qgrad,
-                       G1);
+    float* mu1 = Mk + f_m;
+    float* Craw = mu1 + f_mu;
+    float* Wt = Craw + f_c;
+    float* T = Wt + f_w;
+    float* Cpart = T + f_t;
+    hipLaunchKernelGGL(blk_stein_rows_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, N, D, LP, X, tgrad,
+                       qgrad, X1, G1);
     GMMVI_LAUNCH_CHECK(ctx);
     for (int k0 = 0; k0 < K; k0 += Kc) {
         const int kn = (K - k0 < Kc) ? K - k0 : Kc;
-        const long long rows = (long long)kn * N;
-        BLK_TRY(blk_forward(ctx, D, packed, k0, kn, X, N, Z, LP, skip));
-        hipLaunchKernelGGL(blk_fill_col_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, rows, D, LP, Z);
+        hipLaunchKernelGGL(blk_stein_mu_kernel, dim3(kn), dim3(256), 0, ctx->stream, D, LP, ps, packed + (size_t)k0 * ps, mu1);
         hipLaunchKernelGGL(blk_stein_weights_kernel, dim3(kn), dim3(1024), 0, ctx->stream, N, k0, ld, bg, mapping, map_offset,
                            flags, e, Mk);
         GMMVI_LAUNCH_CHECK(ctx);
         {
             BG g = bg_zero();
-            g.A = G1; g.lda = LP; g.sA = 0; g.a_kmajor = 1;             // opA(m = a, k = n) = G1[n][a]
+            g.A = X1; g.lda = LP; g.sA = 0; g.a_kmajor = 1;             // opA(m = b, k = n) = (X1[n][b] - mu1[b]) e[n]
             g.a_kscale = e; g.s_aks = N;
-            g.B = Z; g.ldb = LP; g.sB = (long long)zrow; g.b_kmajor = 1;  // opB(k = n, n = b) = Z1[n][b]
-            g.C = S > 1 ? Apart : Araw; g.ldc = LP; g.sC = (long long)LP * LP;
+            g.a_rsub = mu1; g.s_arsub = LP;
+            g.B = G1; g.ldb = LP; g.sB = 0; g.b_kmajor = 1;             // opB(k = n, n = a) = G1[n][a]
+            g.C = S > 1 ? Cpart : Craw; g.ldc = LP; g.sC = (long long)LP * LP;
             g.M = LP; g.N = LP; g.Kd = N; g.ksplit = S;
             GMMVI_PROF_UNITS(ctx, "blocked_stein_accumulate", (double)kn * N);
             BLK_TRY(bgemm(ctx, g, kn));
             if (S > 1) {
                 const size_t slab = (size_t)LP * LP;
                 hipLaunchKernelGGL(blk_sum_slabs_kernel, dim3((unsigned)((slab + 255) / 256), kn), dim3(256), 0, ctx->stream, S,
-                                   slab, Apart, Araw, 0);
+                                   slab, Cpart, Craw, 0);
                 GMMVI_LAUNCH_CHECK(ctx);
             }
         }
         {
+            // Wt[a][i] = sum_j C[j][a] Linv[i][j]  ( = (A L^-T)[a][i] with A = C^T )
             BG g = bg_zero();
-            g.A = Araw; g.lda = LP; g.sA = (long long)LP * LP; g.a_kmajor = 0;
+            g.A = Craw; g.lda = LP; g.sA = (long long)LP * LP; g.a_kmajor = 1;          // opA(m = a, k = j) = C[j][a]
+            g.B = packed + (size_t)k0 * ps + gmmvi_blocked_linv_ofs(D); g.ldb = D; g.sB = (long long)ps; g.b_kmajor = 0;   // opB(k = j, n = i) = Linv[i][j]
+            g.C = Wt; g.ldc = D; g.sC = (long long)D * D;
+            g.M = D; g.N = D; g.Kd = D; g.tri = 1;                                       // Linv[i][j] = 0 for j > i
+            GMMVI_PROF(ctx, "blocked_stein_unwhiten");
+            BLK_TRY(bgemm(ctx, g, kn));
+        }
+        {
+            // T = Wt L^-1
+            BG g = bg_zero();
+            g.A = Wt; g.lda = D; g.sA = (long long)D * D; g.a_kmajor = 0;
             g.B = packed + (size_t)k0 * ps + gmmvi_blocked_linv_ofs(D); g.ldb = D; g.sB = (long long)ps; g.b_kmajor = 1;
             g.C = T; g.ldc = D; g.sC = (long long)D * D;
             g.M = D; g.N = D; g.Kd = D; g.tri = 2;
             GMMVI_PROF(ctx, "blocked_stein_unwhiten");
             BLK_TRY(bgemm(ctx, g, kn));
         }
-        hipLaunchKernelGGL(blk_stein_finalize_kernel, dim3(kn), dim3(256), 0, ctx->stream, D, N, flags, Araw, T, Mk,
+        hipLaunchKernelGGL(blk_stein_finalize_kernel, dim3(kn), dim3(256), 0, ctx->stream, D, N, flags, Craw, T, Mk,
                            H_neg + (size_t)k0 * D * D, g_neg + (size_t)k0 * D);
         GMMVI_LAUNCH_CHECK(ctx);
     }

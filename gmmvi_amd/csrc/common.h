@@ -15,13 +15,7 @@ struct gmmvi_ctx {
     // scratch reused by multi-kernel entry points (grown on demand, never shrunk)
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    // Every gmmvi_ws_reserve starts a new epoch of the scratch: contents survive from one entry point to the next only by
-    // the explicit hand-over below.  Blocked path: the whitened samples Z of the last single-chunk density sweep stay at the
-    // start of ws; the Stein estimate that follows reuses them when the scratch is untouched and 64-bit content hashes of
-    // (component blocks, samples) match (blocked.hip).
-    uint64_t ws_epoch = 0;
-    struct ZCache { bool valid = false; uint64_t epoch = 0; const void* ws = nullptr; int K = 0, N = 0, D = 0, ldz = 0; } zc;
-    unsigned long long* zc_hash = nullptr;       // device: [0,1] recorded with Z, [2,3] current call, [4] match flag
+    uint64_t ws_epoch = 0;       // bumped by every gmmvi_ws_reserve: the scratch contents belong to the call that reserved them
     void* arena = nullptr;       // persistent scratch of the single-call iteration (fused.hip)
     size_t arena_bytes = 0;
     void* comm = nullptr;        // ncclComm_t

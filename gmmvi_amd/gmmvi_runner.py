@@ -1,106 +1,150 @@
-"""GmmviRunner (reference: src/gmmvi/gmmvi_runner.py:23-200): seeds, timing, metrics and npz dumps around
-GMMVI.train_iter(); same constructor, ``build_from_config``, ``iterate_and_log``, ``log_to_disk`` and ``finalize``."""
+"""Runner around ``GMMVI.train_iter()``: seeding, wall-clock bookkeeping, metric evaluation and model dumps.
+
+Drop-in for the reference's ``gmmvi.gmmvi_runner.GmmviRunner`` (src/gmmvi/gmmvi_runner.py:23-200): the constructor
+signature, ``build_from_config``, the five public methods, the metric keys (:111-116, :134-135, :142), the checkpoint
+line (:169-171) and the npz keys (:187-200) are the contract; everything behind them is organised for a device-resident
+model: one seeding helper, an evaluator that keeps the 2000 evaluation samples on the GPU, and a dump writer that owns the
+output directory.
+"""
 import os
 import random
-from time import time
+import time
 
 import numpy as np
 
-from .optimization.gmmvi import GMMVI
 from .experiments.setup_experiment import init_experiment
+from .optimization.gmmvi import GMMVI
+
+_NUM_EVAL_SAMPLES = 2000          # gmmvi_runner.py:131
+_CHECKPOINT_LINE = "Checkpoint {:3d} | FEVALS: {:10d} | avg. sample logpdf: {:05.05f} | ELBO: {:05.05f}"
+
+
+def _seed_everything(seed):
+    """What tf.keras.utils.set_random_seed does upstream (:38), minus TensorFlow: python and numpy generators here, the
+    device Philox streams are keyed by the caller with the same seed."""
+    random.seed(seed)
+    np.random.seed(seed)
+
+
+def _host(value):
+    return value.numpy() if hasattr(value, "numpy") else np.asarray(value)
+
+
+class _GmmDumper:
+    """Writes ``gmm_dump_<n>.npz`` / ``final_gmm_dump.npz`` below ``<dump_gmm_path>/<creation time>/`` (:56-61, :177-200)."""
+
+    KEYS = ("weights", "means", "covs", "timestamps", "fevals")
+
+    def __init__(self, root):
+        self.directory = os.path.join(root, str(time.time()))
+        os.makedirs(self.directory, exist_ok=True)
+
+    @staticmethod
+    def wanted(iteration):
+        return iteration < 100 or iteration % 50 == 0
+
+    def write(self, name, gmmvi):
+        model = gmmvi.model
+        payload = dict(zip(self.KEYS, (np.exp(_host(model.log_weights)), _host(model.means), _host(model.covs), time.time(),
+                                      gmmvi.sample_db.num_samples_written.numpy())))
+        np.savez(os.path.join(self.directory, name), **payload)
 
 
 class GmmviRunner:
     def __init__(self, config, log_metrics_interval):
-        if "seed" not in config.keys():
-            config["seed"] = config["start_seed"]
-        # tf.keras.utils.set_random_seed(seed) seeds python, numpy and TF (gmmvi_runner.py:38); the device streams
-        # are Philox keyed by the same seed
-        random.seed(config["seed"])
-        np.random.seed(config["seed"])
-        self.wall_times = []
+        config.setdefault("seed", config.get("start_seed"))
+        _seed_everything(config["seed"])
         self.config = config
         self.log_metrics_interval = log_metrics_interval
-        target_distribution, initial_model = init_experiment(self.config)
+        self.wall_times = []
+
+        target_distribution, initial_model = init_experiment(config)
         initial_model.model.seed = int(config["seed"])
-        self.gmmvi = GMMVI.build_from_config(self.config, target_distribution, initial_model)
-        if "mmd_evaluation_config" in config.keys():                                       # gmmvi_runner.py:45-54
-            from .experiments.evaluation.mmd import MMD
-            dir_path = os.path.dirname(os.path.realpath(__file__))
-            samples = np.load(os.path.join(dir_path, config['mmd_evaluation_config']['sample_dir']))
-            self.mmd = MMD(samples, config['mmd_evaluation_config']["alpha"])
-        else:
-            self.mmd = None
-        if "dump_gmm_path" not in self.config:
-            self.dump_gmms = False
-        else:
-            self.dump_gmms = True
-            self.dump_gmm_path = os.path.join(self.config["dump_gmm_path"], str(time()))
-            os.makedirs(self.dump_gmm_path, exist_ok=True)
+        self.gmmvi = GMMVI.build_from_config(config, target_distribution, initial_model)
+
+        self.mmd = self._build_mmd(config.get("mmd_evaluation_config"))
+        self._dumper = _GmmDumper(config["dump_gmm_path"]) if "dump_gmm_path" in config else None
+        self.dump_gmms = self._dumper is not None
+        if self.dump_gmms:
+            self.dump_gmm_path = self._dumper.directory
+
+    @staticmethod
+    def _build_mmd(mmd_config):
+        """:45-54 (no graph to warm up here: the MMD kernel is a plain launch)."""
+        if mmd_config is None:
+            return None
+        from .experiments.evaluation.mmd import MMD
+        here = os.path.dirname(os.path.realpath(__file__))
+        return MMD(np.load(os.path.join(here, mmd_config["sample_dir"])), mmd_config["alpha"])
 
     @staticmethod
     def build_from_config(config: dict):
-        """gmmvi_runner.py:63-81."""
-        return GmmviRunner(config=config, **config['gmmvi_runner_config'])
+        """:63-81: ``config['gmmvi_runner_config']`` holds the runner's own arguments."""
+        return GmmviRunner(config=config, **config["gmmvi_runner_config"])
 
+    # ---- metrics ------------------------------------------------------------------------------------------------
     def get_samples_and_entropy(self, num_samples):
-        """gmmvi_runner.py:83-100."""
-        test_samples = self.gmmvi.model.sample(num_samples)[0]
-        entropy = -float(np.mean(self.gmmvi.model.log_density(test_samples).numpy()))
-        return test_samples, entropy
+        """:83-100 -> (samples drawn from the model, Monte-Carlo entropy estimate)."""
+        samples = self.gmmvi.model.sample(num_samples)[0]
+        log_q = _host(self.gmmvi.model.log_density(samples))
+        return samples, -float(log_q.mean())
 
     def get_cheap_metrics(self):
-        """gmmvi_runner.py:102-117."""
-        return {"num_samples": self.gmmvi.sample_db.num_samples_written.numpy(),
-                "num_components": self.gmmvi.model.num_components,
-                "max_weight": float(np.max(self.gmmvi.model.weights)),
-                "num_db_samples": self.gmmvi.sample_db.samples.shape[0],
-                "num_db_components": self.gmmvi.sample_db.means.shape[0]}
+        """:102-117: quantities that cost nothing to read after an iteration."""
+        db, model = self.gmmvi.sample_db, self.gmmvi.model
+        return {
+            "num_samples": db.num_samples_written.numpy(),
+            "num_components": model.num_components,
+            "max_weight": float(np.max(model.weights)),
+            "num_db_samples": db.samples.shape[0],
+            "num_db_components": db.means.shape[0],
+        }
 
     def get_expensive_metrics(self):
-        """gmmvi_runner.py:119-144: ELBO = E_q[log p~] + temperature * H(q) on 2000 fresh samples."""
-        expensive_metrics = dict()
-        test_samples, entropy = self.get_samples_and_entropy(2000)
-        lp = self.gmmvi.sample_selector.target_uld(test_samples)
-        mean_reward = float(np.mean(np.asarray(lp.numpy() if hasattr(lp, "numpy") else lp)))
-        elbo = mean_reward + self.gmmvi.temperature * entropy
-        expensive_metrics.update({"-elbo": -elbo, "entropy": entropy, "target_density": mean_reward,
-                                  "algo_time": np.sum(self.wall_times)})
-        expensive_metrics.update(
-            self.gmmvi.sample_selector.target_distribution.expensive_metrics(self.gmmvi.model, test_samples))
-        if self.mmd is not None:                                                           # gmmvi_runner.py:140-142
-            expensive_metrics.update({"MMD:": self.mmd.compute_MMD(test_samples)})
-        return expensive_metrics
+        """:119-144: ELBO = E_q[log p~] + temperature * H(q) on fresh samples, plus the target's own metrics and the MMD."""
+        samples, entropy = self.get_samples_and_entropy(_NUM_EVAL_SAMPLES)
+        selector = self.gmmvi.sample_selector
+        target_density = float(_host(selector.target_uld(samples)).mean())
+        metrics = {
+            "-elbo": -(target_density + self.gmmvi.temperature * entropy),
+            "entropy": entropy,
+            "target_density": target_density,
+            "algo_time": np.sum(self.wall_times),
+        }
+        metrics.update(selector.target_distribution.expensive_metrics(self.gmmvi.model, samples))
+        if self.mmd is not None:
+            metrics["MMD:"] = self.mmd.compute_MMD(samples)
+        return metrics
+
+    # ---- one iteration ----------------------------------------------------------------------------------------------
+    def _timed_train_iter(self):
+        """The reference's train_iter returns when the step is done; here the launches are asynchronous, so the stream is
+        drained before the clock is read."""
+        start = time.time()
+        self.gmmvi.train_iter()
+        self.gmmvi.model.ctx.sync()
+        elapsed = time.time() - start
+        self.wall_times.append(elapsed)
+        return elapsed
 
     def iterate_and_log(self, n: int) -> dict:
-        """gmmvi_runner.py:146-175."""
-        output_dict = {}
-        ts1 = time()
-        self.gmmvi.train_iter()
-        self.gmmvi.model.ctx.sync()          # the reference's train_iter returns when the step is done
-        ts2 = time()
-        output_dict.update({"walltime": ts2 - ts1})
-        self.wall_times.append(ts2 - ts1)
-        output_dict.update(self.get_cheap_metrics())
+        """:146-175."""
+        output = {"walltime": self._timed_train_iter()}
+        output.update(self.get_cheap_metrics())
         if n % self.log_metrics_interval == 0:
-            eval_dict = self.get_expensive_metrics()
-            print("Checkpoint {:3d} | FEVALS: {:10d} | avg. sample logpdf: {:05.05f} | ELBO: {:05.05f}".format(
-                n, output_dict["num_samples"], eval_dict["target_density"], -eval_dict["-elbo"]))
+            evaluated = self.get_expensive_metrics()
+            print(_CHECKPOINT_LINE.format(n, output["num_samples"], evaluated["target_density"], -evaluated["-elbo"]))
             print(f"{self.gmmvi.model.num_components} components\n")
-            output_dict.update(eval_dict)
-        return output_dict
+            output.update(evaluated)
+        return output
 
+    # ---- dumps ----------------------------------------------------------------------------------------------------------
     def log_to_disk(self, n: int):
-        """gmmvi_runner.py:177-190."""
-        if self.dump_gmms and (n < 100 or n % 50 == 0):
-            m = self.gmmvi.model
-            np.savez(self.dump_gmm_path + '/gmm_dump_' + str("%01d" % n) + '.npz',
-                     weights=np.exp(m.log_weights.numpy()), means=m.means.numpy(), covs=m.covs, timestamps=time(),
-                     fevals=self.gmmvi.sample_db.num_samples_written.numpy())
+        """:177-190."""
+        if self._dumper is not None and _GmmDumper.wanted(n):
+            self._dumper.write("gmm_dump_" + str("%01d" % n) + ".npz", self.gmmvi)
 
     def finalize(self):
-        """gmmvi_runner.py:192-200."""
-        if self.dump_gmms:
-            m = self.gmmvi.model
-            np.savez(self.dump_gmm_path + '/final_gmm_dump.npz', weights=m.weights, means=m.means.numpy(),
-                     covs=m.covs, timestamps=time(), fevals=self.gmmvi.sample_db.num_samples_written.numpy())
+        """:192-200."""
+        if self._dumper is not None:
+            self._dumper.write("final_gmm_dump.npz", self.gmmvi)
