@@ -17,9 +17,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float wave_max(float v) { return gmmvi_wave_max(v); }
 
 // One workgroup per component: sums the R per-range partials of A_k (each referred to its own maximum m_r) in fixed order,
-// applies Sigma_k^-1 = L^-T L^-1 from the right to the D x D block (row i of the result: h' L^T = t ascending over the rows of
-// L, then h L = h' descending over its columns; L from the component's packed block, common.h Pack<DP>: 1/diag, rows,
-// columns, staged in LDS; the row in registers, loops unrolled for the padded dimension), normalises, symmetrises, negates.
+// applies Sigma_k^-1 = L^-T L^-1 from the right to the D x D block, normalises, symmetrises, negates.  Small blocks (no L^-1
+// fragments): row i of the result by substitution, h' L^T = t ascending over the rows of L, then h L = h' descending over its
+// columns (L from the packed block: 1/diag, rows, columns, staged in LDS; the row in registers, loops unrolled for the padded
+// dimension).  Blocks with fragments (DP >= 32): two triangular products with the explicit inverse on all threads.
 template <int DP>
 __global__ __launch_bounds__(1024) void stein_finalize_kernel(int D, int R, int N, int flags, const float* __restrict__ part,
                                                              const float* __restrict__ part_m, float* __restrict__ H_neg,
@@ -56,7 +57,37 @@ __global__ __launch_bounds__(1024) void stein_finalize_kernel(int D, int R, int 
         A[e] = a;
     }
     __syncthreads();
-    {
+    if constexpr (PK::FRAGS) {
+        // blocks that carry L^-1 (operand fragments, common.h): Sigma^-1 from the right as two triangular products spread over
+        // the whole workgroup -- W = T L^-T, then W L^-1 -- instead of two substitution chains on D threads
+        const float* Pk = packed + (size_t)k * PK::STRIDE;
+        float* Li = Ag;                  // dense L^-1 [DP][DP] (the group sums are consumed), then W [D][D]
+        float* W = Ag + DP * DP;
+        for (int e = threadIdx.x; e < DP * DP; e += blockDim.x) Li[e] = 0.f;
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * PK::NF; e += blockDim.x) {
+            const int f = e >> 6, l = e & 63;
+            int mt = 0, rem = f;
+            for (;; ++mt) { const int nfm = PK::nf(mt); if (rem < nfm) break; rem -= nfm; }
+            const int row = 16 * mt + (l & 15), col = 4 * rem + (l >> 4);        // the fragments cover 16 MT x 4 KS >= DP x DP
+            if (row < DP && col < DP) Li[row * DP + col] = Pk[PK::FWD + e];
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < D * D; o += blockDim.x) {
+            const int a = o / D, i = o - a * D;
+            float w = 0.f;
+            for (int j = 0; j <= i; ++j) w = fmaf(A[a * D1 + j], Li[i * DP + j], w);
+            W[o] = w;
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < D * D; o += blockDim.x) {
+            const int a = o / D, i2 = o - a * D;
+            float h = 0.f;
+            for (int i = i2; i < D; ++i) h = fmaf(W[a * D + i], Li[i * DP + i2], h);
+            A[a * D1 + i2] = h;
+        }
+        __syncthreads();
+    } else {
         const float* Pk = packed + (size_t)k * PK::STRIDE;
         float* Lc = Ag;                  // the group sums are consumed: reuse as [1/diag (DP) | columns (T) | rows (T)]
         for (int e = threadIdx.x; e < DP + 2 * PK::T; e += blockDim.x)
