@@ -250,7 +250,7 @@ __device__ __forceinline__ void sm_store_rows(float* t, int D, const float (&v)[
 // loads, own-samples weights on request
 template <int DP, int VW>
 __global__ __launch_bounds__(256, (SteinTile<DP>::MT <= 2 ? 2 : 1))
-void stein_moment_kernel(int K, int D_rt, int N, int wave_range, const float* __restrict__ packed,
+void stein_moment_kernel(int K, int D_rt, int N, int wave_range, int stacks, int R, const float* __restrict__ packed,
                          const float* __restrict__ X, const float* __restrict__ TG, const float* __restrict__ QG,
                          const float* __restrict__ ld, const float* __restrict__ bg, const int32_t* __restrict__ mapping,
                          int map_offset, int own_rt, float* __restrict__ part, float* __restrict__ part_m) {
@@ -265,9 +265,15 @@ void stein_moment_kernel(int K, int D_rt, int N, int wave_range, const float* __
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int D1 = D + 1;
-    const int k0 = blockIdx.x * NB;
+    // work item (stack, range), range-major.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
+    // workgroup b takes item (b % 8) * ceil(items / 8) + b / 8: an XCD then works through CONTIGUOUS items, i.e. one or two
+    // sample ranges for every stack, and only those rows of x / grad / ld pass through its L2 (placement is for speed only)
+    const int per_xcd = (stacks * R + 7) / 8;
+    const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (item >= stacks * R) return;
+    const int range_id = item / stacks;
+    const int k0 = (item - range_id * stacks) * NB;
     const int nb = min(NB, K - k0);
-    const int R = gridDim.y;
     // wave-private images: Tg rows 0..D-1 = g, row D = 1 (valid samples), row D+1 = 0; Tx rows 0..D-1 = x, row D = 1;
     // Te rows 0..NB-1 = importance weights, row NB = 0
     const int rows_g = D1 + 1, rows_x = D1;
@@ -297,7 +303,7 @@ void stein_moment_kernel(int K, int D_rt, int N, int wave_range, const float* __
         e_off[nt] = (valid ? comp : NB) * SM_RS + 4 * q;
         mu[nt] = (valid && j < D) ? packed[(size_t)(k0 + comp) * Pack<DP>::STRIDE + j] : 0.f;
     }
-    const int w_begin = min(N, (blockIdx.y * 4 + wave) * wave_range);
+    const int w_begin = min(N, (range_id * 4 + wave) * wave_range);
     const int w_end = min(N, w_begin + wave_range);
 
     // log importance weight of (component slot c, sample n0 + lane).  Samples / components beyond the range are CLAMPED to
@@ -425,9 +431,9 @@ void stein_moment_kernel(int K, int D_rt, int N, int wave_range, const float* __
     for (int el = tid; el < nb * DD; el += 256) {
         const int comp = el / DD, rem = el - comp * DD;
         const int i = rem / D1, j = rem - i * D1;
-        part[((size_t)(k0 + comp) * R + blockIdx.y) * DD + rem] = C[i * CW + comp * D1 + j];
+        part[((size_t)(k0 + comp) * R + range_id) * DD + rem] = C[i * CW + comp * D1 + j];
     }
-    if (tid < nb) part_m[(size_t)(k0 + tid) * R + blockIdx.y] = Mall[tid];
+    if (tid < nb) part_m[(size_t)(k0 + tid) * R + range_id] = Mall[tid];
 }
 
 template <int DP, int VW>
@@ -462,9 +468,10 @@ static int launch_stein_moment(gmmvi_ctx* ctx, int K, int D, const float* packed
     }
     {
         GMMVI_PROF(ctx, "stein_partial");
-        hipLaunchKernelGGL((stein_moment_kernel<DP, VW>), dim3(stacks, R), dim3(256), shmem, ctx->stream, K, D, N, wave_range,
-                           packed, X, tgrad, qgrad, ld, bg, mapping, map_offset, (flags & GMMVI_OWN_SAMPLES_ONLY) ? 1 : 0, part,
-                           part_m);
+        const int per_xcd = (stacks * R + 7) / 8;
+        hipLaunchKernelGGL((stein_moment_kernel<DP, VW>), dim3(8 * per_xcd), dim3(256), shmem, ctx->stream, K, D, N, wave_range,
+                           stacks, R, packed, X, tgrad, qgrad, ld, bg, mapping, map_offset,
+                           (flags & GMMVI_OWN_SAMPLES_ONLY) ? 1 : 0, part, part_m);
     }
     GMMVI_LAUNCH_CHECK(ctx);
     return launch_stein_finalize<DP>(ctx, K, D, R, N, flags, part, part_m, H_neg, g_neg, packed);
