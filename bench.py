@@ -35,6 +35,7 @@ WORKLOADS = {
     "c3": ("gmm", 50, 100, 100),       # BASELINE configs[2]: GMM target D=50, K=100, N=10k
     "c4": ("planar", 10, 200, 100),    # BASELINE configs[3] on one GPU: planar-4, K=200, N=20k
     "ns_more": ("stm", 20, 100, 100, "MORE"),   # north-star shape with the MORE estimator ("ZAMTRON") instead of Stein
+    "c3_more": ("gmm", 50, 100, 100, "MORE"),   # C3 shape with MORE: F = 1326 features per component (tiled Gram + blocked fp64 Cholesky)
     # BASELINE configs[4] per GPU: D=300 single-Gaussian target (make_target_with_scale, gmm.py:148-162), K=512 over 8 GPUs
     # = 64 components per GPU, N = 20k samples/iter; blocked path (csrc/blocked.hip).  No CPU baseline: the oracle's
     # [K,N,D] fp64 temporaries make one iteration take minutes ("C5 infeasible on CPU")

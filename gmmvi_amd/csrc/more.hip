@@ -418,6 +418,381 @@ __global__ __launch_bounds__(1024) void more_solve_kernel(int D, int nb, int n_c
     }
 }
 
+// =====================================================================================================================
+// Large systems (D > 21: F + 1 > 256, up to 2 081 at D = 63).  The Gram matrix no longer fits one workgroup's registers:
+//   more_gram_big_kernel    workgroup = (128 x 128 block of the lower triangle of G, component); it runs over ALL samples
+//                           (fixed order, no partial slabs), builds only the <= 256 feature rows its block needs in the LDS
+//                           image and contracts them with v_mfma_f64_16x16x4_f64, 8 tile pairs per wave; G (fp64, row stride
+//                           LDG = 128 ceil((F+1)/128)) is written straight into global memory.
+//   more_solve_big_kernel   one 1024-thread workgroup per component, fp64, G in global memory (L2-resident): ridge, blocked
+//                           right-looking Cholesky (32-column panels: diagonal block by one wave in LDS, panel rows by one
+//                           thread each, trailing update on 128 x 128 tiles staged in LDS with 4 x 4 outputs per thread), the
+//                           right-hand side rides along as row F; blocked back substitution; un-whitening as the small kernel.
+// =====================================================================================================================
+template <int DP>
+__global__ __launch_bounds__(512) void more_gram_big_kernel(int D, int N, int nblk, int LDG, const float* __restrict__ packed,
+                                                            const float* __restrict__ X, const float* __restrict__ ld,
+                                                            const float* __restrict__ bg, const float* __restrict__ tlp,
+                                                            const float* __restrict__ logq, const int32_t* __restrict__ mapping,
+                                                            int map_offset, int flags, const float* __restrict__ lse,
+                                                            double* __restrict__ G) {
+    using PK = Pack<DP>;
+    extern __shared__ float phi[];                     // [256][PHI_LD] feature rows of the two blocks, then 4 whitened tiles, tab
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = blockIdx.y;
+    int BI = 0;
+    while ((BI + 1) * (BI + 2) / 2 <= (int)blockIdx.x) ++BI;
+    const int BC = (int)blockIdx.x - BI * (BI + 1) / 2;
+    const bool diag = BI == BC;
+    const int T2 = D * (D + 1) / 2;
+    const int F = T2 + D + 1;                          // features; row F carries the reward
+    const bool own_only = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
+    const bool self_norm = (flags & GMMVI_SELF_NORMALIZED) != 0;
+    const float* __restrict__ P = packed + (size_t)k * PK::STRIDE;
+    const float lse_k = self_norm ? lse[k] : 0.f;
+    const int ZS_TILE = (D + 3) * 64;                  // per tile: rows 0..D-1 z, row D ones, D+1 reward, D+2 sqrt(weight)
+    float* zs = phi + 256 * PHI_LD;                    // 4 tiles
+    int* tab = reinterpret_cast<int*>(zs + 4 * ZS_TILE);   // local row (0..255) -> (row ia) | (row ib) << 16 of a zs tile, or -1
+    const int n_rows = diag ? 128 : 256;
+    for (int r = tid; r < 256; r += 512) {
+        const int f = 128 * (r < 128 ? BI : BC) + (r & 127);
+        int code = -1;
+        if (r < n_rows && f <= F) {                                     // least_squares.py:113-124 feature order
+            int ia, ib;
+            if (f < T2) {
+                int i = 0, rem = f;
+                while (rem >= D - i) { rem -= D - i; ++i; }
+                ia = i; ib = i + rem;
+            } else if (f < T2 + D) { ia = f - T2; ib = D; }
+            else if (f == F - 1) { ia = D; ib = D; }
+            else { ia = D + 1; ib = D; }
+            code = ia | (ib << 16);
+        }
+        tab[r] = code;
+    }
+    for (int e = tid; e < 256 * PHI_LD; e += 512) phi[e] = 0.f;         // rows without a feature stay zero
+    __syncthreads();
+
+    // wave w owns the tile pairs q = w + 8 pp: row tile q / 8 of block BI, column tile q % 8 of block BC
+    f64x4 acc[8];
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) acc[pp] = f64x4{0.0, 0.0, 0.0, 0.0};
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int col_base = diag ? 0 : 128;
+    const int n_tiles = (N + 63) / 64;
+    for (int t0 = 0; t0 < n_tiles; t0 += 4) {
+        if (wave < 4 && t0 + wave < n_tiles) {                          // waves 0-3 whiten one tile each (lane = sample)
+            float* zw = zs + wave * ZS_TILE;
+            const int n = (t0 + wave) * 64 + lane;
+            const bool valid = n < N;
+            float x[DP], z[DP];
+#pragma unroll
+            for (int i = 0; i < DP; ++i) x[i] = (valid && i < D) ? X[(size_t)n * D + i] : P[PK::MU + i];
+            more_forward_subst<DP>(P, x, z);
+            float sw = 0.f, rew = 0.f;
+            if (valid) {
+                float a;
+                if (own_only) a = (mapping[n] + map_offset == k) ? 0.f : -3.0e38f;
+                else a = ld[(size_t)k * N + n] - bg[n];
+                if (a > -3.0e38f) sw = __expf(0.5f * (a - lse_k));       // sqrt of the importance weight (:353-358)
+                rew = tlp[n] - logq[n];                                  // ng_estimator.py:346
+            }
+            const bool live = sw > 0.f;
+#pragma unroll
+            for (int i = 0; i < DP; ++i)
+                if (i < D) zw[i * 64 + lane] = live ? z[i] : 0.f;
+            zw[D * 64 + lane] = 1.f;
+            zw[(D + 1) * 64 + lane] = live ? rew : 0.f;
+            zw[(D + 2) * 64 + lane] = live ? sw : 0.f;
+        }
+        __syncthreads();
+        for (int u = 0; u < 4 && t0 + u < n_tiles; ++u) {
+            {
+                const float* zu = zs + u * ZS_TILE;
+                const int n = tid & 63;
+                const float swn = zu[(D + 2) * 64 + n];
+                for (int r = tid >> 6; r < n_rows; r += 8) {
+                    const int t = tab[r];
+                    if (t >= 0) phi[r * PHI_LD + n] = (swn * zu[(t & 0xffff) * 64 + n]) * zu[(t >> 16) * 64 + n];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp) {
+                const int q = wave + 8 * pp;
+                const float* pa = phi + (16 * (q >> 3) + r16) * PHI_LD + 4 * kg;
+                const float* pb = phi + (col_base + 16 * (q & 7) + r16) * PHI_LD + 4 * kg;
+                float4 av[4], bv[4];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    av[qq] = *reinterpret_cast<const float4*>(pa + 16 * qq);
+                    bv[qq] = *reinterpret_cast<const float4*>(pb + 16 * qq);
+                }
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    acc[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[qq].x, (double)bv[qq].x, acc[pp], 0, 0, 0);
+                    acc[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[qq].y, (double)bv[qq].y, acc[pp], 0, 0, 0);
+                    acc[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[qq].z, (double)bv[qq].z, acc[pp], 0, 0, 0);
+                    acc[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)av[qq].w, (double)bv[qq].w, acc[pp], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // D[i][j] of the fp64 MFMA: lane l, register r -> i = 4 r + l / 16, j = l % 16
+    double* Gk = G + (size_t)k * LDG * LDG;
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) {
+        const int q = wave + 8 * pp;
+        const int ti = q >> 3, tj = q & 7;
+        if (diag && tj > ti) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gi = 128 * BI + 16 * ti + 4 * r + kg, gj = 128 * BC + 16 * tj + r16;
+            Gk[(size_t)gi * LDG + gj] = acc[pp][r];
+        }
+    }
+}
+
+// One workgroup per component; see the banner above.  G: [LDG][LDG] fp64, lower triangle + row F valid on entry.
+__global__ __launch_bounds__(1024) void more_solve_big_kernel(int D, int LDG, double* __restrict__ Gall,
+                                                              const float* __restrict__ chols, const float* __restrict__ l2,
+                                                              float* __restrict__ H_neg, float* __restrict__ g_neg,
+                                                              double* __restrict__ beta_all) {
+    extern __shared__ double smd[];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    const int k = blockIdx.x;
+    const int T2 = D * (D + 1) / 2;
+    const int F = T2 + D + 1;
+    double* G = Gall + (size_t)k * LDG * LDG;
+    double* beta = beta_all + (size_t)k * LDG;
+    double* Pi = smd;                                  // [128][33] panel rows of the row tile
+    double* Pc = smd + 128 * 33;                       // [128][33] panel rows of the column tile
+    double* Db = smd + 2 * 128 * 33;                   // [32][33] diagonal block
+    double* red = Db + 32 * 33;                        // [32][33] reduction scratch
+    const double ridge = (double)l2[k];
+    for (int i = tid; i < F - 1; i += 1024) G[(size_t)i * LDG + i] += ridge;      // least_squares.py:71-73 (bias unregularised)
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+
+    // ---- blocked right-looking Cholesky of the leading F x F block; row F (the right-hand side) rides along ------------------
+    for (int jb = 0; jb < F; jb += 32) {
+        const int nbc = min(32, F - jb);
+        // diagonal block -> LDS, factorised by the first wave (lane = row)
+        for (int e = tid; e < 32 * 32; e += 1024) {
+            const int i = e >> 5, c = e & 31;
+            Db[i * 33 + c] = (i < nbc && c <= i) ? G[(size_t)(jb + i) * LDG + jb + c] : (i == c ? 1.0 : 0.0);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int i = tid & 31;
+            for (int j = 0; j < nbc; ++j) {
+                const double d = Db[j * 33 + j];
+                if (!(d > 0.0)) { if (tid == 0) s_fail = 1; break; }            // uniform within the wave
+                const double rs = 1.0 / sqrt(d);
+                double lij = 0.0;
+                if (tid < 32 && i >= j) { lij = Db[i * 33 + j] * rs; Db[i * 33 + j] = lij; }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (tid < 32 && i > j)
+                    for (int c = j + 1; c <= i; ++c) Db[i * 33 + c] -= lij * Db[c * 33 + j];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        if (s_fail) break;
+        for (int e = tid; e < 32 * 32; e += 1024) {
+            const int i = e >> 5, c = e & 31;
+            if (i < nbc && c <= i) G[(size_t)(jb + i) * LDG + jb + c] = Db[i * 33 + c];
+        }
+        // panel rows i > jb + nbc - 1 (up to the right-hand side row F): x = a L_jj^-T, one thread per row
+        for (int i = jb + nbc + tid; i <= F; i += 1024) {
+            double x[32];
+            double* row = G + (size_t)i * LDG + jb;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) x[c] = (c < nbc) ? row[c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+                double t = x[c];
+#pragma unroll
+                for (int u = 0; u < c; ++u) t = fma(-x[u], Db[c * 33 + u], t);
+                x[c] = t / Db[c * 33 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 32; ++c)
+                if (c < nbc) row[c] = x[c];
+        }
+        __threadfence_block();
+        __syncthreads();
+        // trailing update G[i][c] -= sum_t P[i][t] P[c][t] for jb + nbc <= c <= i <= F, c < F: 128 x 128 tiles, 4 x 4 per thread
+        const int r0 = jb + nbc;
+        const int nt = (F + 1 - r0 + 127) / 128;
+        const int ty = tid >> 5, tx = tid & 31;                         // rows 4 ty .. 4 ty + 3, columns tx, tx + 32, tx + 64, tx + 96
+        for (int ib = 0; ib < nt; ++ib) {
+            for (int cbk = 0; cbk <= ib; ++cbk) {
+                for (int e = tid; e < 128 * 32; e += 1024) {
+                    const int rr = e >> 5, t = e & 31;
+                    const int gi = r0 + 128 * ib + rr, gc = r0 + 128 * cbk + rr;
+                    Pi[rr * 33 + t] = (gi <= F && t < nbc) ? G[(size_t)gi * LDG + jb + t] : 0.0;
+                    Pc[rr * 33 + t] = (gc < F && t < nbc) ? G[(size_t)gc * LDG + jb + t] : 0.0;
+                }
+                __syncthreads();
+                double a[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) a[u][v] = 0.0;
+                for (int t = 0; t < 32; ++t) {
+                    double pi[4], pc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { pi[u] = Pi[(4 * ty + u) * 33 + t]; pc[u] = Pc[(tx + 32 * u) * 33 + t]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) a[u][v] = fma(pi[u], pc[v], a[u][v]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int gi = r0 + 128 * ib + 4 * ty + u, gc = r0 + 128 * cbk + tx + 32 * v;
+                        if (gi <= F && gc < F && gc <= gi) G[(size_t)gi * LDG + gc] -= a[u][v];
+                    }
+                __syncthreads();
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    const bool fail = s_fail != 0;
+    __syncthreads();
+    if (!fail) {
+        // ---- back substitution L^T beta = y (y = row F), 32 columns per round -----------------------------------------------
+        for (int jb = ((F - 1) / 32) * 32; jb >= 0; jb -= 32) {
+            const int nbc = min(32, F - jb);
+            // part[c] = sum_{i >= jb + nbc} L[i][jb + c] beta[i]: thread (c = tid % 32, rows tid / 32, + 32, ...)
+            {
+                const int c = tid & 31, rr = tid >> 5;
+                double part = 0.0;
+                if (c < nbc)
+                    for (int i = jb + nbc + rr; i < F; i += 32) part = fma(G[(size_t)i * LDG + jb + c], beta[i], part);
+                red[rr * 33 + c] = part;
+            }
+            for (int e = tid; e < 32 * 32; e += 1024) {
+                const int i = e >> 5, c = e & 31;
+                Db[i * 33 + c] = (i < nbc && c <= i) ? G[(size_t)(jb + i) * LDG + jb + c] : (i == c ? 1.0 : 0.0);
+            }
+            __syncthreads();
+            if (tid < 32) {
+                double rc = 0.0;
+                if (tid < nbc) {
+                    double p = 0.0;
+                    for (int rr = 0; rr < 32; ++rr) p += red[rr * 33 + tid];
+                    rc = G[(size_t)F * LDG + jb + tid] - p;
+                }
+                for (int jj = nbc - 1; jj >= 0; --jj) {
+                    const double bj = __shfl(rc, jj, 32) / Db[jj * 33 + jj];
+                    if (tid == jj) beta[jb + jj] = bj;
+                    if (tid < jj) rc = fma(-Db[jj * 33 + tid], bj, rc);
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        // ---- un-whitening (least_squares.py:177-189, ng_estimator.py:371-373), as the small kernel ---------------------------
+        double* Ls = smd;
+        double* Qs = Ls + D * D;
+        double* Xs = Qs + D * (D + 1);
+        for (int e = tid; e < D * D; e += 1024) Ls[e] = (double)chols[(size_t)k * D * D + e];
+        for (int e = tid; e < D * (D + 1); e += 1024) {
+            const int i = e / (D + 1), j = e % (D + 1);
+            double v;
+            if (j == D) v = beta[T2 + i];                                            // lin_w
+            else {
+                const int a = min(i, j), b = max(i, j);
+                const double q = beta[a * D - a * (a - 1) / 2 + (b - a)];
+                v = (a == b) ? -2.0 * q : -q;
+            }
+            Qs[e] = v;
+        }
+        __syncthreads();
+        if (tid <= D) {                                                             // X = L_o^-T [Q_w | lin_w]   (lane = column)
+            for (int i = D - 1; i >= 0; --i) {
+                double t = Qs[i * (D + 1) + tid];
+                for (int j = i + 1; j < D; ++j) t = fma(-Ls[j * D + i], Xs[j * (D + 1) + tid], t);
+                Xs[i * (D + 1) + tid] = t / Ls[i * D + i];
+            }
+        }
+        __syncthreads();
+        if (tid < D) {                                                              // H = X L_o^-1, g = -L_o^-T lin_w
+            double* hrow = Qs + tid * (D + 1);
+            for (int i = D - 1; i >= 0; --i) {
+                double t = Xs[tid * (D + 1) + i];
+                for (int j = i + 1; j < D; ++j) t = fma(-Ls[j * D + i], hrow[j], t);
+                hrow[i] = t / Ls[i * D + i];
+            }
+            for (int i = 0; i < D; ++i) H_neg[((size_t)k * D + tid) * D + i] = (float)hrow[i];
+            g_neg[(size_t)k * D + tid] = (float)(-Xs[tid * (D + 1) + D]);
+        }
+    } else {
+        const float nanv = __int_as_float(0x7fc00000);
+        for (int e = tid; e < D * D; e += 1024) H_neg[(size_t)k * D * D + e] = nanv;
+        for (int e = tid; e < D; e += 1024) g_neg[(size_t)k * D + e] = nanv;
+    }
+}
+
+template <int DP>
+int launch_more_big(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* chols, const float* X, int N,
+                    const float* ld, const float* logq, const float* bg, const float* tlp, const int32_t* mapping,
+                    int map_offset, int flags, const float* l2, float* H_neg, float* g_neg) {
+    const int F = D * (D + 1) / 2 + D + 1;
+    const int nblk = (F + 1 + 127) / 128;
+    const int LDG = 128 * nblk;
+    const size_t g_doubles = (size_t)K * LDG * LDG, b_doubles = (size_t)K * LDG;
+    int rc = gmmvi_ws_reserve(ctx, (g_doubles + b_doubles) * sizeof(double) + (size_t)K * sizeof(float));
+    if (rc != GMMVI_OK) return rc;
+    double* G = (double*)ctx->ws;
+    double* beta = G + g_doubles;
+    float* lse = (float*)(beta + b_doubles);
+    if (flags & GMMVI_SELF_NORMALIZED) {
+        GMMVI_PROF(ctx, "more_lse");
+        hipLaunchKernelGGL(more_lse_kernel, dim3(K), dim3(1024), 0, ctx->stream, N, ld, bg, mapping, map_offset, flags, lse);
+        GMMVI_LAUNCH_CHECK(ctx);
+    }
+    const size_t gram_lds = ((size_t)256 * PHI_LD + (size_t)4 * (D + 3) * 64 + 256) * sizeof(float);
+    static size_t gram_attr = 0;
+    if (gram_lds > gram_attr) {
+        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)more_gram_big_kernel<DP>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)gram_lds));
+        gram_attr = gram_lds;
+    }
+    {
+        GMMVI_PROF(ctx, "more_gram");
+        hipLaunchKernelGGL((more_gram_big_kernel<DP>), dim3(nblk * (nblk + 1) / 2, K), dim3(512), gram_lds, ctx->stream, D, N,
+                           nblk, LDG, packed, X, ld, bg, tlp, logq, mapping, map_offset, flags, lse, G);
+        GMMVI_LAUNCH_CHECK(ctx);
+    }
+    size_t solve_doubles = (size_t)2 * 128 * 33 + 2 * 32 * 33;
+    const size_t unwhiten = (size_t)D * D + 2 * (size_t)D * (D + 1);
+    if (unwhiten > solve_doubles) solve_doubles = unwhiten;
+    const size_t solve_lds = solve_doubles * sizeof(double);
+    static size_t solve_attr = 0;
+    if (solve_lds > solve_attr) {
+        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)more_solve_big_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
+        solve_attr = solve_lds;
+    }
+    GMMVI_PROF(ctx, "more_solve");
+    hipLaunchKernelGGL(more_solve_big_kernel, dim3(K), dim3(1024), solve_lds, ctx->stream, D, LDG, G, chols, l2, H_neg, g_neg,
+                       beta);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
 // workgroups per launch that fill the chip in whole rounds: the count c in [lo, hi] maximising c K / (ceil(c K / cus) cus)
 static int more_pick_chunks(int K, int cus, int tiles) {
     int best = 1; double best_eff = 0.0;
@@ -481,14 +856,27 @@ extern "C" int gmmvi_more(gmmvi_ctx* ctx, int K, int D, const float* packed_dev,
                           const float* tlp_dev, const int32_t* mapping_dev, int map_offset, int flags,
                           const float* l2_dev, float* H_neg_out_dev, float* g_neg_out_dev) {
     GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && N >= 1);
-    if (D > GMMVI_MORE_MAX_DIM)
-        return gmmvi_fail(ctx, GMMVI_ERR_ARG, "gmmvi_more: D must be <= 21 (the F x F ridge system is solved in LDS)");
+    GMMVI_ARG_CHECK(ctx, D < GMMVI_MAX_DIM);
     GMMVI_ARG_CHECK(ctx, packed_dev && chols_dev && X_dev && logq_dev && tlp_dev && l2_dev && H_neg_out_dev && g_neg_out_dev);
     if (flags & GMMVI_OWN_SAMPLES_ONLY) GMMVI_ARG_CHECK(ctx, mapping_dev != nullptr);
     else GMMVI_ARG_CHECK(ctx, ld_dev && bg_dev);
 #define GMMVI_MORE_CASE(DPV, PPV)                                                                                    \
     return launch_more<DPV, PPV>(ctx, K, D, packed_dev, chols_dev, X_dev, N, ld_dev, logq_dev, bg_dev, tlp_dev,      \
                                  mapping_dev, map_offset, flags, l2_dev, H_neg_out_dev, g_neg_out_dev)
+    if (D > GMMVI_MORE_REGISTER_MAX_DIM) {            // the ridge system no longer fits one workgroup's registers: tiled route
+#define GMMVI_MORE_BIG(DPV)                                                                                          \
+    return launch_more_big<DPV>(ctx, K, D, packed_dev, chols_dev, X_dev, N, ld_dev, logq_dev, bg_dev, tlp_dev,       \
+                                mapping_dev, map_offset, flags, l2_dev, H_neg_out_dev, g_neg_out_dev)
+        switch (gmmvi_padded_dim(D)) {
+            case 24: GMMVI_MORE_BIG(24);
+            case 32: GMMVI_MORE_BIG(32);
+            case 40: GMMVI_MORE_BIG(40);
+            case 50: GMMVI_MORE_BIG(50);
+            case 64: GMMVI_MORE_BIG(64);
+            default: return gmmvi_fail(ctx, GMMVI_ERR_ARG, "gmmvi_more: unsupported dimension");
+        }
+#undef GMMVI_MORE_BIG
+    }
     switch (gmmvi_padded_dim(D)) {
         case 2: GMMVI_MORE_CASE(2, 1);
         case 4: GMMVI_MORE_CASE(4, 1);

@@ -206,6 +206,31 @@ def test_more(ctx, rng, k, d, n, snis):
     assert np.all(np.abs(g - rg) <= 2e-3 * scale_g + 1e-5), np.abs(g - rg).max() / scale_g.max()
 
 
+@pytest.mark.parametrize("k,d,n", [(2, 24, 2600), (2, 32, 4200), (2, 50, 9000), (1, 37, 5500)])
+@pytest.mark.parametrize("snis", [True, False])
+def test_more_beyond_the_register_resident_system(ctx, rng, k, d, n, snis):
+    """D > 21: F + 1 = 326 ... 1 327 features -- the tiled fp64 Gram launch and the blocked fp64 Cholesky in global memory
+    (csrc/more.hip, more_gram_big / more_solve_big) against the oracle, well-posed regime (N several times F), ridge 1e-6."""
+    from oracle import more as omore
+    m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    xd = ctx.asarray(x)
+    ld, lp, _ = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_lp=True)
+    l2 = np.full(k, 1e-6)
+    h, g = ops().more(ctx, packed, chols, xd, ld, lp, ctx.asarray(bg), ctx.asarray(tlp), ctx.asarray(l2), d,
+                      self_normalized=snis)
+    rh, rg = omore.get_expected_hessian_and_grad(m, l2, x, mapping, bg, tlp, False, snis)
+    h, g = h.numpy(), g.numpy()
+    assert np.all(np.isfinite(h)) and np.all(np.isfinite(g))
+    scale_h = np.abs(rh).max(axis=(1, 2), keepdims=True)
+    scale_g = np.abs(rg).max(axis=1, keepdims=True)
+    # the fp32 inputs of the regression (z, weights, rewards) carry ~1e-6 relative error that the ridge solution of a larger
+    # system amplifies more than at D = 20: 1e-2 of the per-component magnitude
+    assert np.all(np.abs(h - rh) <= 1e-2 * scale_h + 1e-5), np.abs(h - rh).max() / scale_h.max()
+    assert np.all(np.abs(g - rg) <= 1e-2 * scale_g + 1e-5), np.abs(g - rg).max() / scale_g.max()
+
+
 @pytest.mark.parametrize("k,d,n", [(2, 10, 40), (3, 20, 150), (4, 20, 240)])
 def test_more_fewer_samples_than_features(ctx, rng, k, d, n):
     """Rank-deficient ridge systems (N < F = D(D+1)/2 + D + 1), the state early in a run.  With a ridge that fp64 resolves

@@ -101,7 +101,7 @@ def test_non_self_normalised_and_own_samples():
     run_pair("gmm", 3, 3, 60, seed=5, iters=4, cfg=samtron_config(60, own=True, initial_stepsize=0.05))
 
 
-@pytest.mark.parametrize("kind,d,k,s", [("gmm", 4, 3, 120), ("stm", 10, 4, 300)])
+@pytest.mark.parametrize("kind,d,k,s", [("gmm", 4, 3, 120), ("stm", 10, 4, 300), ("gmm", 24, 2, 1500)])
 def test_more_estimator_trajectory(kind, d, k, s):
     """MORE ("Z...") instead of Stein: fp32 normal equations carry ~1e-3 relative error into (H, g) per iteration."""
     cfg = samtron_config(s, estimator="MORE", initial_stepsize=0.05)
