@@ -111,7 +111,6 @@ __global__ __launch_bounds__(64) void cholesky_kernel(int D, const float* __rest
 // ---------------------------------------------------------------------------------------------------------------
 // mixture_eval
 // ---------------------------------------------------------------------------------------------------------------
-// LDSFEED: component blocks through a wave-private LDS copy (else scalar loads from global memory).
 // gridDim.y > 1: the components are split over blockIdx.y; lp_out / grad_out then receive per-chunk partials
 // ([chunk][N], [chunk][N][D]) that combine_partials merges.
 #ifndef GMMVI_ME_THREADS
@@ -123,7 +122,7 @@ __global__ __launch_bounds__(64) void cholesky_kernel(int D, const float* __rest
 #ifndef GMMVI_ME_WIDE_DP
 #define GMMVI_ME_WIDE_DP 40
 #endif
-template <int DP, int FAMILY, bool GRAD, bool LDSFEED>
+template <int DP, int FAMILY, bool GRAD>
 __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GMMVI_ME_MINW) void mixture_eval_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
                                                             const float* __restrict__ logw, const float* __restrict__ X,
                                                             int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
@@ -146,9 +145,7 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
     const int n_here = min(64, N - n0);
     const int n = n0 + lane;
     const bool valid = lane < n_here;
-    // LDS: [nwaves][STRIDE] wave-private component blocks, then the merge / staging area
-    float* Pw = sm + (size_t)wave * PK::STRIDE;
-    float* sm_merge = sm + (LDSFEED ? (size_t)nwaves * PK::STRIDE : 0);
+    float* sm_merge = sm;                              // staging, then the merge area
 
     // ---- x tile: coalesced load staged through LDS (rows of a row-major [N, D] array are 4D bytes apart) -----------
     const int ldx = D | 1;
@@ -169,21 +166,9 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
     }
     const float nud = nu + (float)D;
 
-    // component blocks: coalesced global loads one component ahead (registers), then a wave-private LDS copy that the
-    // unrolled substitution reads with broadcast ds_read_b128
-    PackStager<DP> stager;
-    if (LDSFEED && k_lo + wave < K) stager.prefetch(packed, k_lo + wave, lane);
     for (int k = k_lo + wave; k < K; k += nwaves) {
         PackRef P;
-        if (LDSFEED) {
-            stager.commit(Pw, lane);
-            if (k + nwaves < K) stager.prefetch(packed, k + nwaves, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            P.p = reinterpret_cast<const float4*>(Pw);
-        } else {
-            P.p = reinterpret_cast<const float4*>(packed + (size_t)k * PK::STRIDE);
-        }
+        P.p = reinterpret_cast<const float4*>(packed + (size_t)k * PK::STRIDE);
         const float lw = logw[k];
         float z[DP], q;
         forward_subst<DP>(P, x, z, q);
@@ -214,10 +199,6 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
             const float ec = e * coef;
 #pragma unroll
             for (int i = 0; i < DP; ++i) acc[i] = fmaf(acc[i], sc, ec * y[i]);
-        }
-        if (LDSFEED) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
         }
     }
     if (lp_out == nullptr && !GRAD) return;
@@ -594,18 +575,16 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     if constexpr (PK::FRAGS) {
         if constexpr (DP >= 40) return launch_mixture_eval_mfma<DP, 2>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
         else return launch_mixture_eval_mfma<DP, 4>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
-    }
+    } else {
     const bool want_grad = grad != nullptr;
     const bool want_merge = want_grad || lp != nullptr;
-    static const int env_feed = getenv("GMMVI_ME_FEED") ? atoi(getenv("GMMVI_ME_FEED")) : 0;
     static const int env_nw = getenv("GMMVI_ME_NW") ? atoi(getenv("GMMVI_ME_NW")) : 0;
     static const int env_ky = getenv("GMMVI_ME_KY") ? atoi(getenv("GMMVI_ME_KY")) : 0;
-    const bool lds_feed = env_feed != 0;
     auto lds_floats = [&](int nw) {
         size_t merge = (size_t)nw * 64 * ((want_grad ? DP : 0) + 2) + (want_grad ? 64 * (size_t)(D | 1) : 0) +
                        (logw2 ? (size_t)nw * 128 : 0);
         size_t stage = 64 * (size_t)(D | 1);
-        return (lds_feed ? (size_t)nw * PK::STRIDE : 0) + (merge > stage ? merge : stage);
+        return merge > stage ? merge : stage;
     };
     const int tiles = (N + 63) / 64;
     // geometry: ky chunks of components over blockIdx.y (partials merged by combine_partials), nw waves per workgroup.
@@ -642,21 +621,19 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     dim3 grid(tiles, ky), block(nw * 64);
     {
         GMMVI_PROF_UNITS(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval", (double)N * K);
-#define GMMVI_LAUNCH_ME(FAM, G, F)                                                                                  \
+#define GMMVI_LAUNCH_ME(FAM, G)                                                                                     \
     do {                                                                                                            \
         if (shmem > 64 * 1024)                                                                                      \
-            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_kernel<DP, FAM, G, F>,               \
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_kernel<DP, FAM, G>,               \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
-        hipLaunchKernelGGL((mixture_eval_kernel<DP, FAM, G, F>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
+        hipLaunchKernelGGL((mixture_eval_kernel<DP, FAM, G>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
                            logw, X, N, ld, lp_k, grad_k, logw2, lp2_k);                                               \
     } while (0)
-#define GMMVI_LAUNCH_ME2(FAM, G) do { if (lds_feed) GMMVI_LAUNCH_ME(FAM, G, true); else GMMVI_LAUNCH_ME(FAM, G, false); } while (0)
         if (family == GMMVI_GAUSS) {
-            if (want_grad) GMMVI_LAUNCH_ME2(GMMVI_GAUSS, true); else GMMVI_LAUNCH_ME2(GMMVI_GAUSS, false);
+            if (want_grad) GMMVI_LAUNCH_ME(GMMVI_GAUSS, true); else GMMVI_LAUNCH_ME(GMMVI_GAUSS, false);
         } else {
-            if (want_grad) GMMVI_LAUNCH_ME2(GMMVI_STUDENT_T, true); else GMMVI_LAUNCH_ME2(GMMVI_STUDENT_T, false);
+            if (want_grad) GMMVI_LAUNCH_ME(GMMVI_STUDENT_T, true); else GMMVI_LAUNCH_ME(GMMVI_STUDENT_T, false);
         }
-#undef GMMVI_LAUNCH_ME2
 #undef GMMVI_LAUNCH_ME
     }
     GMMVI_LAUNCH_CHECK(ctx);
@@ -666,6 +643,7 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         if (rc != GMMVI_OK) return rc;
     }
     return GMMVI_OK;
+    }
 }
 
 extern "C" {

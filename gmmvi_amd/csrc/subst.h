@@ -41,25 +41,3 @@ __device__ __forceinline__ void backward_subst(const PackRef P, const float (&z)
         y[i] = t * P[PK::RD + i];
     }
 }
-
-// Coalesced copy of one component block into a wave-private LDS slot, one component ahead of its use.
-template <int DP>
-struct PackStager {
-    using PK = Pack<DP>;
-    static constexpr int NPF = (PK::STRIDE + 63) / 64;
-    float pf[NPF];
-    __device__ __forceinline__ void prefetch(const float* __restrict__ packed, int k, int lane) {
-#pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            const int idx = lane + 64 * j;
-            pf[j] = (idx < PK::STRIDE) ? packed[(size_t)k * PK::STRIDE + idx] : 0.f;
-        }
-    }
-    __device__ __forceinline__ void commit(float* slot, int lane) const {
-#pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            const int idx = lane + 64 * j;
-            if (idx < PK::STRIDE) slot[idx] = pf[j];
-        }
-    }
-};

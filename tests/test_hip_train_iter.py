@@ -89,6 +89,13 @@ def test_north_star_full_size():
     assert f.sample_db.samples.shape == (20000, 20)
 
 
+def test_planar_config_full_size():
+    """BASELINE configs[3] at full size on one GPU (planar-4 target, D = 10, K = 200, 100 samples per component = 20 000
+    samples per iteration): two iterations against the fp64 oracle, single-call path."""
+    cfg = samtron_config(100)
+    run_pair("planar", 10, 200, 100, seed=37, iters=2, cfg=cfg, fused=True)
+
+
 @pytest.mark.parametrize("updater,wupd", [("direct", "direct"), ("iBLR", "trust-region")])
 def test_other_design_choices(updater, wupd):
     cfg = samtron_config(40, initial_stepsize=0.01, updater=updater, weight_updater=wupd, wstep=0.05)

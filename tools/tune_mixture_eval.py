@@ -1,5 +1,5 @@
 """Developer tool: times gmmvi_mixture_eval at the north-star shape for one (feed, waves/block, K-chunks) geometry taken
-from the environment (GMMVI_ME_FEED / GMMVI_ME_NW / GMMVI_ME_KY).  Driven by tools/tune.sh on the GPU box."""
+from the environment (GMMVI_ME_NW / GMMVI_ME_KY).  Driven by tools/tune.sh on the GPU box."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,5 +26,5 @@ def bench(**kw):
     ctx.record(e1)
     return ctx.elapsed_ms(e0, e1) / 50 * 1e3
 
-print(os.environ.get("GMMVI_ME_FEED", "0"), os.environ.get("GMMVI_ME_NW", "-"), os.environ.get("GMMVI_ME_KY", "-"),
+print(os.environ.get("GMMVI_ME_NW", "-"), os.environ.get("GMMVI_ME_KY", "-"),
       "nograd %.1f us" % bench(want_ld=True, want_lp=True), "grad %.1f us" % bench(want_ld=True, want_lp=True, want_grad=True))
