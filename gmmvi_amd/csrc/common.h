@@ -80,6 +80,17 @@ int gmmvi_sample_components_prep(gmmvi_ctx* ctx, int K, int D, const float* mean
 int gmmvi_combine_partials_internal(gmmvi_ctx* ctx, int R, int N, int D, const float* lp_parts_dev,
                                     const float* grad_parts_dev, float* lp_out_dev, float* grad_out_dev,
                                     const float* lp2_parts_dev, float* lp2_out_dev);
+// stein.hip / update_kl.hip: the Stein estimate split at the partial slab (single-call iteration, fused.hip)
+struct SteinSlab;
+int gmmvi_stein_partials(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* X_dev, int N, const float* ld_dev,
+                         const float* qgrad_dev, const float* bg_dev, const float* tgrad_dev, int flags, SteinSlab* slab);
+int gmmvi_stein_finalize_slab(gmmvi_ctx* ctx, int K, int D, const SteinSlab& slab, int N, int flags, const float* packed_dev,
+                              float* H_neg_out_dev, float* g_neg_out_dev);
+int gmmvi_update_components_kl_from_slab(gmmvi_ctx* ctx, int K, int D, const SteinSlab& slab, int N, int stein_flags,
+                                         const float* packed_old_dev, float* H_neg_dev, float* g_neg_dev, float* means_dev,
+                                         float* chols_dev, const float* stepsizes_dev, float temperature, float l2_init,
+                                         float* last_eta_dev, float* l2_dev, float* num_received_updates_dev,
+                                         int32_t* success_out_dev, float* packed_out_dev);
 // weights.hip: trust-region (mode 0) / direct (mode 1) weight update; exp_out (optional) receives exp(new log weights)
 int gmmvi_update_weights_internal(gmmvi_ctx* ctx, int mode, int K, float* logw_dev, const float* E_dev,
                                   const float* stepsize_dev, float beta, float* kl_eta_out_dev, float* exp_out_dev);

@@ -8,6 +8,7 @@
 #include "common.h"
 #include "stepsize_rules.h"
 #include "iter_prep.h"
+#include "stein_finalize.h"
 
 namespace {
 struct Arena {
@@ -89,11 +90,13 @@ extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan
     GMMVI_TRY(gmmvi_mixture_eval_dual(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, p->logw, p->bg_logw, x, N, a.ld, a.lq, a.qgrad,
                                       a.bg));
     // ---- component update (gmmvi.py:165-169) -----------------------------------------------------------------------------
-    GMMVI_TRY(gmmvi_stein(ctx, K, D, p->packed, x, N, a.ld, a.qgrad, a.bg, p->db_tgrad, nullptr, 0, p->stein_flags, a.H,
-                          a.g));
-    GMMVI_TRY(gmmvi_update_components_kl(ctx, K, D, p->means, p->chols, a.H, a.g, p->stepsizes, p->temperature, p->l2_init,
-                                         p->last_eta, p->l2, p->num_updates, p->success_out ? p->success_out : a.success,
-                                         nullptr, nullptr, p->packed_new));
+    // the Stein estimate stops at its partial slab; its last step (slab sum, Sigma^-1, normalisation) is the prologue of the
+    // update kernel where that is instantiated, the stand-alone launch otherwise -- the same arithmetic either way
+    SteinSlab slab{nullptr, nullptr, 0};
+    GMMVI_TRY(gmmvi_stein_partials(ctx, K, D, p->packed, x, N, a.ld, a.qgrad, a.bg, p->db_tgrad, p->stein_flags, &slab));
+    GMMVI_TRY(gmmvi_update_components_kl_from_slab(ctx, K, D, slab, N, p->stein_flags, p->packed, a.H, a.g, p->means, p->chols,
+                                                   p->stepsizes, p->temperature, p->l2_init, p->last_eta, p->l2, p->num_updates,
+                                                   p->success_out ? p->success_out : a.success, p->packed_new));
     // ---- weight update (gmmvi.py:172-173) ---------------------------------------------------------------------------------
     GMMVI_TRY(gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed_new, p->logw, x, N, a.ld, a.lq, nullptr));
     GMMVI_TRY(gmmvi_expected_log_ratios(ctx, K, N, a.ld, a.bg, p->db_tlp, a.lq, p->temperature, p->logw,

@@ -10,147 +10,35 @@
 #include "common.h"
 #include "blocked.h"
 #include "wave_reduce.h"
+#include "stein_finalize.h"
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_max(float v) { return gmmvi_wave_max(v); }
 
-// One workgroup per component: sums the R per-range partials of A_k (each referred to its own maximum m_r) in fixed order,
-// applies Sigma_k^-1 = L^-T L^-1 from the right to the D x D block, normalises, symmetrises, negates.  Small blocks (no L^-1
-// fragments): row i of the result by substitution, h' L^T = t ascending over the rows of L, then h L = h' descending over its
-// columns (L from the packed block: 1/diag, rows, columns, staged in LDS; the row in registers, loops unrolled for the padded
-// dimension).  Blocks with fragments (DP >= 32): two triangular products with the explicit inverse on all threads.
 template <int DP>
 __global__ __launch_bounds__(1024) void stein_finalize_kernel(int D, int R, int N, int flags, const float* __restrict__ part,
                                                              const float* __restrict__ part_m, float* __restrict__ H_neg,
                                                              float* __restrict__ g_neg, const float* __restrict__ packed) {
-    using PK = Pack<DP>;
-    extern __shared__ float A[];       // (D+1)^2, then R scale factors
-    const int k = blockIdx.x;
-    const int D1 = D + 1;
-    float* scale_r = A + D1 * D1;
-    float M = -3.0e38f;
-    for (int r = threadIdx.x & 63; r < R; r += 64) M = fmaxf(M, part_m[(size_t)k * R + r]);
-    M = wave_max(M);
-    for (int r = threadIdx.x; r < R; r += blockDim.x) scale_r[r] = __expf(part_m[(size_t)k * R + r] - M);
-    __syncthreads();
-    // partial sums: the R partials of an element are split over G = blockDim / 256 thread groups (r = g, g + G, ...), eight
-    // independent chains per thread keep the loads in flight; the groups are combined through LDS in fixed order
-    const float* pk = part + (size_t)k * R * (size_t)(D1 * D1);
-    const int G = blockDim.x >> 8, g = threadIdx.x >> 8, tl = threadIdx.x & 255;
-    float* Ag = scale_r + R;                                              // [G][(D+1)^2]
-    for (int e = tl; e < D1 * D1; e += 256) {
-        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int r = g;
-        for (; r + 7 * G < R; r += 8 * G) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = fmaf(pk[(size_t)(r + u * G) * (D1 * D1) + e], scale_r[r + u * G], v[u]);
-        }
-        for (int u = 0; r < R; r += G, ++u) v[u & 7] = fmaf(pk[(size_t)r * (D1 * D1) + e], scale_r[r], v[u & 7]);
-        Ag[g * D1 * D1 + e] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < D1 * D1; e += blockDim.x) {
-        float a = 0.f;
-        for (int gg = 0; gg < G; ++gg) a += Ag[gg * D1 * D1 + e];
-        A[e] = a;
-    }
-    __syncthreads();
-    if constexpr (PK::FRAGS) {
-        // blocks that carry L^-1 (operand fragments, common.h): Sigma^-1 from the right as two triangular products spread over
-        // the whole workgroup -- W = T L^-T, then W L^-1 -- instead of two substitution chains on D threads
-        const float* Pk = packed + (size_t)k * PK::STRIDE;
-        float* Li = Ag;                  // dense L^-1 [DP][DP] (the group sums are consumed), then W [D][D]
-        float* W = Ag + DP * DP;
-        for (int e = threadIdx.x; e < DP * DP; e += blockDim.x) Li[e] = 0.f;
-        __syncthreads();
-        for (int e = threadIdx.x; e < 64 * PK::NF; e += blockDim.x) {
-            const int f = e >> 6, l = e & 63;
-            int mt = 0, rem = f;
-            for (;; ++mt) { const int nfm = PK::nf(mt); if (rem < nfm) break; rem -= nfm; }
-            const int row = 16 * mt + (l & 15), col = 4 * rem + (l >> 4);        // the fragments cover 16 MT x 4 KS >= DP x DP
-            if (row < DP && col < DP) Li[row * DP + col] = Pk[PK::FWD + e];
-        }
-        __syncthreads();
-        for (int o = threadIdx.x; o < D * D; o += blockDim.x) {
-            const int a = o / D, i = o - a * D;
-            float w = 0.f;
-            for (int j = 0; j <= i; ++j) w = fmaf(A[a * D1 + j], Li[i * DP + j], w);
-            W[o] = w;
-        }
-        __syncthreads();
-        for (int o = threadIdx.x; o < D * D; o += blockDim.x) {
-            const int a = o / D, i2 = o - a * D;
-            float h = 0.f;
-            for (int i = i2; i < D; ++i) h = fmaf(W[a * D + i], Li[i * DP + i2], h);
-            A[a * D1 + i2] = h;
-        }
-        __syncthreads();
-    } else {
-        const float* Pk = packed + (size_t)k * PK::STRIDE;
-        float* Lc = Ag;                  // the group sums are consumed: reuse as [1/diag (DP) | columns (T) | rows (T)]
-        for (int e = threadIdx.x; e < DP + 2 * PK::T; e += blockDim.x)
-            Lc[e] = (e < DP) ? Pk[PK::RD + e] : (e < DP + PK::T ? Pk[PK::LCOL + (e - DP)] : Pk[PK::LROW + (e - DP - PK::T)]);
-        __syncthreads();
-        if (threadIdx.x < D) {
-            float* row = A + threadIdx.x * D1;
-            float h[DP];
-#pragma unroll
-            for (int j = 0; j < DP; ++j) h[j] = (j < D) ? row[j] : 0.f;
-#pragma unroll
-            for (int j = 0; j < DP; ++j) {                                  // h' L^T = t
-                float t = h[j];
-#pragma unroll
-                for (int m = 0; m < j; ++m) t = fmaf(-h[m], Lc[DP + PK::T + PK::rowofs(j) + m], t);      // padding: L = 0
-                h[j] = t * Lc[j];
-            }
-#pragma unroll
-            for (int j = DP - 1; j >= 0; --j) {                             // h L = h'
-                float t = h[j];
-#pragma unroll
-                for (int m = j + 1; m < DP; ++m) t = fmaf(-h[m], Lc[DP + PK::colofs(j) + (m - j - 1)], t);
-                h[j] = t * Lc[j];
-            }
-#pragma unroll
-            for (int j = 0; j < DP; ++j)
-                if (j < D) row[j] = h[j];
-        }
-        __syncthreads();
-    }
-    const bool snis = (flags & GMMVI_SELF_NORMALIZED) != 0;
-    // A[i][j] = sum e g_i y_j, A[i][D] = sum e g_i, A[D][D] = sum e.
-    // plain importance weights: 1/N * sum exp(ld - bg) v   (ng_estimator.py:146-152), Hessian not symmetrised
-    // with only_use_own_samples the expectation runs over the component's own samples only (get_rewards_for_comp,
-    // ng_estimator.py:110-118: weights exp(0) = 1, divisor = their number): sum e = n_own exp(-M) => exp(M) / n_own = 1 / sum e
-    const bool own = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
-    // self-normalised weights over an EMPTY own-sample set: every reduce_sum of the reference runs over nothing and returns
-    // zeros (ng_estimator.py:171-188), the plain branch divides by the set's length (NaN, a rejected update)
-    const float se = A[D * D1 + D];
-    const float scale = snis ? (se > 0.f ? 1.f / se : 0.f) : (own ? 1.f / se : __expf(M) / (float)N);
-    for (int e = threadIdx.x; e < D * D; e += blockDim.x) {
-        const int i = e / D, j = e % D;
-        const float v = snis ? 0.5f * (A[i * D1 + j] + A[j * D1 + i]) : A[i * D1 + j];
-        H_neg[(size_t)k * D * D + e] = -v * scale;
-    }
-    for (int i = threadIdx.x; i < D; i += blockDim.x) g_neg[(size_t)k * D + i] = -A[i * D1 + D] * scale;
+    extern __shared__ float fin_lds[];
+    stein_finalize_component<DP>(fin_lds, blockIdx.x, D, R, N, flags, part, part_m, H_neg, g_neg, packed);
 }
 
 template <int DP>
 static int launch_stein_finalize(gmmvi_ctx* ctx, int K, int D, int R, int N, int flags, const float* part,
                                  const float* part_m, float* H_neg, float* g_neg, const float* packed) {
-    const int D1 = D + 1;
-    size_t floats = (size_t)5 * D1 * D1 + R;
-    if ((size_t)D1 * D1 + R + DP + 2 * Pack<DP>::T > floats) floats = (size_t)D1 * D1 + R + DP + 2 * Pack<DP>::T;
-    const size_t shmem = floats * sizeof(float);
+    const size_t shmem = stein_finalize_lds_floats(DP, D, R) * sizeof(float);
     static size_t attr = 64 * 1024;
     if (shmem > attr) {
         GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_finalize_kernel<DP>,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         attr = shmem;
     }
+    // the products of the explicit-inverse route use every thread; the substitution route only D of them
+    const int threads = Pack<DP>::FRAGS ? 1024 : 256;
     GMMVI_PROF(ctx, "stein_finalize");
-    hipLaunchKernelGGL(stein_finalize_kernel<DP>, dim3(K), dim3(1024), shmem, ctx->stream, D, R, N, flags, part, part_m, H_neg,
+    hipLaunchKernelGGL(stein_finalize_kernel<DP>, dim3(K), dim3(threads), shmem, ctx->stream, D, R, N, flags, part, part_m, H_neg,
                        g_neg, packed);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
@@ -439,7 +327,7 @@ void stein_moment_kernel(int K, int D_rt, int N, int wave_range, int stacks, int
 template <int DP, int VW>
 static int launch_stein_moment(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
                                const float* qgrad, const float* bg, const float* tgrad, const int32_t* mapping,
-                               int map_offset, int flags, float* H_neg, float* g_neg) {
+                               int map_offset, int flags, float* H_neg, float* g_neg, SteinSlab* slab_out) {
     using ST = SteinTile<DP>;
     const int D1 = D + 1;
     const int stacks = (K + ST::NB - 1) / ST::NB;
@@ -474,12 +362,16 @@ static int launch_stein_moment(gmmvi_ctx* ctx, int K, int D, const float* packed
                            (flags & GMMVI_OWN_SAMPLES_ONLY) ? 1 : 0, part, part_m);
     }
     GMMVI_LAUNCH_CHECK(ctx);
+    if (slab_out != nullptr) {                         // the caller finishes the estimate (update kernel prologue, fused.hip)
+        slab_out->part = part; slab_out->part_m = part_m; slab_out->R = R;
+        return GMMVI_OK;
+    }
     return launch_stein_finalize<DP>(ctx, K, D, R, N, flags, part, part_m, H_neg, g_neg, packed);
 }
 
 static int stein_moment(gmmvi_ctx* ctx, int K, int D, const float* packed, const float* X, int N, const float* ld,
                         const float* qgrad, const float* bg, const float* tgrad, const int32_t* mapping, int map_offset,
-                        int flags, float* H_neg, float* g_neg) {
+                        int flags, float* H_neg, float* g_neg, SteinSlab* slab_out) {
     const int dp = gmmvi_padded_dim(D);
     // fast instance: D is exactly the padded dimension, rows aligned to the widest load their length allows, weights from ld - bg
     const uintptr_t bases = reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(tgrad) | reinterpret_cast<uintptr_t>(qgrad);
@@ -489,8 +381,8 @@ static int stein_moment(gmmvi_ctx* ctx, int K, int D, const float* packed, const
     case DPV:                                                                                                          \
         if (fast)                                                                                                      \
             return launch_stein_moment<DPV, (DPV % 4 == 0 ? 4 : 2)>(ctx, K, D, packed, X, N, ld, qgrad, bg, tgrad, mapping, \
-                                                                    map_offset, flags, H_neg, g_neg);                   \
-        return launch_stein_moment<DPV, 1>(ctx, K, D, packed, X, N, ld, qgrad, bg, tgrad, mapping, map_offset, flags, H_neg, g_neg)
+                                                                    map_offset, flags, H_neg, g_neg, slab_out);         \
+        return launch_stein_moment<DPV, 1>(ctx, K, D, packed, X, N, ld, qgrad, bg, tgrad, mapping, map_offset, flags, H_neg, g_neg, slab_out)
     switch (dp) {
         GMMVI_SM(2); GMMVI_SM(4); GMMVI_SM(8); GMMVI_SM(10); GMMVI_SM(12); GMMVI_SM(16); GMMVI_SM(20); GMMVI_SM(24);
         GMMVI_SM(32); GMMVI_SM(40); GMMVI_SM(50); GMMVI_SM(64);
@@ -512,5 +404,27 @@ extern "C" int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev
         return gmmvi_blocked_stein(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev, mapping_dev,
                                    map_offset, flags, H_neg_out_dev, g_neg_out_dev);
     return stein_moment(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev, mapping_dev, map_offset, flags,
-                        H_neg_out_dev, g_neg_out_dev);
+                        H_neg_out_dev, g_neg_out_dev, nullptr);
+}
+
+// C++ linkage (common.h): the moment matrices only -- the partial slab stays in the context's scratch and the caller finishes
+// the estimate (gmmvi_update_components_kl_from_slab: as the prologue of the update kernel where that is instantiated)
+int gmmvi_stein_partials(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* X_dev, int N, const float* ld_dev,
+                         const float* qgrad_dev, const float* bg_dev, const float* tgrad_dev, int flags, SteinSlab* slab) {
+    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D < GMMVI_MAX_DIM && !gmmvi_is_blocked_dim(D) && N >= 1 && slab != nullptr);
+    GMMVI_ARG_CHECK(ctx, packed_dev && X_dev && qgrad_dev && tgrad_dev && ld_dev && bg_dev && !(flags & GMMVI_OWN_SAMPLES_ONLY));
+    return stein_moment(ctx, K, D, packed_dev, X_dev, N, ld_dev, qgrad_dev, bg_dev, tgrad_dev, nullptr, 0, flags, nullptr, nullptr,
+                        slab);
+}
+
+int gmmvi_stein_finalize_slab(gmmvi_ctx* ctx, int K, int D, const SteinSlab& slab, int N, int flags, const float* packed_dev,
+                              float* H_neg_out_dev, float* g_neg_out_dev) {
+    switch (gmmvi_padded_dim(D)) {
+#define GMMVI_FIN(DPV) case DPV: return launch_stein_finalize<DPV>(ctx, K, D, slab.R, N, flags, slab.part, slab.part_m,       \
+                                                                  H_neg_out_dev, g_neg_out_dev, packed_dev)
+        GMMVI_FIN(2); GMMVI_FIN(4); GMMVI_FIN(8); GMMVI_FIN(10); GMMVI_FIN(12); GMMVI_FIN(16); GMMVI_FIN(20); GMMVI_FIN(24);
+        GMMVI_FIN(32); GMMVI_FIN(40); GMMVI_FIN(50); GMMVI_FIN(64);
+#undef GMMVI_FIN
+        default: return gmmvi_fail(ctx, GMMVI_ERR_ARG, "stein_finalize: unsupported dimension");
+    }
 }

@@ -15,6 +15,7 @@
 #include "common.h"
 #include "blocked.h"
 #include "wave_reduce.h"
+#include "stein_finalize.h"
 #include <cfloat>
 
 namespace {
@@ -100,7 +101,8 @@ __device__ __forceinline__ float kl_tridiag(const Ws& s, float eta) {
 // DC > 0: dimension known at compile time (inner loops unrolled, LDS reads issued in batches); DC == 0: generic.
 template <int DC, int NW>
 __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float* __restrict__ means, float* __restrict__ chols,
-                                                            const float* __restrict__ H_neg, const float* __restrict__ g_neg,
+                                                            float* H_neg, float* g_neg, SteinSlab slab, int slab_N, int slab_flags,
+                                                            const float* __restrict__ packed_old,
                                                             const float* __restrict__ stepsizes, float temperature,
                                                             float l2_init, float* __restrict__ last_eta, float* __restrict__ l2,
                                                             float* __restrict__ num_updates, int32_t* __restrict__ success_out,
@@ -112,6 +114,15 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
     carve(s, sm, D);
     const int k = blockIdx.x, t = threadIdx.x, ld = D + 1;
     constexpr int NTH = 64 * NW;
+    if constexpr (DC > 0 && DC <= 24) {
+        // single-call iteration: the last step of the Stein estimate (stein_finalize.h) is this kernel's prologue -- same
+        // arithmetic as the stand-alone launch, one launch and its drain less; H_neg / g_neg still go to global memory
+        if (slab.part != nullptr) {
+            stein_finalize_component<DC>(sm, k, D, slab.R, slab_N, slab_flags, slab.part, slab.part_m, H_neg, g_neg, packed_old);
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
     float* Lg = chols + (size_t)k * D * D;
     float* mug = means + (size_t)k * D;
     const float* Rg = H_neg + (size_t)k * D * D;
@@ -600,6 +611,46 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
 
 }  // namespace
 
+static int update_kl_launch(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_dev, float* H_neg_dev, float* g_neg_dev,
+                            const SteinSlab& slab, int slab_N, int slab_flags, const float* packed_old_dev,
+                            const float* stepsizes_dev, float temperature, float l2_init, float* last_eta_dev, float* l2_dev,
+                            float* num_received_updates_dev, int32_t* success_out_dev, float* kl_out_dev,
+                            int32_t* n_probes_out_dev, float* packed_out_dev) {
+    size_t shmem = lds_bytes(D);
+    if (slab.part != nullptr) {
+        const size_t fin = stein_finalize_lds_floats(gmmvi_padded_dim(D), D, slab.R) * sizeof(float);
+        if (fin > shmem) shmem = fin;
+    }
+    GMMVI_PROF(ctx, "update_kl");
+#define GMMVI_UKL(DCV, NWV)                                                                                        \
+    do {                                                                                                           \
+        if (shmem > 64 * 1024)                                                                                     \
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)update_kl_fast_kernel<DCV, NWV>,                 \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));     \
+        hipLaunchKernelGGL((update_kl_fast_kernel<DCV, NWV>), dim3(K), dim3(64 * NWV), shmem, ctx->stream, D,      \
+                           means_dev, chols_dev, H_neg_dev, g_neg_dev, slab, slab_N, slab_flags, packed_old_dev,   \
+                           stepsizes_dev, temperature, l2_init, last_eta_dev, l2_dev, num_received_updates_dev,    \
+                           success_out_dev, kl_out_dev, n_probes_out_dev, packed_out_dev, gmmvi_padded_dim(D));    \
+    } while (0)
+    // dimensions of the BASELINE configurations get unrolled instances; from D = 32 four wavefronts share the D^3 products,
+    // the load / pack phases and the fragment writes (the chains in between stay on one)
+    const bool pro = slab.part != nullptr;             // with the Stein prologue: four wavefronts (its slab sum is parallel work)
+    switch (D) {
+        case 4: if (pro) GMMVI_UKL(4, 4); else GMMVI_UKL(4, 1); break;
+        case 10: if (pro) GMMVI_UKL(10, 4); else GMMVI_UKL(10, 1); break;
+        case 20: if (pro) GMMVI_UKL(20, 4); else GMMVI_UKL(20, 1); break;
+        case 32: GMMVI_UKL(32, 4); break;
+        case 40: GMMVI_UKL(40, 4); break;
+        case 50: GMMVI_UKL(50, 4); break;
+        default:
+            if (D > 24) GMMVI_UKL(0, 4); else GMMVI_UKL(0, 1);
+            break;
+    }
+#undef GMMVI_UKL
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
 extern "C" int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* means_dev, float* chols_dev,
                                           const float* H_neg_dev, const float* g_neg_dev, const float* stepsizes_dev,
                                           float temperature, float l2_init, float* last_eta_dev, float* l2_dev,
@@ -612,32 +663,29 @@ extern "C" int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* m
         return gmmvi_blocked_update_kl(ctx, K, D, means_dev, chols_dev, H_neg_dev, g_neg_dev, stepsizes_dev, temperature, l2_init,
                                        last_eta_dev, l2_dev, num_received_updates_dev, success_out_dev, kl_out_dev,
                                        n_probes_out_dev, packed_out_dev);
-    size_t shmem = lds_bytes(D);
-    GMMVI_PROF(ctx, "update_kl");
-#define GMMVI_UKL(DCV, NWV)                                                                                        \
-    do {                                                                                                           \
-        if (shmem > 64 * 1024)                                                                                     \
-            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)update_kl_fast_kernel<DCV, NWV>,                 \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));     \
-        hipLaunchKernelGGL((update_kl_fast_kernel<DCV, NWV>), dim3(K), dim3(64 * NWV), shmem, ctx->stream, D,      \
-                           means_dev, chols_dev, H_neg_dev, g_neg_dev, stepsizes_dev, temperature, l2_init,        \
-                           last_eta_dev, l2_dev, num_received_updates_dev, success_out_dev, kl_out_dev,            \
-                           n_probes_out_dev, packed_out_dev, gmmvi_padded_dim(D));                                 \
-    } while (0)
-    // dimensions of the BASELINE configurations get unrolled instances; from D = 32 four wavefronts share the D^3 products,
-    // the load / pack phases and the fragment writes (the chains in between stay on one)
-    switch (D) {
-        case 4: GMMVI_UKL(4, 1); break;
-        case 10: GMMVI_UKL(10, 1); break;
-        case 20: GMMVI_UKL(20, 1); break;
-        case 32: GMMVI_UKL(32, 4); break;
-        case 40: GMMVI_UKL(40, 4); break;
-        case 50: GMMVI_UKL(50, 4); break;
-        default:
-            if (D > 24) GMMVI_UKL(0, 4); else GMMVI_UKL(0, 1);
-            break;
+    // (the estimate is only read: the kernel takes non-const pointers because its single-call form writes them first)
+    return update_kl_launch(ctx, K, D, means_dev, chols_dev, const_cast<float*>(H_neg_dev), const_cast<float*>(g_neg_dev),
+                            SteinSlab{nullptr, nullptr, 0}, 0, 0, nullptr, stepsizes_dev, temperature, l2_init, last_eta_dev, l2_dev,
+                            num_received_updates_dev, success_out_dev, kl_out_dev, n_probes_out_dev, packed_out_dev);
+}
+
+// C++ linkage (common.h), single-call iteration: the Stein estimate is finished from its partial slab and the components are
+// updated -- in ONE launch where the update kernel carries the prologue (the unrolled single-wave instances D = 4 / 10 / 20),
+// by the stand-alone finalize launch followed by the update otherwise.  H_neg / g_neg receive the estimate either way.
+int gmmvi_update_components_kl_from_slab(gmmvi_ctx* ctx, int K, int D, const SteinSlab& slab, int N, int stein_flags,
+                                         const float* packed_old_dev, float* H_neg_dev, float* g_neg_dev, float* means_dev,
+                                         float* chols_dev, const float* stepsizes_dev, float temperature, float l2_init,
+                                         float* last_eta_dev, float* l2_dev, float* num_received_updates_dev,
+                                         int32_t* success_out_dev, float* packed_out_dev) {
+    const bool fused = (D == 4 || D == 10 || D == 20) && !gmmvi_is_blocked_dim(D);
+    if (!fused) {
+        int rc = gmmvi_stein_finalize_slab(ctx, K, D, slab, N, stein_flags, packed_old_dev, H_neg_dev, g_neg_dev);
+        if (rc != GMMVI_OK) return rc;
+        return gmmvi_update_components_kl(ctx, K, D, means_dev, chols_dev, H_neg_dev, g_neg_dev, stepsizes_dev, temperature,
+                                          l2_init, last_eta_dev, l2_dev, num_received_updates_dev, success_out_dev, nullptr,
+                                          nullptr, packed_out_dev);
     }
-#undef GMMVI_UKL
-    GMMVI_LAUNCH_CHECK(ctx);
-    return GMMVI_OK;
+    return update_kl_launch(ctx, K, D, means_dev, chols_dev, H_neg_dev, g_neg_dev, slab, N, stein_flags, packed_old_dev,
+                            stepsizes_dev, temperature, l2_init, last_eta_dev, l2_dev, num_received_updates_dev, success_out_dev,
+                            nullptr, nullptr, packed_out_dev);
 }
