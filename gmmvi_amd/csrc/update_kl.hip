@@ -18,6 +18,10 @@
 #include "stein_finalize.h"
 #include <cfloat>
 
+#ifndef GMMVI_UKL_UNROLL_MAX
+#define GMMVI_UKL_UNROLL_MAX 50      // static dimensions up to here get fully unrolled Householder / UL loops
+#endif
+
 namespace {
 
 // hand-over through LDS inside the one wavefront that runs the chain phases: with several wavefronts in the workgroup only
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
         float* pv = s.pr + 64;                      // scratch is free until the search starts; 3 D (D + 4) floats precede it)
         // fully unrolled for D <= 32: c becomes a compile-time constant, the selects below fold away and the j loops shrink
         // to the live part of the column
-        constexpr int UNR_C = DR <= 32 ? DR : 1;
+        constexpr int UNR_C = DR <= GMMVI_UKL_UNROLL_MAX ? DR : 1;
 #pragma unroll UNR_C
         for (int c = 0; c + 2 < DR; ++c) {
             float mc = 0.f;                         // mrow[c] (c is wave-uniform; a constant when unrolled)
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             for (int c = 0; c < DR; ++c)
                 xr[c] = (t < DR && c >= t) ? ((c == t ? 1.f : 0.f) + s.Mc[t * ld + c] * inv) : 0.f;
             float* uv = s.pr;                                      // column j of U as a broadcast vector
-            constexpr int UNR_J = DR <= 32 ? DR : 1;
+            constexpr int UNR_J = DR <= GMMVI_UKL_UNROLL_MAX ? DR : 1;
 #pragma unroll UNR_J
             for (int j = DR - 1; j >= 0; --j) {
                 float bj = 0.f;                                    // xr[j] (j is wave-uniform; a constant when unrolled)
