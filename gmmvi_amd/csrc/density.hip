@@ -573,8 +573,12 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
                                const float* logw2 = nullptr, float* lp2 = nullptr) {
     using PK = Pack<DP>;
     if constexpr (PK::FRAGS) {
-        if constexpr (DP >= 40) return launch_mixture_eval_mfma<DP, 2>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
-        else return launch_mixture_eval_mfma<DP, 4>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
+        // sub-tiles of 16 samples per wave pass: four (every fragment fetch of a component serves 64 samples) unless the
+        // gradient state of the wide dimensions would not fit the registers
+        if constexpr (DP >= 40) {                      // (D = 40 with the gradient: 60 us at two sub-tiles, 82 us at four)
+            if (grad != nullptr) return launch_mixture_eval_mfma<DP, 2>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
+        }
+        return launch_mixture_eval_mfma<DP, 4>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
     } else {
     const bool want_grad = grad != nullptr;
     const bool want_merge = want_grad || lp != nullptr;
