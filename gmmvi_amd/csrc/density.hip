@@ -342,17 +342,22 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_kernel(float nu, int K_
         me_f32x4 z[NTS][MT];
         float ldv[NTS], ev[NTS], scv[NTS], cfv[NTS];
 #pragma unroll
-        for (int t = 0; t < NTS; ++t) {
-            float b[KS];
+        for (int t = 0; t < NTS; ++t)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) b[s] = xb[t][s] - mus[s];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z[t][mt][r] = 0.f;
+        // k-step outermost: consecutive MFMAs go to different accumulators (NTS x MT independent chains), none waits for the
+        // 40-cycle dependent-issue latency of its predecessor
 #pragma unroll
-                for (int s = 0; s < PK::nf(mt); ++s)
-                    z[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[PK::fwd_index(mt, s)], b[s], z[t][mt], 0, 0, 0);
+        for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) {
+                const float b = xb[t][s] - mus[s];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if (s < PK::nf(mt))
+                        z[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[PK::fwd_index(mt, s)], b, z[t][mt], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -413,17 +418,21 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_kernel(float nu, int K_
                     bz[4 * q4] = v4[0]; bz[4 * q4 + 1] = v4[1]; bz[4 * q4 + 2] = v4[2]; bz[4 * q4 + 3] = v4[3];
                 }
                 const float ec = ev[t] * cfv[t];
+                me_f32x4 y[MT];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    me_f32x4 y;
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] = 0.f;
+                    for (int r = 0; r < 4; ++r) y[mt][r] = 0.f;
 #pragma unroll
-                    for (int s = 4 * mt; s < KS; ++s)
-                        y = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[PK::bwd_index(mt, s)], bz[s], y, 0, 0, 0);
+                for (int s = 0; s < KS; ++s)                           // k-step outermost: MT independent chains
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[t][mt][r] = fmaf(acc[t][mt][r], scv[t], ec * y[r]);
-                }
+                    for (int mt = 0; mt < MT; ++mt)
+                        if (s >= 4 * mt)
+                            y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ab[PK::bwd_index(mt, s)], bz[s], y[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][mt][r] = fmaf(acc[t][mt][r], scv[t], ec * y[mt][r]);
             }
             ME_WAVE_LDS_SYNC();
         }
