@@ -234,7 +234,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=40.0)
+    ap.add_argument("--cpu-seconds", type=float, default=80.0)
     args = ap.parse_args()
     n_gpus = args.gpus
     if "WORLD_SIZE" not in os.environ and n_gpus > 1:
