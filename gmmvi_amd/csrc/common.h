@@ -122,7 +122,7 @@ inline int gmmvi_padded_dim(int D) {
     }
 
 // Padded dimension from which the density sweeps run on the matrix cores with the explicit inverse (density.hip).  Measured at
-// K = 100, N = 10^4 (profiles/r02_notes.md): D = 50 dual sweep 300 -> 112 us, post-update sweep 100 -> 73 us; D = 20 and D = 10
+// K = 100, N = 10^4 (profiles/r02_notes.md): D = 50 dual sweep + target 368 -> 178 us, post-update sweep 100 -> 61 us; D = 20 and D = 10
 // are slower there (a 16-sample sub-tile pays the log-sum-exp tail four times as often per pair): they keep the scalar-fed
 // substitution kernel and the smaller block.
 #ifndef GMMVI_MFMA_DENSITY_FROM_DP
