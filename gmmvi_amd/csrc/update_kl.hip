@@ -17,12 +17,22 @@
 #include "wave_reduce.h"
 #include "stein_finalize.h"
 #include <cfloat>
+#include <type_traits>
 
 #ifndef GMMVI_UKL_UNROLL_MAX
 #define GMMVI_UKL_UNROLL_MAX 50      // static dimensions up to here get fully unrolled Householder / UL loops
 #endif
 
 namespace {
+
+// compile-time loop: f(std::integral_constant<int, B>) ... f(std::integral_constant<int, E - 1>)
+template <int B, int E, class F>
+__device__ __forceinline__ void ukl_static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        ukl_static_for<B + 1, E>(f);
+    }
+}
 
 // hand-over through LDS inside the one wavefront that runs the chain phases: with several wavefronts in the workgroup only
 // that wave's LDS queue has to drain (the others must not be waited for); a single-wave workgroup keeps the plain barrier
@@ -118,6 +128,13 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
     carve(s, sm, D);
     const int k = blockIdx.x, t = threadIdx.x, ld = D + 1;
     constexpr int NTH = 64 * NW;
+#ifdef GMMVI_UKL_STAMPS            // experiment builds (tools/ukl_probe.py): phase time stamps of component 0 into kl_out[1..6]
+    long long stamp[8];
+    stamp[0] = wall_clock64();
+#define UKL_STAMP(i) stamp[i] = wall_clock64()
+#else
+#define UKL_STAMP(i)
+#endif
     if constexpr (DC > 0 && DC <= 24) {
         // single-call iteration: the last step of the Stein estimate (stein_finalize.h) is this kernel's prologue -- same
         // arithmetic as the stand-alone launch, one launch and its drain less; H_neg / g_neg still go to global memory
@@ -187,6 +204,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
     float eta_w = 0.f, kl_w = -1.f;
     int probes_w = 0;
     if (NW == 1 || __builtin_amdgcn_readfirstlane(t >> 6) == 0) {          // wave-uniform: the region keeps its scalar branches
+    UKL_STAMP(1);                                      // load + products done
     // ---- Householder tridiagonalisation of M, reflectors applied to wt.  Every lane forms the column norm and the two dot
     // products itself from broadcast LDS vectors: no cross-lane reduction chains on the critical path.  With a static D the
     // lane keeps its row of M (and a replica of wt) in registers, so a step costs ~20 LDS operations instead of ~200 --
@@ -201,10 +219,11 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
         float* pv = s.pr + 64;                      // scratch is free until the search starts; 3 D (D + 4) floats precede it)
         // fully unrolled for D <= 32: c becomes a compile-time constant, the selects below fold away and the j loops shrink
         // to the live part of the column
-        constexpr int UNR_C = DR <= GMMVI_UKL_UNROLL_MAX ? DR : 1;
-#pragma unroll UNR_C
-        for (int c = 0; c + 2 < DR; ++c) {
-            float mc = 0.f;                         // mrow[c] (c is wave-uniform; a constant when unrolled)
+        // one instantiation per column (ukl_static_for): c is a compile-time constant in every step -- `#pragma unroll` gives
+        // up on this body from D ~ 40, and with a run-time c every select below stays a select
+        ukl_static_for<0, (DR > 2 ? DR - 2 : 0)>([&](auto c_const) {
+            constexpr int c = decltype(c_const)::value;
+            float mc = 0.f;                         // mrow[c]
 #pragma unroll
             for (int j = 0; j < DR; ++j) mc = (j == c) ? mrow[j] : mc;
             if (t < DR) xv[t] = mc;
@@ -215,6 +234,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
                 const float4 v4 = reinterpret_cast<const float4*>(xv)[q4];
                 x[4 * q4] = v4.x; x[4 * q4 + 1] = v4.y; x[4 * q4 + 2] = v4.z; x[4 * q4 + 3] = v4.w;
             }
+            const float xt = xv[t < DR ? t : 0];     // this lane's own element of the column (its v_t below)
             float x1 = 0.f, tail = 0.f;
 #pragma unroll
             for (int j = 0; j < DR; ++j) {
@@ -224,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             if (!(tail > 0.f)) {                    // column already tridiagonal (also covers NaN: handled later)
                 if (t == 0) s.te[c] = x1;
                 UKL_WSYNC();
-                continue;                           // uniform: every lane computed the same tail
+                return;                             // uniform: every lane computed the same tail
             }
             const float nrm = __builtin_amdgcn_sqrtf(tail + x1 * x1);       // v_sqrt_f32 / v_rcp_f32 (1 ulp): the reflector only
                                                                             // has to be orthogonal to working precision
@@ -233,12 +253,15 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             // v_j: 0 for j <= c, x1 - alpha for j = c + 1, x_j below
 #pragma unroll
             for (int j = 0; j < DR; ++j) x[j] = (j <= c) ? 0.f : (j == c + 1 ? x1 - alpha : x[j]);
+            // v vanishes for j <= c and so do p_j of the inactive lanes: every loop below runs over the live part j > c only
+            // (compile-time bounds once c is unrolled); the skipped terms are exact zeros
             const bool act = (t > c) && (t < DR);
-            float vv = 0.f, p = 0.f;
+            float p = 0.f;
 #pragma unroll
-            for (int j = 0; j < DR; ++j) { vv = (j == t) ? x[j] : vv; p = fmaf(mrow[j], x[j], p); }
+            for (int j = 0; j < DR; ++j)
+                if (j > c) p = fmaf(mrow[j], x[j], p);
             p = act ? p * beta : 0.f;
-            vv = act ? vv : 0.f;
+            const float vv = act ? (t == c + 1 ? x1 - alpha : xt) : 0.f;
             if (t < DR) pv[t] = p;
             UKL_WSYNC();
             float pj[4 * D4];
@@ -249,17 +272,20 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             }
             float kk = 0.f, wdot = 0.f;
 #pragma unroll
-            for (int j = 0; j < DR; ++j) { kk = fmaf(x[j], pj[j], kk); wdot = fmaf(x[j], wtr[j], wdot); }
+            for (int j = 0; j < DR; ++j)
+                if (j > c) { kk = fmaf(x[j], pj[j], kk); wdot = fmaf(x[j], wtr[j], wdot); }
             kk *= 0.5f * beta;
             wdot *= beta;
             const float qq = p - kk * vv;
 #pragma unroll
             for (int j = 0; j < DR; ++j) {
-                mrow[j] -= vv * (pj[j] - kk * x[j]) + qq * x[j];
-                wtr[j] -= wdot * x[j];              // replica of wt in every lane
+                if (j > c) {
+                    mrow[j] -= vv * (pj[j] - kk * x[j]) + qq * x[j];
+                    wtr[j] -= wdot * x[j];          // replica of wt in every lane
+                }
             }
             if (t == 0) s.te[c] = alpha;
-        }
+        });
         UKL_WSYNC();
         if (t < DR) {
             float dd = 0.f, sub = 0.f, wme = 0.f;
@@ -326,6 +352,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
         UKL_WSYNC();
     }
 
+    UKL_STAMP(2);                                      // tridiagonal form done
     // ---- speculative bisection: 63 tree nodes (6 levels) per round, one lane per node ------------------------------------
     const float eps = stepsizes[k];
     const float last = last_eta[k];
@@ -359,6 +386,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             else { lb = eta; n = 2 * n + 1; }                                              // :418-419
         }
     }
+    UKL_STAMP(3);                                      // search done
     if (ub_ok) lb = ub;                                                                    // :423-424
     const float lo = expf(lb), hi = expf(ub);                                              // :426-427
     const float eta_star = fmaxf(lo, temperature);                                         // :476
@@ -427,6 +455,9 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
                 const float rd = 1.f / ur[i];
                 xr[i] = a * rd;
                 zr[i] = b * rd;
+                // the rows of U are independent loads: without a fence the scheduler hoists those of many steps above the
+                // chain and the register allocator runs out (D = 50: 770 bytes of scratch per lane)
+                __builtin_amdgcn_sched_barrier(0);
             }
             float acc = 0.f;
             bool bad = false;
@@ -544,6 +575,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
         }
     }
     }
+    UKL_STAMP(4);                                      // new factor done
     success_w = success; eta_w = eta_star; kl_w = kl_val; probes_w = probes;
     }
     __shared__ int sh_success;
@@ -576,6 +608,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             out[2 * DPk + 2 * T] = -lsum - 0.5f * D * 1.8378770664093453f;
             for (int i = 2 * DPk + 2 * T + 1; i < pd.fwd; ++i) out[i] = 0.f;
         }
+        UKL_STAMP(5);                                  // packed block (without fragments) done
         // L^-1 of the final factor for the matrix-core fragments of the block: lane t solves L x = e_t (column t) from the
         // LDS image of L (every lane reads the same element: broadcast), the dense inverse goes through Mc
         __syncthreads();
@@ -602,6 +635,12 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
         __syncthreads();
         if (pd.nf_total > 0) gmmvi_write_inverse_fragments(out, DPk, D, s.Mc, ld, t, NTH);
     }
+#ifdef GMMVI_UKL_STAMPS
+    UKL_STAMP(6);
+    if (k == 0 && t == 0 && kl_out)
+        for (int i = 1; i <= 6; ++i) kl_out[i] = (float)(stamp[i] - stamp[0]);
+    kl_out = nullptr;
+#endif
     if (t == 0) {
         last_eta[k] = success ? eta_w : -1.f;                                              // :504,:511,:524
         if (kl_out) kl_out[k] = success ? kl_w : -1.f;
