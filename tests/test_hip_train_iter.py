@@ -89,6 +89,14 @@ def test_north_star_full_size():
     assert f.sample_db.samples.shape == (20000, 20)
 
 
+def test_gmm50_config_full_size():
+    """BASELINE configs[2] at full size (GMM target, D = 50, K = 100, 100 samples per component = 10 000 samples per iteration):
+    two iterations against the fp64 oracle on the single-call path -- matrix-core density sweeps, moment-form Stein estimate,
+    four-wave update kernel with the inverse fragments, exactly the composition `bench.py --workload c3` times."""
+    cfg = samtron_config(100)
+    run_pair("gmm", 50, 100, 100, seed=41, iters=2, cfg=cfg, fused=True)
+
+
 def test_planar_config_full_size():
     """BASELINE configs[3] at full size on one GPU (planar-4 target, D = 10, K = 200, 100 samples per component = 20 000
     samples per iteration): two iterations against the fp64 oracle, single-call path."""
