@@ -1,0 +1,69 @@
+// Merge of the per-chunk partials of a component-split mixture sweep (density.hip: gridDim.y > 1):
+//   lp[n] = log sum_r exp(lp_r[n]);  grad[n, :] = sum_r exp(lp_r[n] - lp[n]) grad_r[n, :]   (fixed order over r).
+// One element function, three users with identical arithmetic: the stand-alone launch (comm.hip, also the E2 exchange of the
+// sharded path), extra workgroups riding in the NEXT launch of the single-call iteration (a launch that exists anyway and does
+// not read the merged arrays: the target evaluation carries the merge of the model sweep), and the expected-log-ratio kernel,
+// which merges the log values of the post-update sweep while it reads them.
+#pragma once
+#include "common.h"
+
+// thread = one element of the [N, D] gradient (coalesced over r-major partial arrays); the thread of column 0 also writes lp,
+// the thread of column 1 (column 0 without a gradient) the second set of log values
+template <int R>
+__device__ __forceinline__ float combine_log_values_n(const float* __restrict__ parts, int N, int n) {
+    float v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = parts[(size_t)r * N + n];          // all loads in flight
+    float m = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) m = fmaxf(m, v[r]);
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) s += __expf(v[r] - m);
+    return m + __logf(s);
+}
+
+__device__ __forceinline__ float combine_log_values(const float* __restrict__ parts, int R, int N, int n) {
+    switch (R) {                                       // the usual chunk counts, unrolled (R is uniform: a scalar branch)
+        case 2: return combine_log_values_n<2>(parts, N, n);
+        case 3: return combine_log_values_n<3>(parts, N, n);
+        case 4: return combine_log_values_n<4>(parts, N, n);
+        case 5: return combine_log_values_n<5>(parts, N, n);
+        case 6: return combine_log_values_n<6>(parts, N, n);
+        default: break;
+    }
+    float m = -3.0e38f;
+    for (int r = 0; r < R; ++r) m = fmaxf(m, parts[(size_t)r * N + n]);
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += __expf(parts[(size_t)r * N + n] - m);
+    return m + __logf(s);
+}
+
+__device__ __forceinline__ void combine_element(const CombineJob& j, long e) {
+    const bool with_grad = j.grad_out != nullptr && j.grad_parts != nullptr;
+    const int width = with_grad ? j.D : 1;
+    if (e >= (long)j.N * width) return;
+    const int n = (int)(e / width), i = (int)(e - (long)n * width);
+    const float lp = combine_log_values(j.lp_parts, j.R, j.N, n);
+    if (j.lp_out && i == 0) j.lp_out[n] = lp;
+    if (j.lp2_out && j.lp2_parts && i == (width > 1 ? 1 : 0)) j.lp2_out[n] = combine_log_values(j.lp2_parts, j.R, j.N, n);
+    if (with_grad) {
+        float g = 0.f;
+        for (int r = 0; r < j.R; ++r)
+            g = fmaf(__expf(j.lp_parts[(size_t)r * j.N + n] - lp), j.grad_parts[((size_t)r * j.N + n) * j.D + i], g);
+        j.grad_out[(size_t)n * j.D + i] = g;
+    }
+}
+
+// the carried form: workgroups first_block .. first_block + blocks - 1 of the carrying launch (blockIdx.y == 0 only)
+__device__ __forceinline__ bool combine_carried(const CombineJob& j) {
+    if (j.blocks == 0 || (int)blockIdx.x < j.first_block) return false;
+    if (blockIdx.y == 0 && blockIdx.z == 0) {
+        const bool with_grad = j.grad_out != nullptr && j.grad_parts != nullptr;
+        const long elems = (long)j.N * (with_grad ? j.D : 1);
+        const long stride = (long)j.blocks * blockDim.x;
+        for (long e = (long)((int)blockIdx.x - j.first_block) * blockDim.x + threadIdx.x; e < elems; e += stride)
+            combine_element(j, e);
+    }
+    return true;
+}

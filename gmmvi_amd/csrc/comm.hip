@@ -1,6 +1,7 @@
 // Multi-GPU exchange for component shards: one process per GPU, RCCL over xGMI.
 // The reference has no collective; these are the E1/E2/E3 exchanges the sharded design introduces.
 #include "common.h"
+#include "combine.h"
 #include <rccl/rccl.h>
 
 #define GMMVI_NCCL_CHECK(ctx, call)                                                                        \
@@ -10,38 +11,9 @@
             return gmmvi_fail(ctx, GMMVI_ERR_RCCL, std::string(#call) + ": " + ncclGetErrorString(r__));   \
     } while (0)
 
-// lp[n] = LSE_r lp_r[n];  grad[n,:] = sum_r exp(lp_r[n] - lp[n]) grad_r[n,:]
-// lp[n] = log sum_r exp(lp_r[n]);  grad[n, :] = sum_r exp(lp_r[n] - lp[n]) grad_r[n, :].
-// Thread = one element of the [N, D] gradient (coalesced over r-major partial arrays); the thread of column 0 also writes lp.
-// Fixed summation order over r.
-__global__ __launch_bounds__(256) void combine_partials_kernel(int R, int N, int D, const float* __restrict__ lp_parts,
-                                                               const float* __restrict__ grad_parts, float* __restrict__ lp_out,
-                                                               float* __restrict__ grad_out, const float* __restrict__ lp2_parts,
-                                                               float* __restrict__ lp2_out) {
-    const bool with_grad = grad_out != nullptr && grad_parts != nullptr;
-    const int width = with_grad ? D : 1;
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (long)N * width) return;
-    const int n = (int)(e / width), i = (int)(e - (long)n * width);
-    float m = -3.0e38f;
-    for (int r = 0; r < R; ++r) m = fmaxf(m, lp_parts[(size_t)r * N + n]);
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) s += __expf(lp_parts[(size_t)r * N + n] - m);
-    const float lp = m + __logf(s);
-    if (lp_out && i == 0) lp_out[n] = lp;
-    if (lp2_out && i == (width > 1 ? 1 : 0)) {          // second mixture over the same components (log values only)
-        float m2 = -3.0e38f;
-        for (int r = 0; r < R; ++r) m2 = fmaxf(m2, lp2_parts[(size_t)r * N + n]);
-        float s2 = 0.f;
-        for (int r = 0; r < R; ++r) s2 += __expf(lp2_parts[(size_t)r * N + n] - m2);
-        lp2_out[n] = m2 + __logf(s2);
-    }
-    if (with_grad) {
-        float g = 0.f;
-        for (int r = 0; r < R; ++r)
-            g = fmaf(__expf(lp_parts[(size_t)r * N + n] - lp), grad_parts[((size_t)r * N + n) * D + i], g);
-        grad_out[(size_t)n * D + i] = g;
-    }
+// stand-alone merge launch (combine.h has the arithmetic)
+__global__ __launch_bounds__(256) void combine_partials_kernel(CombineJob j) {
+    combine_element(j, (long)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // C++ linkage (common.h): gmmvi_combine_partials plus an optional second set of log-value partials (dual mixture sweep)
@@ -50,12 +22,53 @@ int gmmvi_combine_partials_internal(gmmvi_ctx* ctx, int R, int N, int D, const f
                                     const float* lp2_parts_dev, float* lp2_out_dev) {
     GMMVI_ARG_CHECK(ctx, R >= 1 && N >= 0 && D >= 1 && lp_parts_dev);
     if (N == 0) return GMMVI_OK;
+    CombineJob j;
+    j.R = R; j.N = N; j.D = D;
+    j.lp_parts = lp_parts_dev; j.grad_parts = grad_parts_dev; j.lp2_parts = lp2_parts_dev;
+    j.lp_out = lp_out_dev; j.grad_out = grad_out_dev; j.lp2_out = lp2_parts_dev ? lp2_out_dev : nullptr;
     const long elems = (long)N * ((grad_out_dev && grad_parts_dev) ? D : 1);
-    hipLaunchKernelGGL(combine_partials_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, ctx->stream, R, N, D,
-                       lp_parts_dev, grad_parts_dev, lp_out_dev, grad_out_dev, lp2_parts_dev,
-                       lp2_parts_dev ? lp2_out_dev : nullptr);
+    hipLaunchKernelGGL(combine_partials_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, ctx->stream, j);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
+}
+
+int gmmvi_defer_reserve(gmmvi_ctx* ctx, size_t nbytes) {
+    if (ctx->pending.R > 0) return gmmvi_fail(ctx, GMMVI_ERR_ARG, "gmmvi_defer_reserve: a merge is still pending");
+    if (nbytes <= ctx->defer_bytes) return GMMVI_OK;
+    GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->defer_ws) GMMVI_HIP_CHECK(ctx, hipFree(ctx->defer_ws));
+    ctx->defer_ws = nullptr;
+    ctx->defer_bytes = 0;
+    const size_t want = nbytes + nbytes / 2;
+    GMMVI_HIP_CHECK(ctx, hipMalloc(&ctx->defer_ws, want));
+    ctx->defer_bytes = want;
+    return GMMVI_OK;
+}
+
+int gmmvi_flush_pending_combine(gmmvi_ctx* ctx) {
+    if (ctx->pending.R == 0) return GMMVI_OK;
+    const CombineJob j = ctx->pending;
+    ctx->pending = CombineJob();
+    GMMVI_PROF(ctx, "mixture_combine");
+    return gmmvi_combine_partials_internal(ctx, j.R, j.N, j.D, j.lp_parts, j.grad_parts, j.lp_out, j.grad_out, j.lp2_parts,
+                                           j.lp2_out);
+}
+
+CombineJob gmmvi_take_pending_combine(gmmvi_ctx* ctx, int threads, int first_block) {
+    CombineJob j = ctx->pending;
+    ctx->pending = CombineJob();
+    if (j.R == 0) return j;
+    const long elems = (long)j.N * ((j.grad_out && j.grad_parts) ? j.D : 1);
+    // the carried workgroups have the resource footprint of the carrying kernel: give them the CUs its own workgroups leave idle
+    // in their last round rather than a further round
+    long blocks = ctx->num_cus - first_block % ctx->num_cus;
+    if (blocks < ctx->num_cus / 4) blocks += ctx->num_cus;
+    const long useful = (elems + threads - 1) / threads;
+    if (blocks > useful) blocks = useful;
+    if (blocks < 1) blocks = 1;
+    j.first_block = first_block;
+    j.blocks = (int)blocks;
+    return j;
 }
 
 extern "C" {

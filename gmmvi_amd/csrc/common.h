@@ -8,6 +8,19 @@
 #include <vector>
 #include "../../include/gmmvi_hip.h"
 
+// a merge of component-chunk partials (combine.h) that has not been launched yet: the single-call iteration lets the next
+// launch carry it (density.hip defers, the target / expected-log-ratio launches take it)
+struct CombineJob {
+    int R = 0, N = 0, D = 0;
+    int first_block = 0, blocks = 0;      // set by the carrying launcher
+    const float* lp_parts = nullptr;
+    const float* grad_parts = nullptr;
+    const float* lp2_parts = nullptr;
+    float* lp_out = nullptr;
+    float* grad_out = nullptr;
+    float* lp2_out = nullptr;
+};
+
 struct gmmvi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -18,6 +31,10 @@ struct gmmvi_ctx {
     uint64_t ws_epoch = 0;       // bumped by every gmmvi_ws_reserve: the scratch contents belong to the call that reserved them
     void* arena = nullptr;       // persistent scratch of the single-call iteration (fused.hip)
     size_t arena_bytes = 0;
+    bool defer_combine = false;  // set by fused.hip around a sweep whose merge the next launch carries
+    CombineJob pending;          // R > 0: partials in defer_ws wait for their merge
+    void* defer_ws = nullptr;    // partials of a deferred merge (ctx->ws is reused by the launches in between)
+    size_t defer_bytes = 0;
     void* comm = nullptr;        // ncclComm_t
     int n_ranks = 1, rank = 0;
     int num_cus = 256;
@@ -80,6 +97,11 @@ int gmmvi_sample_components_prep(gmmvi_ctx* ctx, int K, int D, const float* mean
 int gmmvi_combine_partials_internal(gmmvi_ctx* ctx, int R, int N, int D, const float* lp_parts_dev,
                                     const float* grad_parts_dev, float* lp_out_dev, float* grad_out_dev,
                                     const float* lp2_parts_dev, float* lp2_out_dev);
+// comm.hip: deferred merges.  reserve: room for the partials (no merge may be pending); flush: launch a pending merge on its
+// own; take: hand a pending merge to a launch of `threads` threads per workgroup whose own workgroups end at `first_block`
+int gmmvi_defer_reserve(gmmvi_ctx* ctx, size_t nbytes);
+int gmmvi_flush_pending_combine(gmmvi_ctx* ctx);
+CombineJob gmmvi_take_pending_combine(gmmvi_ctx* ctx, int threads, int first_block);
 // stein.hip / update_kl.hip: the Stein estimate split at the partial slab (single-call iteration, fused.hip)
 struct SteinSlab;
 int gmmvi_stein_partials(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* X_dev, int N, const float* ld_dev,

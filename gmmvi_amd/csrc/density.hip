@@ -7,6 +7,7 @@
 // solve is fully unrolled for the padded dimension DP; partial (max, sum, gradient) of the W waves are merged
 // through LDS.
 #include "common.h"
+#include "combine.h"
 #include "subst.h"
 #include "blocked.h"
 #include <cmath>
@@ -127,9 +128,10 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
                                                             const float* __restrict__ logw, const float* __restrict__ X,
                                                             int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
                                                             float* __restrict__ grad_out, const float* __restrict__ logw2,
-                                                            float* __restrict__ lp2_out) {
+                                                            float* __restrict__ lp2_out, CombineJob carried) {
     using PK = Pack<DP>;
     extern __shared__ __align__(16) float sm[];
+    if (combine_carried(carried)) return;              // workgroups past the sample tiles: the merge of the previous sweep
     const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
     const int k_lo = blockIdx.y * kchunk;
     const int K = min(K_total, k_lo + kchunk);
@@ -273,9 +275,10 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_kernel(float nu, int K_
                                                                 const float* __restrict__ logw, const float* __restrict__ X,
                                                                 int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
                                                                 float* __restrict__ grad_out, const float* __restrict__ logw2,
-                                                                float* __restrict__ lp2_out) {
+                                                                float* __restrict__ lp2_out, CombineJob carried) {
     using PK = Pack<DP>;
     constexpr int MT = PK::MT, KS = PK::KS;
+    if (combine_carried(carried)) return;              // workgroups past the sample tiles: the merge of the previous sweep
     constexpr int TS = 16 * NTS;                       // samples per workgroup tile
     constexpr int KSP = ((KS + 3) / 4) * 4;            // k-steps per lane in the z image, padded to 16-byte reads
     constexpr int ZW = 4 * KSP + 4;                    // row stride of the z image
@@ -541,15 +544,22 @@ static int launch_mixture_eval_mfma(gmmvi_ctx* ctx, int family, float nu, int K,
     float* lp_k = lp;
     float* grad_k = grad;
     float* lp2_k = lp2;
+    // the merge of the chunk partials: its own launch, or (single-call iteration) left to the next launch
+    const bool defer = ctx->defer_combine && ky > 1 && want_merge;
+    if (defer) {
+        int rc = gmmvi_flush_pending_combine(ctx);
+        if (rc != GMMVI_OK) return rc;
+    }
     if (ky > 1 && want_merge) {
         size_t need = ((size_t)ky * N * (logw2 ? 2 : 1) + (want_grad ? (size_t)ky * N * D : 0)) * sizeof(float);
-        int rc = gmmvi_ws_reserve(ctx, need);
+        int rc = defer ? gmmvi_defer_reserve(ctx, need) : gmmvi_ws_reserve(ctx, need);
         if (rc != GMMVI_OK) return rc;
-        lp_k = (float*)ctx->ws;
+        lp_k = (float*)(defer ? ctx->defer_ws : ctx->ws);
         lp2_k = logw2 ? lp_k + (size_t)ky * N : nullptr;
         grad_k = want_grad ? lp_k + (size_t)ky * N * (logw2 ? 2 : 1) : nullptr;
     }
-    dim3 grid(tiles, ky), block(nw * 64);
+    const CombineJob carried = gmmvi_take_pending_combine(ctx, nw * 64, tiles);
+    dim3 grid(tiles + carried.blocks, ky), block(nw * 64);
     {
         GMMVI_PROF_UNITS(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval", (double)N * K);
 #define GMMVI_LAUNCH_MM(FAM, G)                                                                                     \
@@ -558,7 +568,7 @@ static int launch_mixture_eval_mfma(gmmvi_ctx* ctx, int family, float nu, int K,
             GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_mfma_kernel<DP, FAM, G, NTS>,        \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
         hipLaunchKernelGGL((mixture_eval_mfma_kernel<DP, FAM, G, NTS>), grid, block, shmem, ctx->stream, nu, K, D,  \
-                           packed, logw, X, N, ld, lp_k, grad_k, logw2, lp2_k);                                      \
+                           packed, logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried);                             \
     } while (0)
         if (family == GMMVI_GAUSS) {
             if (want_grad) GMMVI_LAUNCH_MM(GMMVI_GAUSS, true); else GMMVI_LAUNCH_MM(GMMVI_GAUSS, false);
@@ -568,7 +578,12 @@ static int launch_mixture_eval_mfma(gmmvi_ctx* ctx, int family, float nu, int K,
 #undef GMMVI_LAUNCH_MM
     }
     GMMVI_LAUNCH_CHECK(ctx);
-    if (ky > 1 && want_merge) {
+    if (defer) {
+        CombineJob& j = ctx->pending;
+        j.R = ky; j.N = N; j.D = D;
+        j.lp_parts = lp_k; j.grad_parts = grad_k; j.lp2_parts = lp2_k;
+        j.lp_out = lp; j.grad_out = grad; j.lp2_out = lp2_k ? lp2 : nullptr;
+    } else if (ky > 1 && want_merge) {
         GMMVI_PROF(ctx, "mixture_combine");
         int rc = gmmvi_combine_partials_internal(ctx, ky, N, D, lp_k, grad_k, lp, grad, lp2_k, lp2);
         if (rc != GMMVI_OK) return rc;
@@ -623,15 +638,22 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     float* lp_k = lp;
     float* grad_k = grad;
     float* lp2_k = lp2;
+    // the merge of the chunk partials: its own launch, or (single-call iteration) left to the next launch
+    const bool defer = ctx->defer_combine && ky > 1 && want_merge;
+    if (defer) {
+        int rc = gmmvi_flush_pending_combine(ctx);
+        if (rc != GMMVI_OK) return rc;
+    }
     if (ky > 1 && want_merge) {
         size_t need = ((size_t)ky * N * (logw2 ? 2 : 1) + (want_grad ? (size_t)ky * N * D : 0)) * sizeof(float);
-        int rc = gmmvi_ws_reserve(ctx, need);
+        int rc = defer ? gmmvi_defer_reserve(ctx, need) : gmmvi_ws_reserve(ctx, need);
         if (rc != GMMVI_OK) return rc;
-        lp_k = (float*)ctx->ws;
+        lp_k = (float*)(defer ? ctx->defer_ws : ctx->ws);
         lp2_k = logw2 ? lp_k + (size_t)ky * N : nullptr;
         grad_k = want_grad ? lp_k + (size_t)ky * N * (logw2 ? 2 : 1) : nullptr;
     }
-    dim3 grid(tiles, ky), block(nw * 64);
+    const CombineJob carried = gmmvi_take_pending_combine(ctx, nw * 64, tiles);
+    dim3 grid(tiles + carried.blocks, ky), block(nw * 64);
     {
         GMMVI_PROF_UNITS(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval", (double)N * K);
 #define GMMVI_LAUNCH_ME(FAM, G)                                                                                     \
@@ -640,7 +662,7 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
             GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_kernel<DP, FAM, G>,               \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
         hipLaunchKernelGGL((mixture_eval_kernel<DP, FAM, G>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
-                           logw, X, N, ld, lp_k, grad_k, logw2, lp2_k);                                               \
+                           logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried);                                      \
     } while (0)
         if (family == GMMVI_GAUSS) {
             if (want_grad) GMMVI_LAUNCH_ME(GMMVI_GAUSS, true); else GMMVI_LAUNCH_ME(GMMVI_GAUSS, false);
@@ -650,7 +672,12 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
 #undef GMMVI_LAUNCH_ME
     }
     GMMVI_LAUNCH_CHECK(ctx);
-    if (ky > 1 && want_merge) {
+    if (defer) {
+        CombineJob& j = ctx->pending;
+        j.R = ky; j.N = N; j.D = D;
+        j.lp_parts = lp_k; j.grad_parts = grad_k; j.lp2_parts = lp2_k;
+        j.lp_out = lp; j.grad_out = grad; j.lp2_out = lp2_k ? lp2 : nullptr;
+    } else if (ky > 1 && want_merge) {
         GMMVI_PROF(ctx, "mixture_combine");
         int rc = gmmvi_combine_partials_internal(ctx, ky, N, D, lp_k, grad_k, lp, grad, lp2_k, lp2);
         if (rc != GMMVI_OK) return rc;

@@ -79,6 +79,14 @@ extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan
         GMMVI_TRY(gmmvi_sample_components_prep(ctx, K, D, p->means, p->chols, p->offsets, N, (N + K - 1) / K, p->seed,
                                                p->first_index, x, p->db_mapping, p->mapping_base, q));
     }
+    // ---- background + model density / gradient in one sweep (sample_db.py:194-228, gmm.py:274-300) ------------------------
+    // issued BEFORE the target evaluation, which does not depend on it: the merge of the sweep's component-chunk partials
+    // rides as extra workgroups in the target launch instead of a launch of its own (combine.h; same arithmetic)
+    ctx->defer_combine = true;
+    int rc_dual = gmmvi_mixture_eval_dual(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, p->logw, p->bg_logw, x, N, a.ld, a.lq,
+                                          a.qgrad, a.bg);
+    ctx->defer_combine = false;
+    GMMVI_TRY(rc_dual);
     if (p->target_kind == 1) {
         GMMVI_TRY(gmmvi_target_planar(ctx, D, p->planar_prior_std, p->planar_goals_count, p->planar_goals,
                                       p->planar_likelihood_std, x, N, p->db_tlp, p->db_tgrad));
@@ -86,9 +94,7 @@ extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan
         GMMVI_TRY(gmmvi_mixture_eval(ctx, p->target_family, p->target_nu, p->target_K, D, p->target_packed,
                                      p->target_logw, x, N, nullptr, p->db_tlp, p->db_tgrad));
     }
-    // ---- background + model density / gradient in one sweep (sample_db.py:194-228, gmm.py:274-300) ------------------------
-    GMMVI_TRY(gmmvi_mixture_eval_dual(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, p->logw, p->bg_logw, x, N, a.ld, a.lq, a.qgrad,
-                                      a.bg));
+    GMMVI_TRY(gmmvi_flush_pending_combine(ctx));       // nothing left unless the target launch could not carry it
     // ---- component update (gmmvi.py:165-169) -----------------------------------------------------------------------------
     // the Stein estimate stops at its partial slab; its last step (slab sum, Sigma^-1, normalisation) is the prologue of the
     // update kernel where that is instantiated, the stand-alone launch otherwise -- the same arithmetic either way
@@ -98,7 +104,11 @@ extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan
                                                    p->stepsizes, p->temperature, p->l2_init, p->last_eta, p->l2, p->num_updates,
                                                    p->success_out ? p->success_out : a.success, p->packed_new));
     // ---- weight update (gmmvi.py:172-173) ---------------------------------------------------------------------------------
-    GMMVI_TRY(gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed_new, p->logw, x, N, a.ld, a.lq, nullptr));
+    // (the merge of this sweep's log-density partials happens inside the expected-log-ratio kernel)
+    ctx->defer_combine = true;
+    int rc_post = gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed_new, p->logw, x, N, a.ld, a.lq, nullptr);
+    ctx->defer_combine = false;
+    GMMVI_TRY(rc_post);
     GMMVI_TRY(gmmvi_expected_log_ratios(ctx, K, N, a.ld, a.bg, p->db_tlp, a.lq, p->temperature, p->logw,
                                         (p->stein_flags & GMMVI_SELF_NORMALIZED) ? 1 : 0, a.E, p->reward_next, nullptr));
     if (K > 1) {

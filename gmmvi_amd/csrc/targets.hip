@@ -2,10 +2,12 @@
 // differentiates it with GradientTape, sample_selector.py:74-77).  GMM and Student-t mixture targets go through
 // gmmvi_mixture_eval (density.hip).
 #include "common.h"
+#include "combine.h"
 
 __global__ void planar_kernel(int D, const float* __restrict__ prior_std, int G, const float* __restrict__ goals,
                               float lik_std, const float* __restrict__ X, int N, float* __restrict__ lp,
-                              float* __restrict__ grad) {
+                              float* __restrict__ grad, CombineJob carried) {
+    if (combine_carried(carried)) return;              // workgroups past the samples: the merge of the previous sweep
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float* th = X + (size_t)n * D;
@@ -49,8 +51,9 @@ extern "C" int gmmvi_target_planar(gmmvi_ctx* ctx, int D, const float* prior_std
     if (N == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, prior_std_dev && goals_dev && X_dev);
     GMMVI_PROF(ctx, "target_planar");
-    hipLaunchKernelGGL(planar_kernel, dim3((N + 127) / 128), dim3(128), 0, ctx->stream, D, prior_std_dev, G, goals_dev,
-                       likelihood_std, X_dev, N, lp_out_dev, grad_out_dev);
+    const CombineJob carried = gmmvi_take_pending_combine(ctx, 128, (N + 127) / 128);
+    hipLaunchKernelGGL(planar_kernel, dim3((N + 127) / 128 + carried.blocks), dim3(128), 0, ctx->stream, D, prior_std_dev, G,
+                       goals_dev, likelihood_std, X_dev, N, lp_out_dev, grad_out_dev, carried);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }

@@ -4,6 +4,7 @@
 #include "common.h"
 #include "stepsize_rules.h"
 #include "wave_reduce.h"
+#include "combine.h"
 #include <cfloat>
 
 namespace {
@@ -29,24 +30,38 @@ __device__ float block_sum(float v, float* red) {
 
 // One 1024-thread workgroup per component: E_k = sum_n softmax_n(ld[k,n] - bg[n]) * (tlp[n] - beta logq[n]) in a single
 // pass (per-thread running maximum with rescaling), then a fixed-order tree over the 16 waves.
+// logq_R > 0: logq holds the logq_R chunk partials [logq_R][N] of a component-split sweep, merged here as combine.h does.
 __global__ __launch_bounds__(1024) void elr_kernel(int N, const float* __restrict__ ld, const float* __restrict__ bg,
-                                                   const float* __restrict__ tlp, const float* __restrict__ logq, float beta,
-                                                   const float* __restrict__ logw, int self_normalized,
+                                                   const float* __restrict__ tlp, const float* __restrict__ logq, int logq_R,
+                                                   float beta, const float* __restrict__ logw, int self_normalized,
                                                    float* __restrict__ E_out, float* __restrict__ reward_out,
                                                    float* __restrict__ ess_out) {
     __shared__ float red[4][16];
     const int k = blockIdx.x;
     const float* row = ld + (size_t)k * N;
     float m = -3.0e38f, s = 0.f, se = 0.f, s2 = 0.f;
-    for (int n = threadIdx.x; n < N; n += 1024) {
-        const float a = row[n] - bg[n];
-        const float rho = tlp[n] - beta * logq[n];
-        const float mn = fmaxf(m, a);
-        const float sc = __expf(m - mn), e = __expf(a - mn);
-        s = fmaf(s, sc, e);
-        se = fmaf(se, sc, e * rho);
-        s2 = fmaf(s2, sc * sc, e * e);
-        m = mn;
+    // four samples per round with their loads in flight together (the kernel is a latency chain: ~10 rounds per thread at
+    // N = 10^4); accumulated in the order n = t, t + 1024, ...
+    for (int n0 = threadIdx.x; n0 < N; n0 += 4096) {
+        float av[4], rv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = min(n0 + 1024 * u, N - 1);
+            av[u] = row[n] - bg[n];
+            rv[u] = tlp[n] - beta * (logq_R > 0 ? combine_log_values(logq, logq_R, N, n) : logq[n]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (n0 + 1024 * u < N) {
+                const float a = av[u], rho = rv[u];
+                const float mn = fmaxf(m, a);
+                const float sc = __expf(m - mn), e = __expf(a - mn);
+                s = fmaf(s, sc, e);
+                se = fmaf(se, sc, e * rho);
+                s2 = fmaf(s2, sc * sc, e * e);
+                m = mn;
+            }
+        }
     }
     // wave level
     const float mw = wmax(m);
@@ -225,8 +240,22 @@ int gmmvi_expected_log_ratios(gmmvi_ctx* ctx, int K, int N, const float* ld_dev,
                               int self_normalized, float* E_out_dev, float* reward_out_dev, float* ess_out_dev) {
     GMMVI_ARG_CHECK(ctx, K >= 1 && N >= 1);
     GMMVI_ARG_CHECK(ctx, ld_dev && bg_dev && tlp_dev && logq_dev && logw_dev);
+    // a deferred merge (single-call iteration): log values of the post-update sweep are merged while they are read; anything
+    // else still pending is launched first
+    int logq_R = 0;
+    {
+        const CombineJob& j = ctx->pending;
+        if (j.R > 0 && j.lp_out == logq_dev && j.N == N && !j.grad_out && !j.lp2_out) {
+            logq_R = j.R;
+            logq_dev = j.lp_parts;
+            ctx->pending = CombineJob();
+        } else {
+            int rc = gmmvi_flush_pending_combine(ctx);
+            if (rc != GMMVI_OK) return rc;
+        }
+    }
     GMMVI_PROF(ctx, "expected_log_ratios");
-    hipLaunchKernelGGL(elr_kernel, dim3(K), dim3(1024), 0, ctx->stream, N, ld_dev, bg_dev, tlp_dev, logq_dev, beta,
+    hipLaunchKernelGGL(elr_kernel, dim3(K), dim3(1024), 0, ctx->stream, N, ld_dev, bg_dev, tlp_dev, logq_dev, logq_R, beta,
                        logw_dev, self_normalized, E_out_dev, reward_out_dev, ess_out_dev);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
