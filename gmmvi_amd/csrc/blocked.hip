@@ -1234,6 +1234,251 @@ __global__ __launch_bounds__(1024) void blk_tridiag_kernel(int D, int DT, int G,
     }
 }
 
+// The same reduction with the matrix in REGISTERS (D <= 320): NW = 8 wavefronts (two per SIMD: 256 registers a thread),
+// wavefront tj owns rows j = tj + NW a (a < BR), lane l columns i = l + 64 b (b < BC), a thread keeps its BR x BC elements for
+// the whole kernel (D = 300: 38 x 5 on 512 threads, 380 KB of the CU's 512 KB register file; with 16 wavefronts the 128
+// registers a thread gets spill ~20 of them to scratch and the kernel is no faster than the global-memory one) -- a step no longer streams the trailing block through the L2 (the
+// global-memory kernel above is bound by the ~8 loads a thread keeps in flight: 8 us per step at D = 300).  Per step a thread
+// needs the reflector vectors at its rows (uniform in the wavefront: 16-byte broadcast reads from a copy stored in row order
+// [tj][a]) and at its columns (one value per lane), 3 BR + 2 BC values for BR BC elements.  Rows / columns that are already
+// reduced see v = q = 0 and stay bit-exact; whole 4-row blocks and 64-column blocks of them are skipped.  (The update is
+// symmetric up to the rounding of the fused multiply-add the compiler contracts it to.)  Row c+1 of the
+// matrix (the source of the next reflector) lives in one wavefront, one value per lane and column block: it goes to LDS.  The per-column state
+// (p, v_i, the running w~) lives in thread i.  Four barriers per step: every thread recomputes q_{c+1} from the partial
+// sums, so the next column can be formed without waiting for q.
+__device__ __forceinline__ float blk_q_elem(float p, float kk, float v) { return p - kk * v; }
+
+template <int NW, int BR, int BC>
+__global__ __launch_bounds__(64 * NW) void blk_tridiag_reg_kernel(int D, const float* __restrict__ Mall, float* __restrict__ wt_all,
+                                                               float* __restrict__ td_all, float* __restrict__ te_all) {
+    constexpr int RBP = (BR + 3) / 4 * 4;          // row slots per wavefront in the row-order copies
+    constexpr int NBK = RBP / 4;
+    constexpr int DT = 64 * BC;
+    constexpr int NWS = NW == 16 ? 4 : (NW == 8 ? 3 : 2);           // log2(NW)
+    static_assert(NW == 16 || NW == 8 || NW == 4, "row classes: a power of two");
+    static_assert(64 * NW >= DT, "one state thread per column");
+    extern __shared__ __align__(16) float sm[];
+    float* vNa = sm;                               // reflector (two buffers: current / next), natural order
+    float* vNb = sm + DT;
+    float* qN = sm + 2 * DT;
+    float* xn = sm + 3 * DT;                       // row c+1
+    float* vRa = sm + 4 * DT;                      // the same vectors in row order: element j at (j % NW) RBP + j / NW
+    float* vRb = sm + 4 * DT + NW * RBP;
+    float* qR = sm + 4 * DT + 2 * NW * RBP;
+    float* part = sm + 4 * DT + 3 * NW * RBP;      // [NW][DT] partial products
+    float* red = part + NW * DT;                   // [48]
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int tj = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* M = Mall + (size_t)k * D * D;
+    float* te = te_all + (size_t)k * D;
+    const int i = tid;                             // the column whose state this thread keeps
+    const bool cs = tid < D;
+    const int pr = (i & (NW - 1)) * RBP + (i >> NWS);
+    float wti = cs ? wt_all[(size_t)k * D + i] : 0.f;
+    for (int e = tid; e < 4 * DT + 3 * NW * RBP; e += 64 * NW) sm[e] = 0.f;
+
+    float m[BR][BC];
+#pragma unroll
+    for (int a = 0; a < BR; ++a)
+#pragma unroll
+        for (int b = 0; b < BC; ++b) {
+            const int j = tj + NW * a, ci = lane + 64 * b;
+            m[a][b] = (j < D && ci < D) ? M[(size_t)j * D + ci] : 0.f;
+        }
+    __syncthreads();
+
+    // reflector from the sub-diagonal part x of a column (x_i in thread i), tail = sum_{i > c+1} x_i^2: writes v (both orders),
+    // alpha or the untouched sub-diagonal entry to te[c]; returns v_i, sets beta_out
+    auto reflector = [&](int c, float xi, float x1, float tail, int buf, float& beta_out) {
+        float v_here = 0.f;
+        if (!(tail > 0.f)) {                       // column already tridiagonal (NaN lands here too: handled by the search)
+            beta_out = 0.f;
+            if (tid == 0) te[c] = x1;
+        } else {
+            const float nrm = sqrtf(tail + x1 * x1);
+            const float alpha = (x1 > 0.f) ? -nrm : nrm;
+            beta_out = 1.f / (nrm * nrm - alpha * x1);
+            v_here = (cs && i > c) ? (i == c + 1 ? x1 - alpha : xi) : 0.f;
+            if (tid == 0) te[c] = alpha;
+        }
+        if (cs) { (buf ? vNb : vNa)[i] = v_here; (buf ? vRb : vRa)[pr] = v_here; }
+        return v_here;
+    };
+    auto column_sum = [&](int col) {               // fixed order over the NW row classes
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < NW; ++g) s += part[g * DT + col];
+        return s;
+    };
+
+    float beta = 0.f, vi = 0.f, p = 0.f, pc1 = 0.f;
+    if (D >= 3) {
+        // step 0: reflector of column 0, p = beta M v
+        const float x1 = M[1];
+        const float xi = (cs && i > 0) ? M[i] : 0.f;
+        float t2 = gmmvi_wave_sum((cs && i > 1) ? xi * xi : 0.f);
+        if (lane == 0) red[32 + tj] = t2;
+        __syncthreads();
+        float tail = 0.f;
+#pragma unroll
+        for (int g = 0; g < NW; ++g) tail += red[32 + g];
+        vi = reflector(0, xi, x1, tail, 0, beta);
+        __syncthreads();
+        {
+            float acc[BC];
+#pragma unroll
+            for (int b = 0; b < BC; ++b) acc[b] = 0.f;
+#pragma unroll
+            for (int a = 0; a < BR; ++a) {
+                const float vr = vRa[tj * RBP + a];
+#pragma unroll
+                for (int b = 0; b < BC; ++b) acc[b] = fmaf(m[a][b], vr, acc[b]);
+            }
+#pragma unroll
+            for (int b = 0; b < BC; ++b) part[tj * DT + lane + 64 * b] = acc[b];
+        }
+        __syncthreads();
+        p = (cs && i > 0) ? beta * column_sum(i) : 0.f;
+        pc1 = beta * column_sum(1);
+    }
+    int cur = 0;
+#ifdef GMMVI_TRI_STAMPS
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
+#define TRI_STAMP(x) do { const long long tn = wall_clock64(); tacc[x] += tn - tprev; tprev = tn; } while (0)
+#else
+#define TRI_STAMP(x)
+#endif
+    for (int c = 0; c + 2 < D; ++c) {
+        const bool more = c + 3 < D;                   // another reflector follows
+        const int a_lo = c >= tj ? ((c - tj) >> NWS) + 1 : 0;             // first live row slot of this wavefront (rows > c)
+        const int b_lo = (c + 1) >> 6;                                 // first column block with a live column
+        const float* vNc = cur ? vNb : vNa;
+        const float* vRc = (cur ? vRb : vRa) + tj * RBP;
+        // row c+1 (not yet updated) into LDS: it lives in ONE wavefront (tj = (c+1) % NW, slot (c+1) / NW), spread over the lanes
+        if (more && tj == ((c + 1) & (NW - 1))) {
+            // run-time (uniform) slot -> static register index: two levels of scalar branches
+            const int asel = (c + 1) >> NWS, ahi = asel >> 3, alo = asel & 7;
+#pragma unroll
+            for (int hi = 0; hi < (BR + 7) / 8; ++hi) {
+                if (hi == ahi) {
+#pragma unroll
+                    for (int lo = 0; lo < 8; ++lo) {
+                        if (8 * hi + lo < BR && lo == alo) {
+#pragma unroll
+                            for (int b = 0; b < BC; ++b) xn[lane + 64 * b] = m[8 * hi + lo][b];
+                        }
+                    }
+                }
+            }
+        }
+        float s_vp = gmmvi_wave_sum(vi * p), s_vw = gmmvi_wave_sum(vi * wti);
+        if (lane == 0) { red[tj] = s_vp; red[16 + tj] = s_vw; }
+        TRI_STAMP(0);
+        __syncthreads();                                                               // 1
+        TRI_STAMP(1);
+        s_vp = 0.f; s_vw = 0.f;
+#pragma unroll
+        for (int g = 0; g < NW; ++g) { s_vp += red[g]; s_vw += red[16 + g]; }
+        const float kk = 0.5f * beta * s_vp;
+        const float wdot = beta * s_vw;
+        const float q_i = (cs && i > c) ? blk_q_elem(p, kk, vi) : 0.f;
+        if (cs) { qN[i] = q_i; qR[pr] = q_i; }
+        wti -= wdot * vi;
+        float beta_n = 0.f, vi_n = 0.f, xv = 0.f;
+        if (more) {
+            // row c+1 of the updated matrix: its entries right of the diagonal are the next column
+            const float vc1 = vNc[c + 1];
+            const float qc1 = blk_q_elem(pc1, kk, vc1);
+            if (cs && i > c) {
+                xv = xn[i] - __fadd_rn(__fmul_rn(vc1, q_i), __fmul_rn(qc1, vi));
+                xn[i] = xv;
+            }
+            const float t2 = gmmvi_wave_sum((cs && i > c + 2) ? xv * xv : 0.f);
+            if (lane == 0) red[32 + tj] = t2;
+        }
+        __syncthreads();                                                               // 2
+        TRI_STAMP(2);
+        if (more) {
+            float tail = 0.f;
+#pragma unroll
+            for (int g = 0; g < NW; ++g) tail += red[32 + g];
+            vi_n = reflector(c + 1, (cs && i > c + 1) ? xv : 0.f, xn[c + 2], tail, cur ^ 1, beta_n);
+        }
+        __syncthreads();                                                               // 3
+        TRI_STAMP(3);
+        // one sweep: M[j][i] -= v_j q_i + q_j v_i, and the partial product with the next reflector.  Row blocks outermost: the
+        // three 16-byte broadcast reads of a block serve all the thread's column blocks
+        {
+            const float* vRn = (cur ? vRa : vRb) + tj * RBP;
+            const float* qRc = qR + tj * RBP;
+            float vcb[BC], qcb[BC], acc[BC];
+#pragma unroll
+            for (int b = 0; b < BC; ++b) {
+                vcb[b] = vNc[lane + 64 * b]; qcb[b] = qN[lane + 64 * b];
+                acc[b] = 0.f;
+            }
+#pragma unroll
+            for (int blk = 0; blk < NBK; ++blk) {
+                if (4 * blk + 3 >= a_lo) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(vRc + 4 * blk);
+                    const float4 q4 = *reinterpret_cast<const float4*>(qRc + 4 * blk);
+                    const float4 w4 = *reinterpret_cast<const float4*>(vRn + 4 * blk);
+                    const float vv[4] = {v4.x, v4.y, v4.z, v4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w};
+                    const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int b = 0; b < BC; ++b) {
+                        if (b >= b_lo) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                if (4 * blk + u < BR) {
+                                    const float mn = m[4 * blk + u][b] - __fadd_rn(__fmul_rn(vv[u], qcb[b]), __fmul_rn(qq[u], vcb[b]));
+                                    m[4 * blk + u][b] = mn;
+                                    acc[b] = fmaf(mn, ww[u], acc[b]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < BC; ++b)
+                if (b >= b_lo) part[tj * DT + lane + 64 * b] = acc[b];
+        }
+        TRI_STAMP(4);
+        __syncthreads();                                                               // 4
+        p = (more && cs && i > c + 1) ? beta_n * column_sum(i) : 0.f;
+        pc1 = more ? beta_n * column_sum(c + 2) : 0.f;
+        beta = beta_n;
+        vi = vi_n;
+        cur ^= 1;
+        TRI_STAMP(5);
+    }
+#ifdef GMMVI_TRI_STAMPS
+    if (blockIdx.x == 0 && (tid == 0 || tid == 64 * NW - 1))
+        printf("tridiag stamps (100 MHz ticks) tid %d: dump+sums %lld, barrier1 %lld, q/xv+barrier2 %lld, reflector+barrier3 %lld, sweep %lld, barrier4+colsum %lld\n",
+               tid, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5]);
+#endif
+#pragma unroll
+    for (int a = 0; a < BR; ++a)
+#pragma unroll
+        for (int b = 0; b < BC; ++b) {
+            const int j = tj + NW * a, ci = lane + 64 * b;
+            if (j == ci && ci < D) td_all[(size_t)k * D + ci] = m[a][b];
+            if (D >= 2 && j == D - 1 && ci == D - 2) te[D - 2] = m[a][b];
+        }
+    if (cs) wt_all[(size_t)k * D + i] = wti;
+}
+
+// instance (rows per wavefront, column blocks) of the register-resident tridiagonalisation; 0 = D > 320, the global-memory
+// kernel runs
+static int blk_tridiag_instance(int D) {
+    if (D > 320) return 0;
+    const int br = (D + 7) / 8, bc = (D + 63) / 64;
+    const int brs[] = {8, 16, 24, 32, 38, 40};
+    for (int r : brs) if (br <= r) return r * 8 + bc;
+    return 0;
+}
+
 // KL(eta) from the tridiagonal form (update_kl.hip kl_tridiag), pivots kept in a global scratch column per lane
 __device__ __forceinline__ float blk_kl_tridiag(int D, const float* td, const float* te, const float* wt, float* scratch,
                                                 float eta) {
@@ -1497,8 +1742,21 @@ int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* c
         const int DT = blk_threads(D);
         int G = 1024 / DT;
         if (G < 1) G = 1;
-        const size_t shmem = ((size_t)4 * D + (size_t)G * DT + 48) * sizeof(float);
-        hipLaunchKernelGGL(blk_tridiag_kernel, dim3(K), dim3(G * DT), shmem, ctx->stream, D, DT, G, M, wt, td, te);
+        static const bool no_reg = getenv("GMMVI_BLOCKED_TRIDIAG_GLOBAL") != nullptr;         // experiments
+        const int inst = no_reg ? 0 : blk_tridiag_instance(D);
+        if (inst > 0) {
+            const int br = inst / 8, bc = inst % 8;
+            const size_t shmem = ((size_t)4 * 64 * bc + (size_t)24 * ((br + 3) / 4 * 4) + (size_t)8 * 64 * bc + 48) * sizeof(float);
+#define BLK_TRIDIAG_REG(BRV, BCV)                                                                                         \
+    if (br == BRV && bc == BCV)                                                                                           \
+        hipLaunchKernelGGL((blk_tridiag_reg_kernel<8, BRV, BCV>), dim3(K), dim3(512), shmem, ctx->stream, D, M, wt, td, te)
+            BLK_TRIDIAG_REG(8, 1); BLK_TRIDIAG_REG(16, 2); BLK_TRIDIAG_REG(24, 3); BLK_TRIDIAG_REG(32, 4);
+            BLK_TRIDIAG_REG(38, 5); BLK_TRIDIAG_REG(40, 5);
+#undef BLK_TRIDIAG_REG
+        } else {
+            const size_t shmem = ((size_t)4 * D + (size_t)G * DT + 48) * sizeof(float);
+            hipLaunchKernelGGL(blk_tridiag_kernel, dim3(K), dim3(G * DT), shmem, ctx->stream, D, DT, G, M, wt, td, te);
+        }
         GMMVI_LAUNCH_CHECK(ctx);
     }
     hipLaunchKernelGGL(blk_search_kernel, dim3(K), dim3(64), (size_t)3 * D * sizeof(float), ctx->stream, D, td, te, wt, stepsizes,
