@@ -15,13 +15,26 @@ MORE_REGISTER_MAX_DIM = 21     # gmmvi_more: register-resident ridge system up t
 BLOCKED_ABOVE_DEFAULT = 50     # csrc/blocked.h: D > 50 runs the blocked (MFMA) kernels
 
 
+_blocked_above = None
+
+
+def _atoi(text):
+    """C atoi: optional sign and leading digits, anything else ends the number (no digits: 0)."""
+    import re
+    m = re.match(r"\s*([+-]?\d+)", text)
+    return int(m.group(1)) if m else 0
+
+
 def blocked_above():
-    """Dimensions above this take the blocked (MFMA) path: csrc/blocked.h gmmvi_blocked_above(), same environment knob."""
-    try:
-        t = int(os.environ.get("GMMVI_BLOCKED_ABOVE", BLOCKED_ABOVE_DEFAULT))
-    except ValueError:
-        t = BLOCKED_ABOVE_DEFAULT
-    return min(max(t, 16), MAX_DIM)
+    """Dimensions above this take the blocked (MFMA) path.  Mirrors csrc/blocked.h gmmvi_blocked_above(): the environment
+    knob GMMVI_BLOCKED_ABOVE is read ONCE per process (the library keeps it in a static), parsed as atoi does, clamped to
+    16..64."""
+    global _blocked_above
+    if _blocked_above is None:
+        raw = os.environ.get("GMMVI_BLOCKED_ABOVE")
+        t = BLOCKED_ABOVE_DEFAULT if raw is None else _atoi(raw)
+        _blocked_above = min(max(t, 16), MAX_DIM)
+    return _blocked_above
 
 
 class GmmviError(RuntimeError):

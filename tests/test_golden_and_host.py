@@ -140,13 +140,19 @@ def test_alias_package_maps_reference_module_paths():
 
 
 def test_blocked_threshold_knob(monkeypatch):
-    """gmmvi_amd._lib.blocked_above() mirrors csrc/blocked.h gmmvi_blocked_above(): default 50, clamped to 16..64."""
+    """gmmvi_amd._lib.blocked_above() mirrors csrc/blocked.h gmmvi_blocked_above(): default 50, atoi parsing, clamped to 16..64,
+    read once per process (as the library's static is)."""
     from gmmvi_amd import _lib
+    monkeypatch.setattr(_lib, "_blocked_above", None)
     monkeypatch.delenv("GMMVI_BLOCKED_ABOVE", raising=False)
     assert _lib.blocked_above() == _lib.BLOCKED_ABOVE_DEFAULT == 50
-    for raw, want in (("32", 32), ("5", 16), ("200", 64), ("junk", 50)):
+    monkeypatch.setenv("GMMVI_BLOCKED_ABOVE", "32")
+    assert _lib.blocked_above() == 50                  # cached: the two sides cannot disagree within one process
+    for raw, want in (("32", 32), ("5", 16), ("200", 64), ("junk", 16), ("40x", 40)):
+        monkeypatch.setattr(_lib, "_blocked_above", None)
         monkeypatch.setenv("GMMVI_BLOCKED_ABOVE", raw)
         assert _lib.blocked_above() == want
+    monkeypatch.setattr(_lib, "_blocked_above", None)
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gmmvi_amd", "csrc", "blocked.h")).read()
     assert "atoi(s) : 50" in src                       # the C side carries the same default
 
