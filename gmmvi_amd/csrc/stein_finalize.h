@@ -20,15 +20,13 @@ inline size_t stein_finalize_lds_floats(int dp, int D, int R) {
 // columns (L from the packed block: 1/diag, rows, columns, staged in LDS; the row in registers, loops unrolled for the padded
 // dimension).  Blocks with fragments (DP >= 32): two triangular products with the explicit inverse on all threads.
 // A: LDS, stein_finalize_lds_floats(DP, D, R) floats.  Ends with the results in global memory (no trailing barrier).
-template <int DP>
-__device__ __forceinline__ void stein_finalize_component(float* A, int k, int D, int R, int N, int flags,
-                                                         const float* __restrict__ part, const float* __restrict__ part_m,
-                                                         float* H_neg, float* g_neg, const float* __restrict__ packed) {
-    using PK = Pack<DP>;
+// A[(D+1)^2] <- sum over the R partials of component k, each referred to its own maximum m_r, rescaled to the common maximum
+// (returned).  Every element is summed by exactly one thread over r = 0, 1, ... in eight interleaved chains, so the result
+// does not depend on the number of threads.  scale_r: R floats of LDS.  Ends with a barrier.
+__device__ __forceinline__ float stein_slab_sum(float* A, float* scale_r, int k, int D, int R, const float* __restrict__ part,
+                                                const float* __restrict__ part_m) {
     const int nth = blockDim.x;
     const int D1 = D + 1;
-    float* scale_r = A + D1 * D1;
-    float* Wk = scale_r + R;                                               // work area
     float M = -3.0e38f;
     for (int r = threadIdx.x & 63; r < R; r += 64) M = fmaxf(M, part_m[(size_t)k * R + r]);
     M = gmmvi_wave_max(M);
@@ -46,6 +44,26 @@ __device__ __forceinline__ void stein_finalize_component(float* A, int k, int D,
         A[e] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
     __syncthreads();
+    return M;
+}
+
+// normalisation of the summed moments: 1 / sum e (self-normalised; 0 over an empty set), exp(M) / N (plain importance
+// weights), 1 / sum e = exp(M) / n_own for plain weights over the component's own samples
+__device__ __forceinline__ float stein_moment_scale(float se, float M, int N, int flags) {
+    const bool snis = (flags & GMMVI_SELF_NORMALIZED) != 0, own = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
+    return snis ? (se > 0.f ? 1.f / se : 0.f) : (own ? 1.f / se : __expf(M) / (float)N);
+}
+
+template <int DP>
+__device__ __forceinline__ void stein_finalize_component(float* A, int k, int D, int R, int N, int flags,
+                                                         const float* __restrict__ part, const float* __restrict__ part_m,
+                                                         float* H_neg, float* g_neg, const float* __restrict__ packed) {
+    using PK = Pack<DP>;
+    const int nth = blockDim.x;
+    const int D1 = D + 1;
+    float* scale_r = A + D1 * D1;
+    float* Wk = scale_r + R;                                               // work area
+    const float M = stein_slab_sum(A, scale_r, k, D, R, part, part_m);
     if constexpr (PK::FRAGS) {
         // blocks that carry L^-1 (operand fragments, common.h): Sigma^-1 from the right as two triangular products spread over
         // the whole workgroup -- W = T L^-T, then W L^-1 -- instead of two substitution chains on D threads
@@ -112,11 +130,10 @@ __device__ __forceinline__ void stein_finalize_component(float* A, int k, int D,
     // plain importance weights: 1/N * sum exp(ld - bg) v   (ng_estimator.py:146-152), Hessian not symmetrised
     // with only_use_own_samples the expectation runs over the component's own samples only (get_rewards_for_comp,
     // ng_estimator.py:110-118: weights exp(0) = 1, divisor = their number): sum e = n_own exp(-M) => exp(M) / n_own = 1 / sum e
-    const bool own = (flags & GMMVI_OWN_SAMPLES_ONLY) != 0;
     // self-normalised weights over an EMPTY own-sample set: every reduce_sum of the reference runs over nothing and returns
     // zeros (ng_estimator.py:171-188), the plain branch divides by the set's length (NaN, a rejected update)
     const float se = A[D * D1 + D];
-    const float scale = snis ? (se > 0.f ? 1.f / se : 0.f) : (own ? 1.f / se : __expf(M) / (float)N);
+    const float scale = stein_moment_scale(se, M, N, flags);
     for (int e = threadIdx.x; e < D * D; e += nth) {
         const int i = e / D, j = e % D;
         const float v = snis ? 0.5f * (A[i * D1 + j] + A[j * D1 + i]) : A[i * D1 + j];

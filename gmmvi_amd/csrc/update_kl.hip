@@ -135,19 +135,73 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
 #else
 #define UKL_STAMP(i)
 #endif
+    // single-call iteration: the Stein estimate arrives as its partial slab (stein_finalize.h).
+    //  * self-normalised weights (H symmetric): the whitened matrix is formed DIRECTLY from the moment matrix C = sum e g (x-mu)^T,
+    //    M = L^T (-sym(C Sigma^-1) / sum e) L = -sym(L^T C L^-T) / sum e, w = -L^T (sum e g) / sum e:
+    //    one product and one triangular substitution instead of two substitutions (Sigma^-1), a round trip of H through global
+    //    memory and two products.  H_neg / g_neg are not written on this route.
+    //  * plain importance weights (H not symmetric, its lower triangle is mirrored): the estimate is finished as the
+    //    stand-alone kernel does it, H_neg / g_neg go through global memory.
+    bool direct = false;
     if constexpr (DC > 0 && DC <= 24) {
-        // single-call iteration: the last step of the Stein estimate (stein_finalize.h) is this kernel's prologue -- same
-        // arithmetic as the stand-alone launch, one launch and its drain less; H_neg / g_neg still go to global memory
         if (slab.part != nullptr) {
-            stein_finalize_component<DC>(sm, k, D, slab.R, slab_N, slab_flags, slab.part, slab.part_m, H_neg, g_neg, packed_old);
-            __threadfence_block();
-            __syncthreads();
+            direct = (slab_flags & GMMVI_SELF_NORMALIZED) != 0 && (slab_flags & GMMVI_EXPLICIT_ESTIMATE) == 0 &&
+                     (DC + 1) * (DC + 1) + slab.R <= 2 * DC * 64;
+            if (!direct) {
+                stein_finalize_component<DC>(sm, k, D, slab.R, slab_N, slab_flags, slab.part, slab.part_m, H_neg, g_neg, packed_old);
+                __threadfence_block();
+                __syncthreads();
+            }
         }
     }
     float* Lg = chols + (size_t)k * D * D;
     float* mug = means + (size_t)k * D;
     const float* Rg = H_neg + (size_t)k * D * D;
 
+    if (direct) {
+        const int D1 = D + 1;
+        float* A = s.pr;                               // the probe scratch is idle until the search
+        const float Mx = stein_slab_sum(A, A + D1 * D1, k, D, slab.R, slab.part, slab.part_m);
+        const float scale = stein_moment_scale(A[D * D1 + D], Mx, slab_N, slab_flags);
+        for (int e = t; e < D * D; e += NTH) {
+            const int i = e / D, j = e % D;
+            s.L[i * ld + j] = (j <= i) ? Lg[e] : 0.f;
+        }
+        if (t < D) {
+            s.mu[t] = mug[t];
+            s.y[t] = -A[t * D1 + D] * scale;           // g~ = g_neg (H is symmetric: no correction)
+            s.v[t] = 1.f / Lg[t * D + t];
+        }
+        __syncthreads();
+        // P = L^T C (into Mc): P[i][j] = sum_{c >= i} L[c][i] C[c][j]
+        for (int o = t; o < D * D; o += NTH) {
+            const int i = o / D, j = o % D;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) a = fmaf(s.L[c * ld + i], A[c * D1 + j], a);          // L[c][i] = 0 for c < i
+            s.Mc[i * ld + j] = a;
+        }
+        __syncthreads();
+        // S L^T = P, row r by lane r (forward over the columns); M = -scale S, symmetrised below
+        if (t < D) {
+            float srow[DC > 0 ? DC : 1];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                float a = s.Mc[t * ld + j];
+#pragma unroll
+                for (int m2 = 0; m2 < j; ++m2) a = fmaf(-srow[m2], s.L[j * ld + m2], a);
+                srow[j] = a * s.v[j];
+            }
+#pragma unroll
+            for (int j = 0; j < D; ++j) s.M[t * ld + j] = -scale * srow[j];
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < D; ++c) a = fmaf(s.L[c * ld + t], s.y[c], a);
+            s.w[t] = a;
+            s.wt[t] = a;
+        }
+        __syncthreads();
+    } else {
     // ---- load: L, R_sym (lower triangle mirrored, as tf.linalg.cholesky reads only the lower part) into M -----------
     for (int e = t; e < D * D; e += NTH) {
         const int i = e / D, j = e % D;
@@ -186,6 +240,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
         s.wt[t] = a;
     }
     __syncthreads();
+    }
     for (int o = t; o < D * D; o += NTH) {          // exact symmetry for the reflectors; keep a copy for the final step
         const int i = o / D, j = o % D;
         if (j < i) {

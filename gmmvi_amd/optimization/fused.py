@@ -50,6 +50,9 @@ class SamtronFastPath:
         self.plan = SamtronPlan()
         self.enabled = os.environ.get("GMMVI_FAST_PATH", "1") != "0"
         self._static_ok = None
+        # True: the Stein estimate is materialised exactly as the modules do it (bit-equal trajectories); False: the update
+        # kernel whitens the moment sums directly where it can (csrc/update_kl.hip), same mathematics with fewer roundings
+        self.explicit_estimate = os.environ.get("GMMVI_EXPLICIT_ESTIMATE", "0") == "1"
         lib = _lib.load()
         lib.gmmvi_train_iter_samtron.restype = C.c_int
         lib.gmmvi_train_iter_samtron.argtypes = [C.c_void_p, C.POINTER(SamtronPlan)]
@@ -164,6 +167,8 @@ class SamtronFastPath:
             p.weight_stepsize_mode = 0
         p.weight_update_mode = 0 if type(wu) is TrustRegionBasedWeightUpdater else 1
         p.stein_flags = _lib.SELF_NORMALIZED if g.ng_estimator._use_self_normalized_importance_weights else 0
+        if self.explicit_estimate:
+            p.stein_flags |= _lib.EXPLICIT_ESTIMATE
 
         ctx.check(self._fn(ctx.handle, C.byref(p)))
 

@@ -47,7 +47,10 @@ enum gmmvi_family {
 
 enum gmmvi_stein_flags {
     GMMVI_SELF_NORMALIZED = 1, /* ng_estimator.py:171-188 (else :154-169, not symmetrised) */
-    GMMVI_OWN_SAMPLES_ONLY = 2 /* ng_estimator.py:110-118 */
+    GMMVI_OWN_SAMPLES_ONLY = 2, /* ng_estimator.py:110-118 */
+    /* gmmvi_train_iter_samtron only: finish the estimate as gmmvi_stein does (H, g materialised) instead of forming the
+     * whitened matrix of the component update directly from the moment sums (same mathematics, different rounding) */
+    GMMVI_EXPLICIT_ESTIMATE = 4
 };
 
 #define GMMVI_MORE_REGISTER_MAX_DIM 21  /* gmmvi_more: up to here the F x F ridge system (F = D(D+1)/2 + D + 1) is factorised in
@@ -274,7 +277,8 @@ typedef struct gmmvi_samtron_plan {
     int32_t weight_stepsize_mode;         /* 0 fixed, 1 improvement-based */
     float ws_min, ws_max, ws_inc, ws_dec;
     int32_t weight_update_mode;           /* 0 trust-region, 1 direct */
-    int32_t stein_flags;                  /* enum gmmvi_stein_flags (own-samples-only is not supported here) */
+    int32_t stein_flags;                  /* enum gmmvi_stein_flags (own-samples-only is not supported here;
+                                           * GMMVI_EXPLICIT_ESTIMATE: results bit-equal to the module-by-module calls) */
 } gmmvi_samtron_plan;
 int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan* plan);
 

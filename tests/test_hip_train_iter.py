@@ -76,17 +76,25 @@ def test_trajectory_wide_register_kernels(d, k, s, fused):
 def test_north_star_full_size():
     """The north-star shape at full size (K = 100, D = 20, 100 samples per component = 10 000 samples per iteration,
     Student-t mixture target), two iterations against the fp64 oracle: parameters to 5e-4, identical accept / reject
-    decisions, identical probe counts (modular path; the single-call path must then agree with it bit for bit)."""
+    decisions, identical probe counts (modular path; the single-call path is then compared with it)."""
     cfg = samtron_config(100)
     o, g, worst = run_pair("stm", 20, 100, 100, seed=31, iters=2, cfg=cfg)
     np.testing.assert_array_equal(g.ng_based_updater.last_info[1].numpy(), o.last["n_probes"])
-    f = make_device("stm", 20, 100, 100, 31, cfg, make_oracle("stm", 20, 100, 100, 31, cfg))
-    assert f._fast_path.eligible()
-    for _ in range(2):
-        f.train_iter()
-    for name in ("means", "chol_cov", "log_weights", "stepsizes", "last_log_etas"):
-        np.testing.assert_array_equal(getattr(f.model, name).numpy(), getattr(g.model, name).numpy(), err_msg=name)
-    assert f.sample_db.samples.shape == (20000, 20)
+    # single-call path with the estimate materialised as the modules do it: bit for bit; its default route (the update kernel
+    # whitens the Stein moment sums directly, csrc/update_kl.hip) differs by rounding only
+    for explicit in (True, False):
+        f = make_device("stm", 20, 100, 100, 31, cfg, make_oracle("stm", 20, 100, 100, 31, cfg))
+        assert f._fast_path.eligible()
+        f._fast_path.explicit_estimate = explicit
+        for _ in range(2):
+            f.train_iter()
+        for name in ("means", "chol_cov", "log_weights", "stepsizes", "last_log_etas"):
+            a, b = getattr(f.model, name).numpy(), getattr(g.model, name).numpy()
+            if explicit:
+                np.testing.assert_array_equal(a, b, err_msg=name)
+            else:
+                np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(b).max())), err_msg=name)
+        assert f.sample_db.samples.shape == (20000, 20)
 
 
 def test_gmm50_config_full_size():
