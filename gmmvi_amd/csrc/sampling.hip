@@ -16,14 +16,16 @@ __global__ __launch_bounds__(256) void sample_components_kernel(int K, int D, co
                                                                 uint64_t first_index, uint32_t stream_id,
                                                                 const float* __restrict__ eps_in, float* __restrict__ X,
                                                                 int32_t* __restrict__ mapping, int32_t mapping_base,
-                                                                int n_chunks, PrepArgs prep) {
+                                                                int n_chunks, int uniform_count, PrepArgs prep) {
     extern __shared__ float sm[];
     if ((int)blockIdx.y >= n_chunks) {                 // bookkeeping blocks of the single-call iteration (iter_prep.h)
         iter_prep_block(prep, blockIdx.x, gridDim.x);
         return;
     }
     const int k = blockIdx.x;
-    const int begin = offsets[k], end = offsets[k + 1];
+    // equal counts known to the caller (single-call iteration): no dependent load in front of everything else
+    const int begin = uniform_count > 0 ? k * uniform_count : offsets[k];
+    const int end = uniform_count > 0 ? begin + uniform_count : offsets[k + 1];
     const int base = begin + blockIdx.y * 256;
     if (base >= end) return;
     const int n_here = min(256, end - base);
@@ -32,28 +34,39 @@ __global__ __launch_bounds__(256) void sample_components_kernel(int K, int D, co
     float* tile = mus + D;               // [256][ldx]
     const int ldx = D | 1;
     const int t = threadIdx.x;
-    for (int e = t; e < D * D; e += 256) Ls[e] = chols[(size_t)k * D * D + e];
-    for (int e = t; e < D; e += 256) mus[e] = means[(size_t)k * D + e];
+    // (mu, L) are fetched into registers first and reach LDS after the random numbers are made: the loads (L2 round trips:
+    // the previous iteration's update kernel wrote them on other CUs) overlap the Philox rounds
+    constexpr int NL = (DP * DP + 255) / 256;
+    float lreg[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) lreg[u] = (t + 256 * u < D * D) ? chols[(size_t)k * D * D + t + 256 * u] : 0.f;
+    const float mreg = t < D ? means[(size_t)k * D + t] : 0.f;
     if (eps_in) {
         for (int e = t; e < n_here * D; e += 256) tile[(e / D) * ldx + (e % D)] = eps_in[(size_t)base * D + e];
     }
-    __syncthreads();
     const bool valid = t < n_here;
-    float eps[DP];
-    if (eps_in) {
-#pragma unroll
-        for (int i = 0; i < DP; ++i) eps[i] = (valid && i < D) ? tile[t * ldx + i] : 0.f;
-    } else {
-        const uint64_t idx = first_index + (uint64_t)(base + t);
-#pragma unroll
-        for (int b = 0; b < (DP + 3) / 4; ++b) {
+    if (!eps_in) {
+        // the standard normals of the tile, four per Philox block (counter = sample index, block): the (sample, block) items are
+        // spread over ALL threads -- a thread that made all of its sample's blocks itself spent 4 us of a 9 us launch in the
+        // Philox rounds and the Box-Muller transforms (D = 20: five blocks a sample, 100 samples on 256 threads)
+        constexpr int NB4 = (DP + 3) / 4;
+        for (int item = t; item < n_here * NB4; item += 256) {
+            const int smp = item / NB4, b = item - smp * NB4;
             float nn[4];
-            philox_normal4(seed, idx, (uint32_t)b, stream_id, nn);
+            philox_normal4(seed, first_index + (uint64_t)(base + smp), (uint32_t)b, stream_id, nn);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (4 * b + j < DP) eps[4 * b + j] = nn[j];
+                if (4 * b + j < D) tile[smp * ldx + 4 * b + j] = nn[j];
         }
     }
+#pragma unroll
+    for (int u = 0; u < NL; ++u)
+        if (t + 256 * u < D * D) Ls[t + 256 * u] = lreg[u];
+    if (t < D) mus[t] = mreg;
+    __syncthreads();
+    float eps[DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) eps[i] = (valid && i < D) ? tile[t * ldx + i] : 0.f;
     __syncthreads();
     if (valid) {
 #pragma unroll
@@ -98,7 +111,7 @@ __global__ void philox_uniforms_kernel(uint64_t seed, uint64_t first_index, uint
 static int launch_sample(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
                          const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed, uint64_t first_index,
                          int stream_id, const float* eps_dev, float* X_out_dev, int32_t* mapping_out_dev, int32_t mapping_base,
-                         const PrepArgs* prep) {
+                         const PrepArgs* prep, int uniform_count = 0) {
     GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_BLOCKED_MAX_DIM && N >= 0 && max_per_component >= 0);
     if (N == 0 && !prep) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, means_dev && chols_dev && offsets_dev && X_out_dev);
@@ -116,7 +129,7 @@ static int launch_sample(gmmvi_ctx* ctx, int K, int D, const float* means_dev, c
     GMMVI_DISPATCH_DP(dp, hipLaunchKernelGGL((sample_components_kernel<DP>), dim3(K, chunks + (prep ? 1 : 0)), dim3(256),
                                              shmem, ctx->stream, K, D, means_dev, chols_dev, offsets_dev, N, seed,
                                              first_index, (uint32_t)stream_id, eps_dev, X_out_dev, mapping_out_dev,
-                                             mapping_base, chunks, prep ? *prep : none));
+                                             mapping_base, chunks, uniform_count, prep ? *prep : none));
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }
@@ -136,8 +149,10 @@ int gmmvi_sample_components_bounded(gmmvi_ctx* ctx, int K, int D, const float* m
 int gmmvi_sample_components_prep(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
                                  const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed, uint64_t first_index,
                                  float* X_out_dev, int32_t* mapping_out_dev, int32_t mapping_base, const PrepArgs& prep) {
+    // the single-call iteration draws the same number of samples from every component (offsets[k] = k * max_per_component)
+    const int uniform = (long)K * max_per_component == N ? max_per_component : 0;
     return launch_sample(ctx, K, D, means_dev, chols_dev, offsets_dev, N, max_per_component, seed, first_index, 0, nullptr,
-                         X_out_dev, mapping_out_dev, mapping_base, &prep);
+                         X_out_dev, mapping_out_dev, mapping_base, &prep, uniform);
 }
 
 extern "C" {
