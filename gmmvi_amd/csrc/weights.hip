@@ -28,6 +28,42 @@ __device__ float block_sum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// the per-thread pass of elr_kernel over samples n = t, t + 1024, ...: online softmax sums of a_n = ld[k,n] - bg[n] with
+// rho_n = tlp[n] - beta logq[n].  R: number of chunk partials in logq ([R][N], merged as combine.h does), 0 = logq is final,
+// -1 = run-time count Rrt.  R is a template parameter so that the loads of a round are straight-line code: a run-time choice
+// per element makes the compiler branch around every load and wait for each one separately.
+template <int R>
+__device__ __forceinline__ void elr_accumulate(int N, const float* __restrict__ row, const float* __restrict__ bg,
+                                               const float* __restrict__ tlp, const float* __restrict__ logq, int Rrt, float beta,
+                                               float& m, float& s, float& se, float& s2) {
+    constexpr int B = 4;                               // samples per round, loads in flight together
+    for (int n0 = threadIdx.x; n0 < N; n0 += 1024 * B) {
+        float av[B], rv[B];
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            const int n = min(n0 + 1024 * u, N - 1);
+            av[u] = row[n] - bg[n];
+            float lq;
+            if constexpr (R == 0) lq = logq[n];
+            else if constexpr (R > 0) lq = combine_log_values_n<R>(logq, N, n);
+            else lq = combine_log_values(logq, Rrt, N, n);
+            rv[u] = tlp[n] - beta * lq;
+        }
+#pragma unroll
+        for (int u = 0; u < B; ++u) {
+            if (n0 + 1024 * u < N) {
+                const float a = av[u], rho = rv[u];
+                const float mn = fmaxf(m, a);
+                const float sc = __expf(m - mn), e = __expf(a - mn);
+                s = fmaf(s, sc, e);
+                se = fmaf(se, sc, e * rho);
+                s2 = fmaf(s2, sc * sc, e * e);
+                m = mn;
+            }
+        }
+    }
+}
+
 // One 1024-thread workgroup per component: E_k = sum_n softmax_n(ld[k,n] - bg[n]) * (tlp[n] - beta logq[n]) in a single
 // pass (per-thread running maximum with rescaling), then a fixed-order tree over the 16 waves.
 // logq_R > 0: logq holds the logq_R chunk partials [logq_R][N] of a component-split sweep, merged here as combine.h does.
@@ -40,28 +76,12 @@ __global__ __launch_bounds__(1024) void elr_kernel(int N, const float* __restric
     const int k = blockIdx.x;
     const float* row = ld + (size_t)k * N;
     float m = -3.0e38f, s = 0.f, se = 0.f, s2 = 0.f;
-    // four samples per round with their loads in flight together (the kernel is a latency chain: ~10 rounds per thread at
-    // N = 10^4); accumulated in the order n = t, t + 1024, ...
-    for (int n0 = threadIdx.x; n0 < N; n0 += 4096) {
-        float av[4], rv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int n = min(n0 + 1024 * u, N - 1);
-            av[u] = row[n] - bg[n];
-            rv[u] = tlp[n] - beta * (logq_R > 0 ? combine_log_values(logq, logq_R, N, n) : logq[n]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (n0 + 1024 * u < N) {
-                const float a = av[u], rho = rv[u];
-                const float mn = fmaxf(m, a);
-                const float sc = __expf(m - mn), e = __expf(a - mn);
-                s = fmaf(s, sc, e);
-                se = fmaf(se, sc, e * rho);
-                s2 = fmaf(s2, sc * sc, e * e);
-                m = mn;
-            }
-        }
+    switch (logq_R) {
+        case 0: elr_accumulate<0>(N, row, bg, tlp, logq, 0, beta, m, s, se, s2); break;
+        case 2: elr_accumulate<2>(N, row, bg, tlp, logq, 2, beta, m, s, se, s2); break;
+        case 3: elr_accumulate<3>(N, row, bg, tlp, logq, 3, beta, m, s, se, s2); break;
+        case 4: elr_accumulate<4>(N, row, bg, tlp, logq, 4, beta, m, s, se, s2); break;
+        default: elr_accumulate<-1>(N, row, bg, tlp, logq, logq_R, beta, m, s, se, s2); break;
     }
     // wave level
     const float mw = wmax(m);
