@@ -39,31 +39,68 @@ __device__ __forceinline__ float combine_log_values(const float* __restrict__ pa
     return m + __logf(s);
 }
 
-__device__ __forceinline__ void combine_element(const CombineJob& j, long e) {
+// R > 0: compile-time chunk count (all loads of an element straight-line, in flight together); R == 0: run-time j.R
+template <int R>
+__device__ __forceinline__ void combine_element_n(const CombineJob& j, long e) {
     const bool with_grad = j.grad_out != nullptr && j.grad_parts != nullptr;
     const int width = with_grad ? j.D : 1;
     if (e >= (long)j.N * width) return;
     const int n = (int)(e / width), i = (int)(e - (long)n * width);
-    const float lp = combine_log_values(j.lp_parts, j.R, j.N, n);
+    const int Rr = R > 0 ? R : j.R;
+    float lp;
+    if constexpr (R > 0) lp = combine_log_values_n<R>(j.lp_parts, j.N, n); else lp = combine_log_values(j.lp_parts, Rr, j.N, n);
     if (j.lp_out && i == 0) j.lp_out[n] = lp;
-    if (j.lp2_out && j.lp2_parts && i == (width > 1 ? 1 : 0)) j.lp2_out[n] = combine_log_values(j.lp2_parts, j.R, j.N, n);
+    if (j.lp2_out && j.lp2_parts && i == (width > 1 ? 1 : 0)) {
+        if constexpr (R > 0) j.lp2_out[n] = combine_log_values_n<R>(j.lp2_parts, j.N, n);
+        else j.lp2_out[n] = combine_log_values(j.lp2_parts, Rr, j.N, n);
+    }
     if (with_grad) {
         float g = 0.f;
-        for (int r = 0; r < j.R; ++r)
-            g = fmaf(__expf(j.lp_parts[(size_t)r * j.N + n] - lp), j.grad_parts[((size_t)r * j.N + n) * j.D + i], g);
+        if constexpr (R > 0) {
+            float lv[R], gv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                lv[r] = j.lp_parts[(size_t)r * j.N + n];
+                gv[r] = j.grad_parts[((size_t)r * j.N + n) * j.D + i];
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) g = fmaf(__expf(lv[r] - lp), gv[r], g);
+        } else {
+            for (int r = 0; r < Rr; ++r)
+                g = fmaf(__expf(j.lp_parts[(size_t)r * j.N + n] - lp), j.grad_parts[((size_t)r * j.N + n) * j.D + i], g);
+        }
         j.grad_out[(size_t)n * j.D + i] = g;
     }
 }
 
+__device__ __forceinline__ void combine_element(const CombineJob& j, long e) {
+    switch (j.R) {                                     // uniform
+        case 2: combine_element_n<2>(j, e); break;
+        case 3: combine_element_n<3>(j, e); break;
+        case 4: combine_element_n<4>(j, e); break;
+        default: combine_element_n<0>(j, e); break;
+    }
+}
+
 // the carried form: workgroups first_block .. first_block + blocks - 1 of the carrying launch (blockIdx.y == 0 only)
+template <int R>
+__device__ __forceinline__ void combine_carried_n(const CombineJob& j) {
+    const bool with_grad = j.grad_out != nullptr && j.grad_parts != nullptr;
+    const long elems = (long)j.N * (with_grad ? j.D : 1);
+    const long stride = (long)j.blocks * blockDim.x;
+    for (long e = (long)((int)blockIdx.x - j.first_block) * blockDim.x + threadIdx.x; e < elems; e += stride)
+        combine_element_n<R>(j, e);
+}
+
 __device__ __forceinline__ bool combine_carried(const CombineJob& j) {
     if (j.blocks == 0 || (int)blockIdx.x < j.first_block) return false;
     if (blockIdx.y == 0 && blockIdx.z == 0) {
-        const bool with_grad = j.grad_out != nullptr && j.grad_parts != nullptr;
-        const long elems = (long)j.N * (with_grad ? j.D : 1);
-        const long stride = (long)j.blocks * blockDim.x;
-        for (long e = (long)((int)blockIdx.x - j.first_block) * blockDim.x + threadIdx.x; e < elems; e += stride)
-            combine_element(j, e);
+        switch (j.R) {
+            case 2: combine_carried_n<2>(j); break;
+            case 3: combine_carried_n<3>(j); break;
+            case 4: combine_carried_n<4>(j); break;
+            default: combine_carried_n<0>(j); break;
+        }
     }
     return true;
 }
