@@ -47,6 +47,8 @@ __device__ __forceinline__ void ukl_static_for(F&& f) {
         }                                                          \
     } while (0)
 
+typedef float ukl_v2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ float wsum(float v) { return gmmvi_wave_sum(v); }
 
 struct Ws {
@@ -267,35 +269,49 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
     if (DC > 0) {
         constexpr int DR = DC > 0 ? DC : 1;
         constexpr int D4 = (DR + 3) / 4;
-        float mrow[DR], wtr[DR];
+        constexpr int DH = 2 * D4;                  // pairs (padded to whole float4 reads)
+        // the lane's row of M, the replica of wt and the broadcast vectors are kept as PAIRS: the dot products and the rank-2
+        // update run on v_pk_fma_f32 / v_pk_mul_f32 (two elements per instruction) -- the phase is a single wavefront issuing
+        // one vector instruction every four cycles, so its time is its instruction count.  Elements beyond D and the dead part
+        // j <= c of the reflector are exact zeros.
+        ukl_v2 mrow[DH], wtr[DH];
 #pragma unroll
-        for (int j = 0; j < DR; ++j) { mrow[j] = (t < DR) ? s.M[t * ld + j] : 0.f; wtr[j] = s.wt[j]; }
+        for (int m2 = 0; m2 < DH; ++m2) {
+            mrow[m2].x = (t < DR && 2 * m2 < DR) ? s.M[t * ld + 2 * m2] : 0.f;
+            mrow[m2].y = (t < DR && 2 * m2 + 1 < DR) ? s.M[t * ld + 2 * m2 + 1] : 0.f;
+            wtr[m2].x = (2 * m2 < DR) ? s.wt[2 * m2] : 0.f;
+            wtr[m2].y = (2 * m2 + 1 < DR) ? s.wt[2 * m2 + 1] : 0.f;
+        }
         float* xv = s.pr;                           // column c of M and p as 16-byte aligned broadcast vectors (the probe
         float* pv = s.pr + 64;                      // scratch is free until the search starts; 3 D (D + 4) floats precede it)
-        // fully unrolled for D <= 32: c becomes a compile-time constant, the selects below fold away and the j loops shrink
-        // to the live part of the column
+        if (t < 64) { xv[t] = 0.f; pv[t] = 0.f; }   // the padding of the broadcast vectors
+        UKL_WSYNC();
         // one instantiation per column (ukl_static_for): c is a compile-time constant in every step -- `#pragma unroll` gives
         // up on this body from D ~ 40, and with a run-time c every select below stays a select
         ukl_static_for<0, (DR > 2 ? DR - 2 : 0)>([&](auto c_const) {
             constexpr int c = decltype(c_const)::value;
-            float mc = 0.f;                         // mrow[c]
-#pragma unroll
-            for (int j = 0; j < DR; ++j) mc = (j == c) ? mrow[j] : mc;
+            constexpr int M0 = (c + 1) / 2;          // first pair with a live element (j > c)
+            const float mc = (c & 1) ? mrow[c / 2].y : mrow[c / 2].x;
             if (t < DR) xv[t] = mc;
             UKL_WSYNC();
-            float x[4 * D4];
+            ukl_v2 x[DH];
 #pragma unroll
             for (int q4 = 0; q4 < D4; ++q4) {
                 const float4 v4 = reinterpret_cast<const float4*>(xv)[q4];
-                x[4 * q4] = v4.x; x[4 * q4 + 1] = v4.y; x[4 * q4 + 2] = v4.z; x[4 * q4 + 3] = v4.w;
+                x[2 * q4].x = v4.x; x[2 * q4].y = v4.y; x[2 * q4 + 1].x = v4.z; x[2 * q4 + 1].y = v4.w;
             }
             const float xt = xv[t < DR ? t : 0];     // this lane's own element of the column (its v_t below)
-            float x1 = 0.f, tail = 0.f;
+            const float x1 = ((c + 1) & 1) ? x[(c + 1) / 2].y : x[(c + 1) / 2].x;
+            // dead part j <= c + 1 zeroed (compile-time), then the tail norm on pairs
+            ukl_v2 t2 = {0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < DR; ++j) {
-                x1 = (j == c + 1) ? x[j] : x1;
-                tail = (j > c + 1) ? fmaf(x[j], x[j], tail) : tail;
+            for (int m2 = M0; m2 < DH; ++m2) {
+                ukl_v2 z = x[m2];
+                if (2 * m2 <= c + 1) z.x = 0.f;
+                if (2 * m2 + 1 <= c + 1) z.y = 0.f;
+                t2 = z * z + t2;
             }
+            const float tail = t2.x + t2.y;
             if (!(tail > 0.f)) {                    // column already tridiagonal (also covers NaN: handled later)
                 if (t == 0) s.te[c] = x1;
                 UKL_WSYNC();
@@ -307,46 +323,51 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             const float beta = __builtin_amdgcn_rcpf(nrm * nrm - alpha * x1);      // 2 / |v|^2, |v|^2 = 2 (alpha^2 - alpha x1)
             // v_j: 0 for j <= c, x1 - alpha for j = c + 1, x_j below
 #pragma unroll
-            for (int j = 0; j < DR; ++j) x[j] = (j <= c) ? 0.f : (j == c + 1 ? x1 - alpha : x[j]);
-            // v vanishes for j <= c and so do p_j of the inactive lanes: every loop below runs over the live part j > c only
-            // (compile-time bounds once c is unrolled); the skipped terms are exact zeros
+            for (int m2 = M0; m2 < DH; ++m2) {
+                if (2 * m2 <= c) x[m2].x = 0.f; else if (2 * m2 == c + 1) x[m2].x = x1 - alpha;
+                if (2 * m2 + 1 <= c) x[m2].y = 0.f; else if (2 * m2 + 1 == c + 1) x[m2].y = x1 - alpha;
+            }
             const bool act = (t > c) && (t < DR);
-            float p = 0.f;
+            ukl_v2 p2 = {0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < DR; ++j)
-                if (j > c) p = fmaf(mrow[j], x[j], p);
+            for (int m2 = M0; m2 < DH; ++m2) p2 = mrow[m2] * x[m2] + p2;
+            float p = p2.x + p2.y;
             p = act ? p * beta : 0.f;
             const float vv = act ? (t == c + 1 ? x1 - alpha : xt) : 0.f;
             if (t < DR) pv[t] = p;
             UKL_WSYNC();
-            float pj[4 * D4];
+            ukl_v2 pj[DH];
 #pragma unroll
             for (int q4 = 0; q4 < D4; ++q4) {
                 const float4 v4 = reinterpret_cast<const float4*>(pv)[q4];
-                pj[4 * q4] = v4.x; pj[4 * q4 + 1] = v4.y; pj[4 * q4 + 2] = v4.z; pj[4 * q4 + 3] = v4.w;
+                pj[2 * q4].x = v4.x; pj[2 * q4].y = v4.y; pj[2 * q4 + 1].x = v4.z; pj[2 * q4 + 1].y = v4.w;
             }
-            float kk = 0.f, wdot = 0.f;
+            ukl_v2 kk2 = {0.f, 0.f}, wd2 = {0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < DR; ++j)
-                if (j > c) { kk = fmaf(x[j], pj[j], kk); wdot = fmaf(x[j], wtr[j], wdot); }
-            kk *= 0.5f * beta;
-            wdot *= beta;
+            for (int m2 = M0; m2 < DH; ++m2) { kk2 = x[m2] * pj[m2] + kk2; wd2 = x[m2] * wtr[m2] + wd2; }
+            const float kk = (kk2.x + kk2.y) * (0.5f * beta);
+            const float wdot = (wd2.x + wd2.y) * beta;
             const float qq = p - kk * vv;
+            const ukl_v2 vv2 = {vv, vv}, qq2 = {qq, qq}, kkn = {-kk, -kk}, wdn = {-wdot, -wdot};
 #pragma unroll
-            for (int j = 0; j < DR; ++j) {
-                if (j > c) {
-                    mrow[j] -= vv * (pj[j] - kk * x[j]) + qq * x[j];
-                    wtr[j] -= wdot * x[j];          // replica of wt in every lane
-                }
+            for (int m2 = M0; m2 < DH; ++m2) {
+                const ukl_v2 u = kkn * x[m2] + pj[m2];              // p_j - kk v_j
+                mrow[m2] = mrow[m2] - (vv2 * u + qq2 * x[m2]);
+                wtr[m2] = wdn * x[m2] + wtr[m2];                    // replica of wt in every lane
             }
             if (t == 0) s.te[c] = alpha;
         });
         UKL_WSYNC();
         if (t < DR) {
-            float dd = 0.f, sub = 0.f, wme = 0.f;
+            float dd = 0.f, wme = 0.f;
 #pragma unroll
-            for (int j = 0; j < DR; ++j) { dd = (j == t) ? mrow[j] : dd; wme = (j == t) ? wtr[j] : wme; }
-            sub = mrow[DR >= 2 ? DR - 2 : 0];
+            for (int j = 0; j < DR; ++j) {
+                const float mj = (j & 1) ? mrow[j / 2].y : mrow[j / 2].x;
+                const float wj = (j & 1) ? wtr[j / 2].y : wtr[j / 2].x;
+                dd = (j == t) ? mj : dd; wme = (j == t) ? wj : wme;
+            }
+            constexpr int JS = DR >= 2 ? DR - 2 : 0;
+            const float sub = (JS & 1) ? mrow[JS / 2].y : mrow[JS / 2].x;
             s.td[t] = dd;
             s.wt[t] = wme;
             if (t == DR - 1 && DR >= 2) s.te[DR - 2] = sub;
@@ -694,6 +715,10 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
     UKL_STAMP(6);
     if (k == 0 && t == 0 && kl_out)
         for (int i = 1; i <= 6; ++i) kl_out[i] = (float)(stamp[i] - stamp[0]);
+    if (k == 0 && t == 0 && !kl_out && slab.part)       // single-call iteration: no info array, print
+        printf("update_kl stamps (10 ns): front %lld householder %lld search %lld factor %lld pack %lld end %lld\n",
+               stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4],
+               stamp[6] - stamp[5]);
     kl_out = nullptr;
 #endif
     if (t == 0) {
