@@ -30,6 +30,8 @@ __device__ __forceinline__ float combine_log_values(const float* __restrict__ pa
         case 4: return combine_log_values_n<4>(parts, N, n);
         case 5: return combine_log_values_n<5>(parts, N, n);
         case 6: return combine_log_values_n<6>(parts, N, n);
+        case 7: return combine_log_values_n<7>(parts, N, n);
+        case 8: return combine_log_values_n<8>(parts, N, n);
         default: break;
     }
     float m = -3.0e38f;
@@ -78,6 +80,10 @@ __device__ __forceinline__ void combine_element(const CombineJob& j, long e) {
         case 2: combine_element_n<2>(j, e); break;
         case 3: combine_element_n<3>(j, e); break;
         case 4: combine_element_n<4>(j, e); break;
+        case 5: combine_element_n<5>(j, e); break;
+        case 6: combine_element_n<6>(j, e); break;
+        case 7: combine_element_n<7>(j, e); break;
+        case 8: combine_element_n<8>(j, e); break;
         default: combine_element_n<0>(j, e); break;
     }
 }
@@ -99,6 +105,10 @@ __device__ __forceinline__ bool combine_carried(const CombineJob& j) {
             case 2: combine_carried_n<2>(j); break;
             case 3: combine_carried_n<3>(j); break;
             case 4: combine_carried_n<4>(j); break;
+            case 5: combine_carried_n<5>(j); break;
+            case 6: combine_carried_n<6>(j); break;
+            case 7: combine_carried_n<7>(j); break;
+            case 8: combine_carried_n<8>(j); break;
             default: combine_carried_n<0>(j); break;
         }
     }

@@ -54,17 +54,24 @@ int gmmvi_flush_pending_combine(gmmvi_ctx* ctx) {
                                            j.lp2_out);
 }
 
-CombineJob gmmvi_take_pending_combine(gmmvi_ctx* ctx, int threads, int first_block) {
+CombineJob gmmvi_take_pending_combine(gmmvi_ctx* ctx, int threads, int first_block, bool light) {
     CombineJob j = ctx->pending;
     ctx->pending = CombineJob();
     if (j.R == 0) return j;
     const long elems = (long)j.N * ((j.grad_out && j.grad_parts) ? j.D : 1);
-    // the carried workgroups have the resource footprint of the carrying kernel: give them the CUs its own workgroups leave idle
-    // in their last round rather than a further round
-    long blocks = ctx->num_cus - first_block % ctx->num_cus;
-    if (blocks < ctx->num_cus / 4) blocks += ctx->num_cus;
-    const long useful = (elems + threads - 1) / threads;
-    if (blocks > useful) blocks = useful;
+    long blocks;
+    if (light) {
+        // a carrying kernel with a small footprint (no LDS, small workgroups): two elements per thread
+        blocks = (elems + 2L * threads - 1) / (2L * threads);
+        if (blocks > 16L * ctx->num_cus) blocks = 16L * ctx->num_cus;
+    } else {
+        // the carried workgroups have the resource footprint of the carrying kernel: give them the CUs its own workgroups
+        // leave idle in their last round rather than a further round
+        blocks = ctx->num_cus - first_block % ctx->num_cus;
+        if (blocks < ctx->num_cus / 4) blocks += ctx->num_cus;
+        const long useful = (elems + threads - 1) / threads;
+        if (blocks > useful) blocks = useful;
+    }
     if (blocks < 1) blocks = 1;
     j.first_block = first_block;
     j.blocks = (int)blocks;

@@ -101,7 +101,7 @@ int gmmvi_combine_partials_internal(gmmvi_ctx* ctx, int R, int N, int D, const f
 // own; take: hand a pending merge to a launch of `threads` threads per workgroup whose own workgroups end at `first_block`
 int gmmvi_defer_reserve(gmmvi_ctx* ctx, size_t nbytes);
 int gmmvi_flush_pending_combine(gmmvi_ctx* ctx);
-CombineJob gmmvi_take_pending_combine(gmmvi_ctx* ctx, int threads, int first_block);
+CombineJob gmmvi_take_pending_combine(gmmvi_ctx* ctx, int threads, int first_block, bool light = false);
 // stein.hip / update_kl.hip: the Stein estimate split at the partial slab (single-call iteration, fused.hip)
 struct SteinSlab;
 int gmmvi_stein_partials(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* X_dev, int N, const float* ld_dev,

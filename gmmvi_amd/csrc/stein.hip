@@ -72,7 +72,7 @@ static int launch_stein_finalize(gmmvi_ctx* ctx, int K, int D, int R, int N, int
 // sums over all of them): the lane with k-slot q takes samples 16 u + 4 q + {0,1,2,3} for its four steps of block u, which
 // are contiguous in the image.
 // The four waves are merged through LDS in fixed order (common maximum); one partial per (component, range) goes to the
-// slab that stein_finalize sums -- K x R x (D+1)^2 floats with R ~ 2 x CUs / stacks ranges instead of one per 256 samples.
+// slab that stein_finalize sums -- K x R x (D+1)^2 floats with R ~ CUs / stacks ranges instead of one per 256 samples.
 // =====================================================================================================================
 constexpr int SM_RS = 72;          // LDS row stride (floats) of the transposed images: 64 samples + 8
 constexpr int SM_NBMAX = 5;        // most components stacked in one tile row
@@ -333,7 +333,10 @@ static int launch_stein_moment(gmmvi_ctx* ctx, int K, int D, const float* packed
     const int stacks = (K + ST::NB - 1) / ST::NB;
     // sample ranges: the grid fits the chip in ONE round of resident workgroups (a few workgroups over that would double the
     // time), at least 64 samples per wave
-    const int wgs_per_cu = ST::MT <= 2 ? 2 : 1;
+    // workgroups per CU: two for one row tile (D <= 15: few MFMAs per sample, the loads and the vector work of a second
+    // workgroup fill the gaps: C4 28.0 against 33.3 us), one from two row tiles (D = 20: 143.4 against 144.6 us per iteration
+    // with half the partial slab -- f32 MFMA and vector work of co-resident waves do not overlap)
+    const int wgs_per_cu = ST::MT == 1 ? 2 : 1;
     static const int env_wgs = getenv("GMMVI_STEIN_WGS_PER_CU") ? atoi(getenv("GMMVI_STEIN_WGS_PER_CU")) : 0;
     int R = ((env_wgs > 0 ? env_wgs : wgs_per_cu) * ctx->num_cus) / stacks;
     if (R > (N + 255) / 256) R = (N + 255) / 256;

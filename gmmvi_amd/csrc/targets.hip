@@ -51,7 +51,7 @@ extern "C" int gmmvi_target_planar(gmmvi_ctx* ctx, int D, const float* prior_std
     if (N == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, prior_std_dev && goals_dev && X_dev);
     GMMVI_PROF(ctx, "target_planar");
-    const CombineJob carried = gmmvi_take_pending_combine(ctx, 128, (N + 127) / 128);
+    const CombineJob carried = gmmvi_take_pending_combine(ctx, 128, (N + 127) / 128, true);
     hipLaunchKernelGGL(planar_kernel, dim3((N + 127) / 128 + carried.blocks), dim3(128), 0, ctx->stream, D, prior_std_dev, G,
                        goals_dev, likelihood_std, X_dev, N, lp_out_dev, grad_out_dev, carried);
     GMMVI_LAUNCH_CHECK(ctx);

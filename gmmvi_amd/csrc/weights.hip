@@ -81,6 +81,10 @@ __global__ __launch_bounds__(1024) void elr_kernel(int N, const float* __restric
         case 2: elr_accumulate<2>(N, row, bg, tlp, logq, 2, beta, m, s, se, s2); break;
         case 3: elr_accumulate<3>(N, row, bg, tlp, logq, 3, beta, m, s, se, s2); break;
         case 4: elr_accumulate<4>(N, row, bg, tlp, logq, 4, beta, m, s, se, s2); break;
+        case 5: elr_accumulate<5>(N, row, bg, tlp, logq, 5, beta, m, s, se, s2); break;
+        case 6: elr_accumulate<6>(N, row, bg, tlp, logq, 6, beta, m, s, se, s2); break;
+        case 7: elr_accumulate<7>(N, row, bg, tlp, logq, 7, beta, m, s, se, s2); break;
+        case 8: elr_accumulate<8>(N, row, bg, tlp, logq, 8, beta, m, s, se, s2); break;
         default: elr_accumulate<-1>(N, row, bg, tlp, logq, logq_R, beta, m, s, se, s2); break;
     }
     // wave level

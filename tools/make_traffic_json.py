@@ -15,7 +15,7 @@ NAMES = [  # (substring of the kernel instance name, bench.py kernel name); firs
     ("sample_components_kernel", "sample_components"), ("elr_kernel", "expected_log_ratios"),
     ("update_weights_kernel", "update_weights"),
     ("bgemm_kernel<5, 1, 1, 4>", "blocked_stein_accumulate"), ("bgemm_kernel<5, 0, 0, 1>", "blocked_forward"),
-    ("bgemm_kernel<5, 0, 1, 2>", "blocked_grad"), ("blk_tridiag_kernel", "blocked_tridiag"),
+    ("bgemm_kernel<5, 0, 1, 2>", "blocked_grad"), ("blk_tridiag", "blocked_tridiag"),
 ]
 
 
