@@ -142,32 +142,80 @@ __device__ float weights_kl(float eta, float beta, const float* lw, const float*
     return wsum(kl);
 }
 
-// weights_kl for K <= 128 with the lane's two elements (i = lane, lane + 64) in registers: the same operations in the same
-// order as the LDS form (every lane reduces its strided elements first, then the wave), without the LDS round trips and
-// barriers of up to 50 probes.  v0 / v1 return the new log weights of the lane's elements.
-__device__ __forceinline__ float weights_kl_reg(float eta, float beta, float lw0, float lw1, float E0, float E1, bool h0,
-                                               bool h1, float& v0, float& v1) {
+// weights_kl for K <= 64 NE with the lane's NE elements (i = lane, lane + 64, ...) in registers: the same operations in the
+// same order as the LDS form (every lane reduces its strided elements first, then the wave), without the LDS round trips and
+// barriers of up to 50 probes.  v[] returns the new log weights of the lane's elements.
+template <int NE>
+__device__ __forceinline__ float weights_kl_reg(float eta, float beta, const float (&lw)[NE], const float (&E)[NE],
+                                               const bool (&h)[NE], float (&v)[NE]) {
     const float a = (eta + 1.f) / (beta + eta), b = 1.f / (beta + eta);
-    float n0 = a * lw0 + b * E0, n1 = a * lw1 + b * E1;                                   // :184-185
-    auto lse2 = [&](float x0, float x1) {
+    float nv[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) nv[e] = a * lw[e] + b * E[e];                            // :184-185
+    auto lse = [&](const float (&x)[NE]) {
         float m = -3.0e38f;
-        if (h0) m = fmaxf(m, x0);
-        if (h1) m = fmaxf(m, x1);
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (h[e]) m = fmaxf(m, x[e]);
         m = wmax(m);
         float s = 0.f;
-        if (h0) s += __expf(x0 - m);
-        if (h1) s += __expf(x1 - m);
+#pragma unroll
+        for (int e = 0; e < NE; ++e)
+            if (h[e]) s += __expf(x[e] - m);
         s = wsum(s);
         return m + __logf(s);
     };
-    float l = lse2(n0, n1);
-    n0 = fmaxf(n0 - l, -69.07f); n1 = fmaxf(n1 - l, -69.07f);                             // :186-187
-    l = lse2(n0, n1);
+    float l = lse(nv);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) nv[e] = fmaxf(nv[e] - l, -69.07f);                       // :186-187
+    l = lse(nv);
     float kl = 0.f;
-    v0 = n0 - l; v1 = n1 - l;                                                             // :188
-    if (h0) kl = fmaf(__expf(v0), v0 - lw0, kl);                                          // :190
-    if (h1) kl = fmaf(__expf(v1), v1 - lw1, kl);
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        v[e] = nv[e] - l;                                                                 // :188
+        if (h[e]) kl = fmaf(__expf(v[e]), v[e] - lw[e], kl);                              // :190
+    }
     return wsum(kl);
+}
+
+// the bisection of the trust-region update (:232-260) with the lane's elements in registers
+template <int NE>
+__device__ __forceinline__ void weights_search_reg(int K, float beta, float bound, const float* lw_s, const float* E_s, float* nl,
+                                                   float& kl, float& eta, bool& updated) {
+    const int t = threadIdx.x;
+    float lw[NE], E[NE], v[NE];
+    bool h[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        h[e] = t + 64 * e < K;
+        lw[e] = h[e] ? lw_s[t + 64 * e] : 0.f;
+        E[e] = h[e] ? E_s[t + 64 * e] : 0.f;
+        v[e] = lw[e];                                                                     // nl starts as the old weights
+    }
+    float lb = -45.f, ub = 45.f;                                                          // :276-277
+    float log_eta = 0.5f * (ub + lb);
+    bool ub_ok = false;
+    for (int it = 0; it < 50; ++it) {                                                     // :232
+        eta = expf(log_eta);
+        if (fabsf(expf(ub) - expf(lb)) < 1e-1f) break;                                    // :234-236
+        kl = weights_kl_reg<NE>(eta, beta, lw, E, h, v);                                  // :238
+        if (fabsf(bound - kl) < 1e-1f * bound) { lb = ub; break; }                        // :240-243
+        if (bound > kl) { ub = log_eta; ub_ok = true; } else { lb = log_eta; }            // :245-249
+        log_eta = 0.5f * (ub + lb);
+    }
+    if (lb == ub) {
+        // :252-253 keep the last evaluated weights
+    } else if (ub_ok) {
+        eta = expf(ub);
+        kl = weights_kl_reg<NE>(eta, beta, lw, E, h, v);                                  // :256-258
+    } else {
+        updated = false;                                                                  // :260
+        kl = -1.f; eta = -1.f;
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+        if (h[e]) nl[t + 64 * e] = v[e];                                                  // hand the result to the LDS image
+    __syncthreads();
 }
 
 // mode 0: trust region (:193-279); mode 1: direct (:123-141).  Single wavefront; lw/E/nl live in LDS.
@@ -194,36 +242,31 @@ __global__ __launch_bounds__(64) void update_weights_kernel(int mode, int K, flo
         for (int i = t; i < K; i += 64) nl[i] -= l;                                       // :140
         __syncthreads();
     } else {
-        float lb = -45.f, ub = 45.f;                                                      // :276-277
-        float log_eta = 0.5f * (ub + lb);
-        bool ub_ok = false;
-        const bool in_regs = K <= 128;
-        const bool h0 = t < K, h1 = t + 64 < K;
-        const float lw0 = h0 ? lw[t] : 0.f, lw1 = h1 ? lw[t + 64] : 0.f, E0 = h0 ? E[t] : 0.f, E1 = h1 ? E[t + 64] : 0.f;
-        float v0 = lw0, v1 = lw1;                                                         // nl starts as the old weights
-        for (int it = 0; it < 50; ++it) {                                                 // :232
-            eta = expf(log_eta);
-            if (fabsf(expf(ub) - expf(lb)) < 1e-1f) break;                                // :234-236
-            kl = in_regs ? weights_kl_reg(eta, beta, lw0, lw1, E0, E1, h0, h1, v0, v1)
-                         : weights_kl(eta, beta, lw, E, nl, K);                           // :238
-            if (fabsf(bound - kl) < 1e-1f * bound) { lb = ub; break; }                    // :240-243
-            if (bound > kl) { ub = log_eta; ub_ok = true; } else { lb = log_eta; }        // :245-249
-            log_eta = 0.5f * (ub + lb);
-        }
-        if (lb == ub) {
-            // :252-253 keep the last evaluated weights
-        } else if (ub_ok) {
-            eta = expf(ub);
-            kl = in_regs ? weights_kl_reg(eta, beta, lw0, lw1, E0, E1, h0, h1, v0, v1)
-                         : weights_kl(eta, beta, lw, E, nl, K);                           // :256-258
+        if (K <= 128) {
+            weights_search_reg<2>(K, beta, bound, lw, E, nl, kl, eta, updated);
+        } else if (K <= 256) {
+            weights_search_reg<4>(K, beta, bound, lw, E, nl, kl, eta, updated);
         } else {
-            updated = false;                                                              // :260
-            kl = -1.f; eta = -1.f;
-        }
-        if (in_regs) {                                                                    // hand the result to the LDS image
-            if (h0) nl[t] = v0;
-            if (h1) nl[t + 64] = v1;
-            __syncthreads();
+            float lb = -45.f, ub = 45.f;                                                  // :276-277
+            float log_eta = 0.5f * (ub + lb);
+            bool ub_ok = false;
+            for (int it = 0; it < 50; ++it) {                                             // :232
+                eta = expf(log_eta);
+                if (fabsf(expf(ub) - expf(lb)) < 1e-1f) break;                            // :234-236
+                kl = weights_kl(eta, beta, lw, E, nl, K);                                 // :238
+                if (fabsf(bound - kl) < 1e-1f * bound) { lb = ub; break; }                // :240-243
+                if (bound > kl) { ub = log_eta; ub_ok = true; } else { lb = log_eta; }    // :245-249
+                log_eta = 0.5f * (ub + lb);
+            }
+            if (lb == ub) {
+                // :252-253 keep the last evaluated weights
+            } else if (ub_ok) {
+                eta = expf(ub);
+                kl = weights_kl(eta, beta, lw, E, nl, K);                                 // :256-258
+            } else {
+                updated = false;                                                          // :260
+                kl = -1.f; eta = -1.f;
+            }
         }
     }
     if (!updated) {
