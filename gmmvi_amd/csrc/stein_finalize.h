@@ -40,7 +40,16 @@ __device__ __forceinline__ float stein_slab_sum(float* A, float* scale_r, int k,
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = fmaf(pk[(size_t)(r + u) * (D1 * D1) + e], scale_r[r + u], v[u]);
         }
-        for (int u = 0; r < R; ++r, ++u) v[u] = fmaf(pk[(size_t)r * (D1 * D1) + e], scale_r[r], v[u]);
+        if (r < R) {
+            // the last (partial) group of eight: all eight loads unconditional (clamped index, weight 0 beyond R) -- a run-time
+            // trip count makes the compiler wait for every load separately (a few partials only at D = 50: 17 us for the sum)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rr = min(r + u, R - 1);
+                const float sc = (r + u < R) ? scale_r[rr] : 0.f;
+                v[u] = fmaf(pk[(size_t)rr * (D1 * D1) + e], sc, v[u]);
+            }
+        }
         A[e] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
     }
     __syncthreads();

@@ -49,6 +49,39 @@ __device__ __forceinline__ void ukl_static_for(F&& f) {
 
 typedef float ukl_v2 __attribute__((ext_vector_type(2)));
 
+// out(i, j) = sum_c fa(c, i) fb(c, j), i, j < D, by 2 x 5 register blocks (one per thread: D <= 50 gives <= 250 blocks): seven
+// LDS reads per ten multiply-adds instead of twenty
+template <int D, class FA, class FB, class FO>
+__device__ __forceinline__ void ukl_block_product(int t, FA fa, FB fb, FO out) {
+    constexpr int NG = (D + 4) / 5, NP = (D + 1) / 2;
+    if (t >= NP * NG) return;
+    const int i0 = 2 * (t / NG), j0 = 5 * (t % NG);
+    const int i1 = min(i0 + 1, D - 1);
+    int jj[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) jj[u] = min(j0 + u, D - 1);
+    float acc[2][5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) { acc[0][u] = 0.f; acc[1][u] = 0.f; }
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const float a0 = fa(c, i0), a1 = fa(c, i1);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const float b = fb(c, jj[u]);
+            acc[0][u] = fmaf(a0, b, acc[0][u]);
+            acc[1][u] = fmaf(a1, b, acc[1][u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        if (j0 + u < D) {
+            out(i0, j0 + u, acc[0][u]);
+            if (i0 + 1 < D) out(i0 + 1, j0 + u, acc[1][u]);
+        }
+    }
+}
+
 __device__ __forceinline__ float wsum(float v) { return gmmvi_wave_sum(v); }
 
 struct Ws {
@@ -131,7 +164,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
     const int k = blockIdx.x, t = threadIdx.x, ld = D + 1;
     constexpr int NTH = 64 * NW;
 #ifdef GMMVI_UKL_STAMPS            // experiment builds (tools/ukl_probe.py): phase time stamps of component 0 into kl_out[1..6]
-    long long stamp[8];
+    long long stamp[12];
     stamp[0] = wall_clock64();
 #define UKL_STAMP(i) stamp[i] = wall_clock64()
 #else
@@ -145,14 +178,16 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
     //  * plain importance weights (H not symmetric, its lower triangle is mirrored): the estimate is finished as the
     //    stand-alone kernel does it, H_neg / g_neg go through global memory.
     bool direct = false;
-    if constexpr (DC > 0 && DC <= 24) {
+    if constexpr (DC > 0) {
         if (slab.part != nullptr) {
             direct = (slab_flags & GMMVI_SELF_NORMALIZED) != 0 && (slab_flags & GMMVI_EXPLICIT_ESTIMATE) == 0 &&
-                     (DC + 1) * (DC + 1) + slab.R <= 2 * DC * 64;
-            if (!direct) {
-                stein_finalize_component<DC>(sm, k, D, slab.R, slab_N, slab_flags, slab.part, slab.part_m, H_neg, g_neg, packed_old);
-                __threadfence_block();
-                __syncthreads();
+                     (DC + 1) * (DC + 1) + slab.R + 4 + (Pack<DC>::FRAGS ? DC * DC : 0) <= 2 * DC * 64;
+            if constexpr (DC <= 24) {                  // (wider instances are only launched with a slab on the direct route)
+                if (!direct) {
+                    stein_finalize_component<DC>(sm, k, D, slab.R, slab_N, slab_flags, slab.part, slab.part_m, H_neg, g_neg, packed_old);
+                    __threadfence_block();
+                    __syncthreads();
+                }
             }
         }
     }
@@ -164,6 +199,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
         const int D1 = D + 1;
         float* A = s.pr;                               // the probe scratch is idle until the search
         const float Mx = stein_slab_sum(A, A + D1 * D1, k, D, slab.R, slab.part, slab.part_m);
+        UKL_STAMP(7);
         const float scale = stein_moment_scale(A[D * D1 + D], Mx, slab_N, slab_flags);
         for (int e = t; e < D * D; e += NTH) {
             const int i = e / D, j = e % D;
@@ -176,6 +212,12 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
         }
         __syncthreads();
         // P = L^T C (into Mc): P[i][j] = sum_{c >= i} L[c][i] C[c][j]
+        if constexpr (DC >= 32) {
+            static_assert(DC < 32 || ((DC + 4) / 5) * ((DC + 1) / 2) <= 64 * NW, "one register block per thread");
+            ukl_block_product<(DC >= 32 ? DC : 2)>(t, [&](int c, int i) { return s.L[c * ld + i]; },
+                                                   [&](int c, int j) { return A[c * D1 + j]; },
+                                                   [&](int i, int j, float v) { s.Mc[i * ld + j] = v; });
+        } else {
         for (int o = t; o < D * D; o += NTH) {
             const int i = o / D, j = o % D;
             float a = 0.f;
@@ -183,9 +225,31 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             for (int c = 0; c < D; ++c) a = fmaf(s.L[c * ld + i], A[c * D1 + j], a);          // L[c][i] = 0 for c < i
             s.Mc[i * ld + j] = a;
         }
+        }
         __syncthreads();
-        // S L^T = P, row r by lane r (forward over the columns); M = -scale S, symmetrised below
-        if (t < D) {
+        UKL_STAMP(8);
+        if constexpr (Pack<(DC > 0 ? DC : 2)>::FRAGS) {
+            // blocks that carry L^-1 (operand fragments, common.h): S = P L^-T as a triangular product on all threads
+            using PK = Pack<(DC > 0 ? DC : 2)>;
+            constexpr int DPc = DC > 0 ? DC : 2;
+            float* Li = A + ((D1 * D1 + slab.R + 3) & ~3);                  // dense L^-1 [DP][DP] behind the moment matrix
+            const float* Pk = packed_old + (size_t)k * PK::STRIDE;
+            for (int e = t; e < DPc * DPc; e += NTH) Li[e] = 0.f;
+            __syncthreads();
+            for (int e = t; e < 64 * PK::NF; e += NTH) {
+                const int f = e >> 6, l = e & 63;
+                int mt = 0, rem = f;
+                for (;; ++mt) { const int nfm = PK::nf(mt); if (rem < nfm) break; rem -= nfm; }
+                const int row = 16 * mt + (l & 15), col = 4 * rem + (l >> 4);
+                if (row < DPc && col < DPc) Li[row * DPc + col] = Pk[PK::FWD + e];
+            }
+            __syncthreads();
+            // (L^-1 is stored dense with its zeros: the sum runs over all m, straight-line)
+            ukl_block_product<DPc>(t, [&](int m2, int r) { return s.Mc[r * ld + m2]; },
+                                   [&](int m2, int j) { return Li[j * DPc + m2]; },
+                                   [&](int r, int j, float v) { s.M[r * ld + j] = -scale * v; });
+        } else if (t < D) {
+            // S L^T = P, row r by lane r (forward over the columns); M = -scale S, symmetrised below
             float srow[DC > 0 ? DC : 1];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
@@ -196,6 +260,8 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             }
 #pragma unroll
             for (int j = 0; j < D; ++j) s.M[t * ld + j] = -scale * srow[j];
+        }
+        if (t < D) {
             float a = 0.f;
 #pragma unroll
             for (int c = 0; c < D; ++c) a = fmaf(s.L[c * ld + t], s.y[c], a);
@@ -716,8 +782,8 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
     if (k == 0 && t == 0 && kl_out)
         for (int i = 1; i <= 6; ++i) kl_out[i] = (float)(stamp[i] - stamp[0]);
     if (k == 0 && t == 0 && !kl_out && slab.part)       // single-call iteration: no info array, print
-        printf("update_kl stamps (10 ns): front %lld householder %lld search %lld factor %lld pack %lld end %lld\n",
-               stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4],
+        printf("update_kl stamps (10 ns): slabsum %lld P %lld rest-of-front %lld | front %lld householder %lld search %lld factor %lld pack %lld end %lld\n",
+               stamp[7] - stamp[0], stamp[8] - stamp[7], stamp[1] - stamp[8], stamp[1] - stamp[0], stamp[2] - stamp[1], stamp[3] - stamp[2], stamp[4] - stamp[3], stamp[5] - stamp[4],
                stamp[6] - stamp[5]);
     kl_out = nullptr;
 #endif
@@ -800,7 +866,12 @@ int gmmvi_update_components_kl_from_slab(gmmvi_ctx* ctx, int K, int D, const Ste
                                          float* chols_dev, const float* stepsizes_dev, float temperature, float l2_init,
                                          float* last_eta_dev, float* l2_dev, float* num_received_updates_dev,
                                          int32_t* success_out_dev, float* packed_out_dev) {
-    const bool fused = (D == 4 || D == 10 || D == 20) && !gmmvi_is_blocked_dim(D);
+    // one launch: the instances that carry the finalize prologue (D = 4 / 10 / 20), and every unrolled instance on the direct
+    // route (self-normalised weights, estimate not requested explicitly, the moment matrix fits the probe scratch)
+    const bool direct = (stein_flags & GMMVI_SELF_NORMALIZED) != 0 && (stein_flags & GMMVI_EXPLICIT_ESTIMATE) == 0 &&
+                        (size_t)(D + 1) * (D + 1) + slab.R + 4 + (D >= GMMVI_MFMA_DENSITY_FROM_DP ? (size_t)D * D : 0) <= (size_t)2 * D * 64;
+    const bool fused = !gmmvi_is_blocked_dim(D) &&
+                       ((D == 4 || D == 10 || D == 20) || ((D == 32 || D == 40 || D == 50) && direct));
     if (!fused) {
         int rc = gmmvi_stein_finalize_slab(ctx, K, D, slab, N, stein_flags, packed_old_dev, H_neg_dev, g_neg_dev);
         if (rc != GMMVI_OK) return rc;
