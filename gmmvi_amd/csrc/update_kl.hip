@@ -284,7 +284,17 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
         s.y[t] = gt;
     }
     __syncthreads();
-    // ---- T1 = R_sym L (into Mc), M = L^T T1, w = L^T g~ : the D^2 outputs are spread over all 64 lanes ---------------------
+    // ---- T1 = R_sym L (into Mc), M = L^T T1, w = L^T g~ : the D^2 outputs are spread over all lanes (2 x 5 register blocks
+    // for the wide instances) ---------------------------------------------------------------------------------------------
+    if constexpr (DC >= 32) {
+        ukl_block_product<(DC >= 32 ? DC : 2)>(t, [&](int c, int i) { return s.M[i * ld + c]; },
+                                               [&](int c, int j) { return s.L[c * ld + j]; },
+                                               [&](int i, int j, float v) { s.Mc[i * ld + j] = v; });
+        __syncthreads();
+        ukl_block_product<(DC >= 32 ? DC : 2)>(t, [&](int c, int i) { return s.L[c * ld + i]; },
+                                               [&](int c, int j) { return s.Mc[c * ld + j]; },
+                                               [&](int i, int j, float v) { s.M[i * ld + j] = v; });
+    } else {
     for (int o = t; o < D * D; o += NTH) {
         const int i = o / D, j = o % D;
         float a = 0.f;
@@ -299,6 +309,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
 #pragma unroll
         for (int c = 0; c < D; ++c) a = fmaf(s.L[c * ld + i], s.Mc[c * ld + j], a);        // L[c][i] = 0 for c < i
         s.M[i * ld + j] = a;
+    }
     }
     if (t < D) {
         float a = 0.f;
