@@ -25,6 +25,7 @@ def _pair(kind, d, k, s, seed, cfg):
     ("stm", 6, 5, 30, samtron_config(30, snis=False, initial_stepsize=0.01)),
     ("gmm", 32, 4, 80, samtron_config(80)),            # tiled Stein kernel + wide mixture_eval (what bench.py c3 composes)
     ("gmm", 50, 5, 100, samtron_config(100)),
+    ("gmm", 32, 4, 80, samtron_config(80, snis=False, initial_stepsize=0.01)),   # plain weights: finalize launch + update
 ])
 def test_fast_path_equals_modular_path(kind, d, k, s, cfg):
     o, fast, slow = _pair(kind, d, k, s, 23, cfg)
@@ -54,9 +55,11 @@ def test_fast_path_equals_modular_path(kind, d, k, s, cfg):
     ("stm", 4, 3, 32, samtron_config(32)),
     ("planar", 10, 4, 50, samtron_config(50)),
     ("gmm", 20, 8, 64, samtron_config(64)),
+    ("gmm", 32, 4, 80, samtron_config(80)),            # wide instances: dense L^-1 from the fragments, register-blocked products
+    ("gmm", 50, 5, 100, samtron_config(100)),
 ])
 def test_direct_whitening_of_the_moment_sums(kind, d, k, s, cfg):
-    """Default single-call route at D = 4 / 10 / 20 with self-normalised weights: the update kernel forms
+    """Default single-call route at D = 4 / 10 / 20 / 32 / 40 / 50 with self-normalised weights: the update kernel forms
     M = -sym(L^T C L^-T) / sum e from the Stein moment sums instead of materialising H (csrc/update_kl.hip).  Same mathematics,
     fewer roundings: the first iteration agrees with the module-by-module path to a few ulp, the trajectories stay together,
     the accept / reject decisions are the same."""
