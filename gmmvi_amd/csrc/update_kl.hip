@@ -565,7 +565,6 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
 #pragma unroll
             for (int c = 0; c < DR; ++c)
                 xr[c] = (t < DR && c >= t) ? ((c == t ? 1.f : 0.f) + s.Mc[t * ld + c] * inv) : 0.f;
-            float* uv = s.pr;                                      // column j of U as a broadcast vector
             constexpr int UNR_J = DR <= GMMVI_UKL_UNROLL_MAX ? DR : 1;
 #pragma unroll UNR_J
             for (int j = DR - 1; j >= 0; --j) {
@@ -576,18 +575,18 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
                 if (!(p > 0.f) || !(p < FLT_MAX)) { success = false; break; }
                 const float d = sqrtf(p);
                 const float u = (t == j) ? d : (t < j ? bj / d : 0.f);
-                if (t < DR) { uv[t] = u; Us[t * LU + j] = u; }
-                UKL_WSYNC();
-                float uc[LU];
+                if (t < DR) Us[t * LU + j] = u;                    // the image is only read by the back substitution
+                // column j of U reaches the other lanes through v_readlane (scalar operands of the update below): no LDS
+                // round trip inside the D-step dependency chain
 #pragma unroll
-                for (int q4 = 0; q4 < LU / 4; ++q4) {
-                    const float4 v4 = reinterpret_cast<const float4*>(uv)[q4];
-                    uc[4 * q4] = v4.x; uc[4 * q4 + 1] = v4.y; uc[4 * q4 + 2] = v4.z; uc[4 * q4 + 3] = v4.w;
+                for (int c = 0; c < DR; ++c) {
+                    if (c < j) {
+                        const float ucc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(u), c));
+                        xr[c] = (c >= t) ? fmaf(-u, ucc, xr[c]) : xr[c];
+                    }
                 }
-#pragma unroll
-                for (int c = 0; c < DR; ++c) xr[c] = (c < j && c >= t) ? fmaf(-u, uc[c], xr[c]) : xr[c];
-                UKL_WSYNC();
             }
+            UKL_WSYNC();
         }
         if (success) {
             // back substitution U x = r for r = row t of L (x = row t of L') and, in every lane, r = w (z)
