@@ -359,25 +359,22 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             wtr[m2].x = (2 * m2 < DR) ? s.wt[2 * m2] : 0.f;
             wtr[m2].y = (2 * m2 + 1 < DR) ? s.wt[2 * m2 + 1] : 0.f;
         }
-        float* xv = s.pr;                           // column c of M and p as 16-byte aligned broadcast vectors (the probe
-        float* pv = s.pr + 64;                      // scratch is free until the search starts; 3 D (D + 4) floats precede it)
-        if (t < 64) { xv[t] = 0.f; pv[t] = 0.f; }   // the padding of the broadcast vectors
-        UKL_WSYNC();
+        // column c of M (element (j, c) lives in lane j) and p reach the other lanes through v_readlane: no LDS round trip in
+        // the two hand-overs of a step (the D-step chain is latency bound)
+        auto rl = [](float v, int lane_c) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_c)); };
         // one instantiation per column (ukl_static_for): c is a compile-time constant in every step -- `#pragma unroll` gives
         // up on this body from D ~ 40, and with a run-time c every select below stays a select
         ukl_static_for<0, (DR > 2 ? DR - 2 : 0)>([&](auto c_const) {
             constexpr int c = decltype(c_const)::value;
             constexpr int M0 = (c + 1) / 2;          // first pair with a live element (j > c)
             const float mc = (c & 1) ? mrow[c / 2].y : mrow[c / 2].x;
-            if (t < DR) xv[t] = mc;
-            UKL_WSYNC();
             ukl_v2 x[DH];
 #pragma unroll
-            for (int q4 = 0; q4 < D4; ++q4) {
-                const float4 v4 = reinterpret_cast<const float4*>(xv)[q4];
-                x[2 * q4].x = v4.x; x[2 * q4].y = v4.y; x[2 * q4 + 1].x = v4.z; x[2 * q4 + 1].y = v4.w;
+            for (int m2 = M0; m2 < DH; ++m2) {
+                x[m2].x = (2 * m2 < DR && 2 * m2 > c) ? rl(mc, 2 * m2 < DR ? 2 * m2 : 0) : 0.f;
+                x[m2].y = (2 * m2 + 1 < DR && 2 * m2 + 1 > c) ? rl(mc, 2 * m2 + 1 < DR ? 2 * m2 + 1 : 0) : 0.f;
             }
-            const float xt = xv[t < DR ? t : 0];     // this lane's own element of the column (its v_t below)
+            const float xt = mc;                     // this lane's own element of the column (its v_t below)
             const float x1 = ((c + 1) & 1) ? x[(c + 1) / 2].y : x[(c + 1) / 2].x;
             // dead part j <= c + 1 zeroed (compile-time), then the tail norm on pairs
             ukl_v2 t2 = {0.f, 0.f};
@@ -411,13 +408,11 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             float p = p2.x + p2.y;
             p = act ? p * beta : 0.f;
             const float vv = act ? (t == c + 1 ? x1 - alpha : xt) : 0.f;
-            if (t < DR) pv[t] = p;
-            UKL_WSYNC();
             ukl_v2 pj[DH];
 #pragma unroll
-            for (int q4 = 0; q4 < D4; ++q4) {
-                const float4 v4 = reinterpret_cast<const float4*>(pv)[q4];
-                pj[2 * q4].x = v4.x; pj[2 * q4].y = v4.y; pj[2 * q4 + 1].x = v4.z; pj[2 * q4 + 1].y = v4.w;
+            for (int m2 = M0; m2 < DH; ++m2) {
+                pj[m2].x = (2 * m2 < DR && 2 * m2 > c) ? rl(p, 2 * m2 < DR ? 2 * m2 : 0) : 0.f;
+                pj[m2].y = (2 * m2 + 1 < DR && 2 * m2 + 1 > c) ? rl(p, 2 * m2 + 1 < DR ? 2 * m2 + 1 : 0) : 0.f;
             }
             ukl_v2 kk2 = {0.f, 0.f}, wd2 = {0.f, 0.f};
 #pragma unroll
