@@ -550,11 +550,14 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
     if (DC > 0) {
         // ---- static D: B = I + Mc/eta* = U U^T (U upper) factorised right-looking with the lane's row in registers; then
         // L' = L U^-T and z = U^-1 w by one back substitution per lane (lane t: row t of L, every lane also carries w), and
-        // mu' = mu - L' z / eta*.  U is shared through an LDS image with 16-byte aligned rows (broadcast ds_read_b128). -----
+        // mu' = mu - L' z / eta*.  Lane t keeps row t of U in registers; the other lanes read it with v_readlane (both phases
+        // are D-step dependency chains: an LDS hand-over per step was half their time). ----------------------------------------
         constexpr int DR = DC > 0 ? DC : 1;
-        constexpr int LU = ((DR + 3) / 4) * 4;                     // row stride of the U image
-        float* Us = s.pr + 64;                                     // D x LU image in the (idle) probe scratch, 16-byte aligned
         float xr[DR];                                              // B row, later the solution row (L' row t)
+        float urow[DR];                                            // row t of U (entries j >= t)
+#pragma unroll
+        for (int c = 0; c < DR; ++c) urow[c] = 0.f;
+        auto rlane = [](float v, int lane_c) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_c)); };
         float new_mu = 0.f;
         if (success) {
 #pragma unroll
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
                 if (!(p > 0.f) || !(p < FLT_MAX)) { success = false; break; }
                 const float d = sqrtf(p);
                 const float u = (t == j) ? d : (t < j ? bj / d : 0.f);
-                if (t < DR) Us[t * LU + j] = u;                    // the image is only read by the back substitution
+                urow[j] = u;                                       // row t of U stays in the lane's registers
                 // column j of U reaches the other lanes through v_readlane (scalar operands of the update below): no LDS
                 // round trip inside the D-step dependency chain
 #pragma unroll
@@ -588,23 +591,19 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             float zr[DR];
 #pragma unroll
             for (int c = 0; c < DR; ++c) { xr[c] = (t < DR) ? s.L[t * ld + c] : 0.f; zr[c] = s.w[c]; }
+            // row i of U is read out of lane i's registers (v_readlane: scalar operands of the chains below)
 #pragma unroll
             for (int i = DR - 1; i >= 0; --i) {
-                float ur[LU];
-#pragma unroll
-                for (int q4 = i / 4; q4 < LU / 4; ++q4) {
-                    const float4 v4 = reinterpret_cast<const float4*>(Us + i * LU)[q4];
-                    ur[4 * q4] = v4.x; ur[4 * q4 + 1] = v4.y; ur[4 * q4 + 2] = v4.z; ur[4 * q4 + 3] = v4.w;
-                }
                 float a = xr[i], b = zr[i];
 #pragma unroll
-                for (int j = i + 1; j < DR; ++j) { a = fmaf(-ur[j], xr[j], a); b = fmaf(-ur[j], zr[j], b); }
-                const float rd = 1.f / ur[i];
+                for (int j = i + 1; j < DR; ++j) {
+                    const float uij = rlane(urow[j], i);
+                    a = fmaf(-uij, xr[j], a);
+                    b = fmaf(-uij, zr[j], b);
+                }
+                const float rd = 1.f / rlane(urow[i], i);
                 xr[i] = a * rd;
                 zr[i] = b * rd;
-                // the rows of U are independent loads: without a fence the scheduler hoists those of many steps above the
-                // chain and the register allocator runs out (D = 50: 770 bytes of scratch per lane)
-                __builtin_amdgcn_sched_barrier(0);
             }
             float acc = 0.f;
             bool bad = false;
@@ -617,7 +616,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             new_mu = s.mu[t < DR ? t : 0] - acc * inv;
             bad |= !(new_mu == new_mu);
             success = (__any(bad && t < DR) == 0);                                         // :493 is_nan(new_chol)
-            UKL_WSYNC();                                       // all reads of the U image are done: M becomes L'
+            UKL_WSYNC();
             if (success && t < DR) {
 #pragma unroll
                 for (int c = 0; c < DR; ++c) {
