@@ -758,15 +758,32 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
         // L^-1 of the final factor for the matrix-core fragments of the block: lane t solves L x = e_t (column t) from the
         // LDS image of L (every lane reads the same element: broadcast), the dense inverse goes through Mc
         __syncthreads();
+        constexpr int LA = DC > 0 ? ((DC + 3) / 4) * 4 : 4;          // static instances: L again with 16-byte aligned rows
+        float* La = s.pr;                                           // (the probe scratch is idle; broadcast ds_read_b128)
+        if constexpr (DC > 0) {
+            if (pd.nf_total > 0) {
+                for (int e = t; e < DC * LA; e += NTH) {
+                    const int i = e / LA, j = e - i * LA;
+                    La[e] = (j <= i) ? Lf[i * ld + j] : 0.f;
+                }
+            }
+            __syncthreads();
+        }
         if (pd.nf_total > 0 && t < D) {
             if constexpr (DC > 0) {
                 float x[DC > 0 ? DC : 1];
 #pragma unroll
                 for (int i = 0; i < DC; ++i) {
+                    float lr[LA];
+#pragma unroll
+                    for (int q4 = 0; q4 <= i / 4; ++q4) {
+                        const float4 v4 = reinterpret_cast<const float4*>(La + i * LA)[q4];
+                        lr[4 * q4] = v4.x; lr[4 * q4 + 1] = v4.y; lr[4 * q4 + 2] = v4.z; lr[4 * q4 + 3] = v4.w;
+                    }
                     float a = (i == t) ? 1.f : 0.f;
 #pragma unroll
-                    for (int j = 0; j < i; ++j) a = fmaf(-Lf[i * ld + j], x[j], a);       // x_j = 0 for j < t
-                    x[i] = (i >= t) ? a / Lf[i * ld + i] : 0.f;
+                    for (int j = 0; j < i; ++j) a = fmaf(-lr[j], x[j], a);                // x_j = 0 for j < t
+                    x[i] = (i >= t) ? a / lr[i] : 0.f;
                 }
 #pragma unroll
                 for (int i = 0; i < DC; ++i) s.Mc[i * ld + t] = x[i];
