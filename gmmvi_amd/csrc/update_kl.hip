@@ -574,8 +574,10 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
                 for (int c = 0; c < DR; ++c) bj = (c == j) ? xr[c] : bj;
                 const float p = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bj), j));
                 if (!(p > 0.f) || !(p < FLT_MAX)) { success = false; break; }
-                const float d = sqrtf(p);
-                const float u = (t == j) ? d : (t < j ? bj / d : 0.f);
+                // v_sqrt_f32 / v_rcp_f32 (1 ulp each, like the rounding of the updates around them) keep the IEEE sequences out of
+                // the D-step chain
+                const float d = __builtin_amdgcn_sqrtf(p);
+                const float u = (t == j) ? d : (t < j ? bj * __builtin_amdgcn_rcpf(d) : 0.f);
                 urow[j] = u;                                       // row t of U stays in the lane's registers
                 // column j of U reaches the other lanes through v_readlane (scalar operands of the update below): no LDS
                 // round trip inside the D-step dependency chain
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
                     a = fmaf(-uij, xr[j], a);
                     b = fmaf(-uij, zr[j], b);
                 }
-                const float rd = 1.f / rlane(urow[i], i);
+                const float rd = __builtin_amdgcn_rcpf(rlane(urow[i], i));
                 xr[i] = a * rd;
                 zr[i] = b * rd;
             }
