@@ -149,14 +149,29 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
     const bool valid = lane < n_here;
     float* sm_merge = sm;                              // staging, then the merge area
 
-    // ---- x tile: coalesced load staged through LDS (rows of a row-major [N, D] array are 4D bytes apart) -----------
+    // ---- x tile: rows that are a whole number of 16-byte pieces are read straight into the lane's registers (lane = sample:
+    // the five loads of a row walk the same cache lines, the W waves of the workgroup hit in L1); other shapes are staged
+    // through LDS with a coalesced load (rows of a row-major [N, D] array are 4D bytes apart) ---------------------------
     const int ldx = D | 1;
-    for (int e = threadIdx.x; e < n_here * D; e += blockDim.x) sm_merge[(e / D) * ldx + (e % D)] = X[(size_t)n0 * D + e];
-    __syncthreads();
     float x[DP];
+    if (DP % 4 == 0 && D == DP && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+        const float4* xrow = reinterpret_cast<const float4*>(X + (size_t)min(n, N - 1) * D);
 #pragma unroll
-    for (int i = 0; i < DP; ++i) x[i] = (valid && i < D) ? sm_merge[lane * ldx + i] : 0.f;
-    __syncthreads();
+        for (int q4 = 0; q4 < DP / 4; ++q4) {
+            const float4 v4 = xrow[q4];
+            x[4 * q4] = v4.x; x[4 * q4 + 1] = v4.y; x[4 * q4 + 2] = v4.z; x[4 * q4 + 3] = v4.w;
+        }
+        if (!valid) {
+#pragma unroll
+            for (int i = 0; i < DP; ++i) x[i] = 0.f;
+        }
+    } else {
+        for (int e = threadIdx.x; e < n_here * D; e += blockDim.x) sm_merge[(e / D) * ldx + (e % D)] = X[(size_t)n0 * D + e];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < DP; ++i) x[i] = (valid && i < D) ? sm_merge[lane * ldx + i] : 0.f;
+        __syncthreads();
+    }
 
     float m = -3.0e38f, s = 0.f;
     float m2 = -3.0e38f, s2 = 0.f;                      // second mixture over the same components (logw2), optional
