@@ -149,8 +149,8 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
     const bool valid = lane < n_here;
     float* sm_merge = sm;                              // staging, then the merge area
 
-    // ---- x tile: rows that are a whole number of 16-byte pieces are read straight into the lane's registers (lane = sample:
-    // the five loads of a row walk the same cache lines, the W waves of the workgroup hit in L1); other shapes are staged
+    // ---- x tile: rows that are a whole number of 16- or 8-byte pieces are read straight into the lane's registers (lane = sample:
+    // the loads of a row walk the same cache lines, the W waves of the workgroup hit in L1); other shapes are staged
     // through LDS with a coalesced load (rows of a row-major [N, D] array are 4D bytes apart) ---------------------------
     const int ldx = D | 1;
     float x[DP];
@@ -160,6 +160,17 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
         for (int q4 = 0; q4 < DP / 4; ++q4) {
             const float4 v4 = xrow[q4];
             x[4 * q4] = v4.x; x[4 * q4 + 1] = v4.y; x[4 * q4 + 2] = v4.z; x[4 * q4 + 3] = v4.w;
+        }
+        if (!valid) {
+#pragma unroll
+            for (int i = 0; i < DP; ++i) x[i] = 0.f;
+        }
+    } else if (DP % 2 == 0 && D == DP && (reinterpret_cast<uintptr_t>(X) & 7) == 0) {       // 8-byte pieces (D = 10)
+        const float2* xrow = reinterpret_cast<const float2*>(X + (size_t)min(n, N - 1) * D);
+#pragma unroll
+        for (int q2 = 0; q2 < DP / 2; ++q2) {
+            const float2 v2 = xrow[q2];
+            x[2 * q2] = v2.x; x[2 * q2 + 1] = v2.y;
         }
         if (!valid) {
 #pragma unroll
