@@ -32,6 +32,9 @@ __device__ __forceinline__ float combine_log_values(const float* __restrict__ pa
         case 6: return combine_log_values_n<6>(parts, N, n);
         case 7: return combine_log_values_n<7>(parts, N, n);
         case 8: return combine_log_values_n<8>(parts, N, n);
+        case 10: return combine_log_values_n<10>(parts, N, n);
+        case 12: return combine_log_values_n<12>(parts, N, n);
+        case 16: return combine_log_values_n<16>(parts, N, n);
         default: break;
     }
     float m = -3.0e38f;
@@ -84,6 +87,9 @@ __device__ __forceinline__ void combine_element(const CombineJob& j, long e) {
         case 6: combine_element_n<6>(j, e); break;
         case 7: combine_element_n<7>(j, e); break;
         case 8: combine_element_n<8>(j, e); break;
+        case 10: combine_element_n<10>(j, e); break;
+        case 12: combine_element_n<12>(j, e); break;
+        case 16: combine_element_n<16>(j, e); break;
         default: combine_element_n<0>(j, e); break;
     }
 }
@@ -109,6 +115,9 @@ __device__ __forceinline__ bool combine_carried(const CombineJob& j) {
             case 6: combine_carried_n<6>(j); break;
             case 7: combine_carried_n<7>(j); break;
             case 8: combine_carried_n<8>(j); break;
+            case 10: combine_carried_n<10>(j); break;
+            case 12: combine_carried_n<12>(j); break;
+            case 16: combine_carried_n<16>(j); break;
             default: combine_carried_n<0>(j); break;
         }
     }

@@ -534,6 +534,240 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_kernel(float nu, int K_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// mixture_eval on the matrix cores, component block shared by the workgroup
+// ---------------------------------------------------------------------------------------------------------------
+// In the kernel above every wave of a workgroup walks its own components and fetches their operand fragments (17 KB a
+// component at D = 50) from the L2 for 16 NTS samples: 0.9 GB per launch at the C3 shape, the kernel's real bound.  Here the
+// EIGHT waves of a workgroup work on the SAME component at a time, each on its own 16 NTS samples: the block (fragments, mu,
+// log-normaliser) is brought to LDS once per workgroup and component (double-buffered: the next block's global loads are in
+// flight while the current one is multiplied; one barrier per component), every MFMA takes its A operand with one
+// conflict-free ds_read_b32.  A wave owns its samples for all components of the chunk, so nothing is merged across waves:
+// log values and gradients leave straight from the registers.  The component chunks over blockIdx.y and the merge of their
+// partials are those of the other kernels.
+template <int DP, int FAMILY, bool GRAD, int NTS>
+__global__ __launch_bounds__(512) void mixture_eval_mfma_ws_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
+                                                                   const float* __restrict__ logw, const float* __restrict__ X,
+                                                                   int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
+                                                                   float* __restrict__ grad_out, const float* __restrict__ logw2,
+                                                                   float* __restrict__ lp2_out, CombineJob carried) {
+    using PK = Pack<DP>;
+    constexpr int MT = PK::MT, KS = PK::KS;
+    constexpr int TSW = 16 * NTS;                      // samples per wave
+    constexpr int TS = 8 * TSW;                        // samples per workgroup
+    constexpr int KSP = ((KS + 3) / 4) * 4;
+    constexpr int ZW = 4 * KSP + 4;
+    constexpr int NFR = 64 * (PK::NF + (GRAD ? PK::NB : 0));           // fragment floats of a block that are used
+    constexpr int BLK = NFR + ((DP + 1 + 3) / 4) * 4;                   // + mu[DP], log-normaliser
+    constexpr int NPRE = (BLK + 511) / 512;
+    extern __shared__ __align__(16) float sm[];
+    if (combine_carried(carried)) return;
+    const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
+    const int k_lo = blockIdx.y * kchunk;
+    const int K = min(K_total, k_lo + kchunk);
+    if (gridDim.y > 1) {
+        if (lp_out) lp_out += (size_t)blockIdx.y * N;
+        if (lp2_out) lp2_out += (size_t)blockIdx.y * N;
+        if (GRAD && grad_out) grad_out += (size_t)blockIdx.y * N * D;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, n16 = lane & 15;
+    const int n0 = blockIdx.x * TS + wave * TSW;       // this wave's first sample
+    float* blk0 = sm;                                  // two component blocks
+    float* Zw = sm + 2 * BLK + (size_t)wave * (GRAD ? NTS * 16 * ZW : 0);
+
+    // one element of component k's LDS block: [fragments | mu | log-normaliser]
+    auto block_src = [&](int k, int e) -> float {
+        const float* Pk = packed + (size_t)k * PK::STRIDE;
+        return e < NFR ? Pk[PK::FWD + e] : (e < NFR + DP ? Pk[PK::MU + (e - NFR)] : (e == NFR + DP ? Pk[PK::CONST] : 0.f));
+    };
+    // ---- the wave's x: lane (g, n) keeps x[n][4 s + g] of its NTS sub-tiles (rows beyond N: clamped, masked at the stores) ---
+    float xb[NTS][KS];
+#pragma unroll
+    for (int t = 0; t < NTS; ++t) {
+        const float* xrow = X + (size_t)min(n0 + 16 * t + n16, N - 1) * D;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xb[t][s] = (4 * s + g < D) ? xrow[4 * s + g] : 0.f;
+    }
+    float m[NTS], sv[NTS], m2[NTS], s2[NTS];
+#pragma unroll
+    for (int t = 0; t < NTS; ++t) { m[t] = -3.0e38f; sv[t] = 0.f; m2[t] = -3.0e38f; s2[t] = 0.f; }
+    const bool dual = logw2 != nullptr;
+    me_f32x4 acc[GRAD ? NTS : 1][GRAD ? MT : 1];
+    if (GRAD) {
+#pragma unroll
+        for (int t = 0; t < NTS; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][mt][r] = 0.f;
+    }
+    const float nud = nu + (float)D;
+
+    float pre[NPRE];
+    if (k_lo < K) {
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u)
+            if (tid + 512 * u < BLK) blk0[tid + 512 * u] = block_src(k_lo, tid + 512 * u);
+    }
+    __syncthreads();
+    for (int k = k_lo; k < K; ++k) {
+        const float* B = blk0 + ((k - k_lo) & 1) * BLK;
+        float* Bn = blk0 + (((k - k_lo) & 1) ^ 1) * BLK;
+        const bool more = k + 1 < K;
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u) pre[u] = (tid + 512 * u < BLK) ? block_src(k + 1, min(tid + 512 * u, BLK - 1)) : 0.f;
+        }
+        const float* Fw = B + lane;                    // forward fragment f at Fw[64 f]
+        const float* Bw = B + 64 * PK::NF + lane;      // backward fragment f at Bw[64 f]
+        float mus[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) mus[s] = (4 * s + g < DP) ? B[NFR + 4 * s + g] : 0.f;
+        const float cst = B[NFR + DP];
+        const float lw = logw[k];
+        const float lw2 = dual ? logw2[k] : 0.f;
+        me_f32x4 z[NTS][MT];
+        float ldv[NTS], ev[NTS], scv[NTS], cfv[NTS];
+#pragma unroll
+        for (int t = 0; t < NTS; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[t][mt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float bx[NTS];
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) bx[t] = xb[t][s] - mus[s];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (s < PK::nf(mt)) {
+                    const float a = Fw[64 * PK::fwd_index(mt, s)];                      // one fragment read serves NTS MFMAs
+#pragma unroll
+                    for (int t = 0; t < NTS; ++t) z[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bx[t], z[t][mt], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) {
+            float q = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q = fmaf(z[t][mt][r], z[t][mt][r], q);
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            float ld, coef;
+            if (FAMILY == GMMVI_GAUSS) {
+                ld = fmaf(-0.5f, q, cst);
+                coef = -1.f;
+            } else {
+                ld = cst - 0.5f * nud * log1pf(q / nu);
+                coef = -nud / (nu + q);
+            }
+            ldv[t] = ld;
+            const float a = ld + lw;
+            const float mn = fmaxf(m[t], a);
+            const float sc = __expf(m[t] - mn);
+            const float e = __expf(a - mn);
+            sv[t] = fmaf(sv[t], sc, e);
+            m[t] = mn;
+            ev[t] = e; scv[t] = sc; cfv[t] = coef;
+            if (dual) {
+                const float a2 = ld + lw2;
+                const float mn2 = fmaxf(m2[t], a2);
+                s2[t] = fmaf(s2[t], __expf(m2[t] - mn2), __expf(a2 - mn2));
+                m2[t] = mn2;
+            }
+        }
+        if (ld_out != nullptr) {
+            float v = ldv[0];
+#pragma unroll
+            for (int t = 1; t < NTS; ++t) v = (g == t) ? ldv[t] : v;
+            if (g < NTS && n0 + 16 * g + n16 < N) ld_out[(size_t)k * N + n0 + 16 * g + n16] = v;
+        }
+        if (GRAD) {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * mt + g < KSP) Zw[(t * 16 + n16) * ZW + r * KSP + 4 * mt + g] = z[t][mt][r];
+            ME_WAVE_LDS_SYNC();
+            float bz[NTS][KSP];
+#pragma unroll
+            for (int t = 0; t < NTS; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < KSP / 4; ++q4) {
+                    const me_f32x4 v4 = *reinterpret_cast<const me_f32x4*>(Zw + (t * 16 + n16) * ZW + g * KSP + 4 * q4);
+                    bz[t][4 * q4] = v4[0]; bz[t][4 * q4 + 1] = v4[1]; bz[t][4 * q4 + 2] = v4[2]; bz[t][4 * q4 + 3] = v4[3];
+                }
+            me_f32x4 y[NTS][MT];
+#pragma unroll
+            for (int t = 0; t < NTS; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[t][mt][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if (s >= 4 * mt) {
+                        const float a = Bw[64 * PK::bwd_index(mt, s)];
+#pragma unroll
+                        for (int t = 0; t < NTS; ++t) y[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bz[t][s], y[t][mt], 0, 0, 0);
+                    }
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) {
+                const float ec = ev[t] * cfv[t];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][mt][r] = fmaf(acc[t][mt][r], scv[t], ec * y[t][mt][r]);
+            }
+            ME_WAVE_LDS_SYNC();
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < NPRE; ++u)
+                if (tid + 512 * u < BLK) Bn[tid + 512 * u] = pre[u];
+        }
+        __syncthreads();
+    }
+    // ---- the wave's results leave from its registers: log values by the lanes of group 0, gradient rows 4 g + r of tile mt ---
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) {
+            const int n = n0 + 16 * t + n16;
+            if (n < N) {
+                if (lp_out != nullptr) lp_out[n] = m[t] + __logf(sv[t]);
+                if (dual && lp2_out != nullptr) lp2_out[n] = m2[t] + __logf(s2[t]);
+            }
+        }
+    }
+    if (GRAD && grad_out != nullptr) {
+#pragma unroll
+        for (int t = 0; t < NTS; ++t) {
+            // every lane of a column (same n16) holds the same m / sv: the sums run over the components, not over lanes
+            const int n = n0 + 16 * t + n16;
+            const float inv = 1.f / sv[t];
+            if (n < N) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * mt + 4 * g + r;
+                        if (i < D) grad_out[(size_t)n * D + i] = acc[t][mt][r] * inv;
+                    }
+            }
+        }
+    }
+}
+
 template <int DP, int NTS>
 static int launch_mixture_eval_mfma(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
                                     const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
@@ -617,12 +851,91 @@ static int launch_mixture_eval_mfma(gmmvi_ctx* ctx, int family, float nu, int K,
     return GMMVI_OK;
 }
 
+template <int DP, int NTS>
+static int launch_mixture_eval_mfma_ws(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
+                                       const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
+                                       const float* logw2, float* lp2) {
+    using PK = Pack<DP>;
+    constexpr int TS = 128 * NTS, KSP = ((PK::KS + 3) / 4) * 4, ZW = 4 * KSP + 4;
+    const bool want_grad = grad != nullptr;
+    const bool want_merge = want_grad || lp != nullptr;
+    const int nfr = 64 * (PK::NF + (want_grad ? PK::NB : 0));
+    const int blk = nfr + ((DP + 1 + 3) / 4) * 4;
+    const size_t shmem = ((size_t)2 * blk + (want_grad ? (size_t)8 * NTS * 16 * ZW : 0)) * sizeof(float);
+    const int tiles = (N + TS - 1) / TS;
+    // component chunks so that every CU gets a workgroup (two where the LDS allows), at least eight components each (the
+    // block pipeline has a prologue and every chunk writes partial outputs)
+    const int per_cu = shmem * 2 <= 150 * 1024 ? 2 : 1;
+    int ky = (per_cu * ctx->num_cus + tiles / 2) / tiles;
+    if (ky > K / 8) ky = K / 8;
+    if (ky < 1) ky = 1;
+    const int kchunk = (K + ky - 1) / ky;
+    ky = (K + kchunk - 1) / kchunk;
+    float* lp_k = lp;
+    float* grad_k = grad;
+    float* lp2_k = lp2;
+    const bool defer = ctx->defer_combine && ky > 1 && want_merge;
+    if (defer) {
+        int rc = gmmvi_flush_pending_combine(ctx);
+        if (rc != GMMVI_OK) return rc;
+    }
+    if (ky > 1 && want_merge) {
+        size_t need = ((size_t)ky * N * (logw2 ? 2 : 1) + (want_grad ? (size_t)ky * N * D : 0)) * sizeof(float);
+        int rc = defer ? gmmvi_defer_reserve(ctx, need) : gmmvi_ws_reserve(ctx, need);
+        if (rc != GMMVI_OK) return rc;
+        lp_k = (float*)(defer ? ctx->defer_ws : ctx->ws);
+        lp2_k = logw2 ? lp_k + (size_t)ky * N : nullptr;
+        grad_k = want_grad ? lp_k + (size_t)ky * N * (logw2 ? 2 : 1) : nullptr;
+    }
+    const CombineJob carried = gmmvi_take_pending_combine(ctx, 512, tiles);
+    dim3 grid(tiles + carried.blocks, ky), block(512);
+    {
+        GMMVI_PROF_UNITS(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval", (double)N * K);
+#define GMMVI_LAUNCH_WS(FAM, G)                                                                                     \
+    do {                                                                                                            \
+        if (shmem > 64 * 1024)                                                                                      \
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_mfma_ws_kernel<DP, FAM, G, NTS>,     \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
+        hipLaunchKernelGGL((mixture_eval_mfma_ws_kernel<DP, FAM, G, NTS>), grid, block, shmem, ctx->stream, nu, K,  \
+                           D, packed, logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried);                          \
+    } while (0)
+        if (family == GMMVI_GAUSS) {
+            if (want_grad) GMMVI_LAUNCH_WS(GMMVI_GAUSS, true); else GMMVI_LAUNCH_WS(GMMVI_GAUSS, false);
+        } else {
+            if (want_grad) GMMVI_LAUNCH_WS(GMMVI_STUDENT_T, true); else GMMVI_LAUNCH_WS(GMMVI_STUDENT_T, false);
+        }
+#undef GMMVI_LAUNCH_WS
+    }
+    GMMVI_LAUNCH_CHECK(ctx);
+    if (defer) {
+        CombineJob& j = ctx->pending;
+        j.R = ky; j.N = N; j.D = D;
+        j.lp_parts = lp_k; j.grad_parts = grad_k; j.lp2_parts = lp2_k;
+        j.lp_out = lp; j.grad_out = grad; j.lp2_out = lp2_k ? lp2 : nullptr;
+    } else if (ky > 1 && want_merge) {
+        GMMVI_PROF(ctx, "mixture_combine");
+        int rc = gmmvi_combine_partials_internal(ctx, ky, N, D, lp_k, grad_k, lp, grad, lp2_k, lp2);
+        if (rc != GMMVI_OK) return rc;
+    }
+    return GMMVI_OK;
+}
+
 template <int DP>
 static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
                                const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
                                const float* logw2 = nullptr, float* lp2 = nullptr) {
     using PK = Pack<DP>;
     if constexpr (PK::FRAGS) {
+        // enough samples for the workgroup-shared form (eight waves on one component at a time): the block goes to LDS once per
+        // workgroup instead of to every wave through the L2
+        // (with the gradient: C3 dual sweep 150 -> 107 us; without it the sweep is bound by the log-sum-exp tails of the 16-sample
+        // sub-tiles, not by the fragment traffic, and stays on the kernel above: 61 against 59 us)
+        static const int env_ws = getenv("GMMVI_ME_WS") ? atoi(getenv("GMMVI_ME_WS")) : -1;      // experiments: 0 off, 1 on, 2 all sweeps
+        const bool ws = env_ws >= 0 ? env_ws != 0 : true;
+        if (ws && N >= 2048 && K >= 16) {
+            if (grad != nullptr) return launch_mixture_eval_mfma_ws<DP, 2>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
+            if (env_ws == 2) return launch_mixture_eval_mfma_ws<DP, 4>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
+        }
         // sub-tiles of 16 samples per wave pass: four (every fragment fetch of a component serves 64 samples) unless the
         // gradient state of the wide dimensions would not fit the registers
         if constexpr (DP >= 40) {                      // (D = 40 with the gradient: 60 us at two sub-tiles, 82 us at four)

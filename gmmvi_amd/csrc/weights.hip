@@ -85,6 +85,9 @@ __global__ __launch_bounds__(1024) void elr_kernel(int N, const float* __restric
         case 6: elr_accumulate<6>(N, row, bg, tlp, logq, 6, beta, m, s, se, s2); break;
         case 7: elr_accumulate<7>(N, row, bg, tlp, logq, 7, beta, m, s, se, s2); break;
         case 8: elr_accumulate<8>(N, row, bg, tlp, logq, 8, beta, m, s, se, s2); break;
+        case 10: elr_accumulate<10>(N, row, bg, tlp, logq, 10, beta, m, s, se, s2); break;
+        case 12: elr_accumulate<12>(N, row, bg, tlp, logq, 12, beta, m, s, se, s2); break;
+        case 16: elr_accumulate<16>(N, row, bg, tlp, logq, 16, beta, m, s, se, s2); break;
         default: elr_accumulate<-1>(N, row, bg, tlp, logq, logq_R, beta, m, s, se, s2); break;
     }
     // wave level
