@@ -77,6 +77,23 @@ def test_mixture_eval_gauss(ctx, rng, k, d, n):
     np.testing.assert_allclose(lp2.numpy(), lp.numpy(), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("k,d,n", [(20, 50, 2304), (17, 40, 2100), (16, 32, 2049), (33, 45, 2600)])
+def test_mixture_eval_workgroup_shared_blocks(ctx, rng, k, d, n):
+    """K >= 16 and N >= 2048 with the gradient on the matrix-core dimensions: the eight waves of a workgroup share a component
+    block through LDS (density.hip mixture_eval_mfma_ws): ragged last tile, chunk merge, padded dimension (45 in 50)."""
+    m = random_gmm(rng, k, d)
+    x = m.means[rng.integers(0, k, n)] + rng.normal(size=(n, d)) * 1.5
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    ld, lp, grad = ops().mixture_eval(ctx, packed, logw, ctx.asarray(x), d, want_ld=True, want_lp=True, want_grad=True)
+    lq, g, cld = m.log_density_and_grad(x.astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(ld.numpy(), cld, rtol=1e-4, atol=5e-4)
+    np.testing.assert_allclose(lp.numpy(), lq, rtol=1e-4, atol=5e-4)
+    np.testing.assert_allclose(grad.numpy(), g, rtol=1e-3, atol=2e-3)
+    _, lp2, _ = ops().mixture_eval(ctx, packed, logw, ctx.asarray(x), d)          # the sweep without the gradient: other kernel
+    np.testing.assert_allclose(lp2.numpy(), lp.numpy(), rtol=1e-5, atol=1e-4)
+
+
 def test_mixture_eval_far_samples_and_empty(ctx, rng):
     m = random_gmm(rng, 6, 5)
     x = rng.normal(size=(100, 5)) * 200                     # far tails: LSE must not underflow to -inf/NaN
