@@ -8,7 +8,7 @@ import json, re, sys
 NAMES = [  # (substring of the kernel instance name, bench.py kernel name); first match wins
     ("stein_moment_kernel", "stein_partial"), ("stein_finalize_kernel", "stein_finalize"),
     ("mixture_eval_kernel<20, 1, true", "target_mixture_eval_grad"), ("mixture_eval_kernel<10, 1, true", "target_mixture_eval_grad"),
-    ("mixture_eval_mfma_kernel<50, 0, true", "mixture_eval_grad"), ("mixture_eval_mfma_kernel<50, 0, false", "mixture_eval"),
+    ("mixture_eval_mfma_ws_kernel<50, 0, true", "mixture_eval_grad"), ("mixture_eval_mfma_kernel<50, 0, true", "target_mixture_eval_grad"), ("mixture_eval_mfma_kernel<50, 0, false", "mixture_eval"),
     ("mixture_eval_kernel<20, 0, true", "mixture_eval_grad"), ("mixture_eval_kernel<20, 0, false", "mixture_eval"),
     ("mixture_eval_kernel<10, 0, true", "mixture_eval_grad"), ("mixture_eval_kernel<10, 0, false", "mixture_eval"),
     ("update_kl_fast_kernel", "update_kl"), ("combine_partials_kernel", "mixture_combine"),
