@@ -121,6 +121,21 @@ def test_student_t_target(ctx, rng, d, c, n):
     np.testing.assert_allclose(grad.numpy(), rg, rtol=2e-3, atol=2e-3)
 
 
+def test_student_t_target_workgroup_shared_blocks(ctx, rng):
+    """The harder Student-t mixture (20 components) at D = 32 with 2 100 samples: family switch of the workgroup-shared
+    matrix-core sweep (K >= 16, N >= 2048, gradient)."""
+    d, n = 32, 2100
+    t = otargets.make_stm_target(d, rng, harder_setting=True)
+    x = t.means[rng.integers(0, t.means.shape[0], n)] + rng.normal(size=(n, d)) * 2
+    from gmmvi_amd import _lib
+    packed, _ = ops().pack_components(ctx, ctx.asarray(t.means), ctx.asarray(t.chols), family=_lib.STUDENT_T, nu=2.0)
+    _, lp, grad = ops().mixture_eval(ctx, packed, ctx.asarray(t.log_weights), ctx.asarray(x), d, family=_lib.STUDENT_T,
+                                     nu=2.0, want_grad=True)
+    rlp, rg = t.log_density_and_grad(x.astype(np.float32).astype(np.float64))
+    np.testing.assert_allclose(lp.numpy(), rlp, rtol=1e-4, atol=5e-4)
+    np.testing.assert_allclose(grad.numpy(), rg, rtol=2e-3, atol=4e-3)
+
+
 def test_planar_target(ctx, rng):
     t = otargets.PlanarRobotTarget(10, 4)
     th = rng.normal(size=(500, 10)) * t.prior_stds
