@@ -389,6 +389,37 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_kernel(float nu, int K_
                         z[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[PK::fwd_index(mt, s)], b, z[t][mt], 0, 0, 0);
             }
         }
+        if constexpr (!GRAD && NTS == 4) {
+            // lane = sample (16 g + n of sub-tile g): after the cross-lane completion every lane group holds |z|^2 of all four
+            // sub-tiles; each lane keeps its own sub-tile's and runs ONE log-sum-exp step -- the four groups used to repeat the
+            // same four tails (the sweep without the gradient is bound by them, not by the matrix cores)
+            float qs = 0.f;
+#pragma unroll
+            for (int t = 0; t < NTS; ++t) {
+                float q = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q = fmaf(z[t][mt][r], z[t][mt][r], q);
+                q += __shfl_xor(q, 16);
+                q += __shfl_xor(q, 32);
+                qs = (g == t) ? q : qs;
+            }
+            float ld;
+            if (FAMILY == GMMVI_GAUSS) ld = fmaf(-0.5f, qs, cst);
+            else ld = cst - 0.5f * nud * log1pf(qs / nu);
+            const float a = ld + lw;
+            const float mn = fmaxf(m[0], a);
+            sv[0] = fmaf(sv[0], __expf(m[0] - mn), __expf(a - mn));
+            m[0] = mn;
+            if (dual) {
+                const float a2 = ld + lw2;
+                const float mn2 = fmaxf(m2[0], a2);
+                s2[0] = fmaf(s2[0], __expf(m2[0] - mn2), __expf(a2 - mn2));
+                m2[0] = mn2;
+            }
+            if (ld_out != nullptr && lane < n_here) ld_out[(size_t)k * N + n0 + lane] = ld;
+        } else {
 #pragma unroll
         for (int t = 0; t < NTS; ++t) {
             float q = 0.f;
@@ -427,6 +458,7 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_kernel(float nu, int K_
 #pragma unroll
             for (int t = 1; t < NTS; ++t) v = (g == t) ? ldv[t] : v;
             if (g < NTS && 16 * g + n16 < n_here) ld_out[(size_t)k * N + n0 + 16 * g + n16] = v;
+        }
         }
         if (GRAD) {
             // z -> wave-private image Zs[t][n][p(i)], p(i) = (i & 3) KSP + (i >> 2): lane (g, n) holds i = 16 mt + 4 g + r
@@ -472,7 +504,9 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_kernel(float nu, int K_
     float* sm_m = sm_merge;
     float* sm_s = sm_merge + nwaves * TS;
     float* sm_acc = sm_merge + 2 * nwaves * TS;
-    if (g == 0) {
+    if constexpr (!GRAD && NTS == 4) {
+        sm_m[wave * TS + lane] = m[0]; sm_s[wave * TS + lane] = sv[0];          // lane = sample
+    } else if (g == 0) {
 #pragma unroll
         for (int t = 0; t < NTS; ++t) { sm_m[wave * TS + 16 * t + n16] = m[t]; sm_s[wave * TS + 16 * t + n16] = sv[t]; }
     }
@@ -500,7 +534,9 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_kernel(float nu, int K_
     if (dual) {
         float* sm_m2 = sm_merge + (size_t)nwaves * TS * ((GRAD ? DP : 0) + 2) + (GRAD ? TS * ldx : 0);
         float* sm_s2 = sm_m2 + nwaves * TS;
-        if (g == 0) {
+        if constexpr (!GRAD && NTS == 4) {
+            sm_m2[wave * TS + lane] = m2[0]; sm_s2[wave * TS + lane] = s2[0];
+        } else if (g == 0) {
 #pragma unroll
             for (int t = 0; t < NTS; ++t) { sm_m2[wave * TS + 16 * t + n16] = m2[t]; sm_s2[wave * TS + 16 * t + n16] = s2[t]; }
         }
