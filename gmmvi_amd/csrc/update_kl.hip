@@ -774,6 +774,71 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
             }
             __syncthreads();
         }
+        if constexpr (DC >= 32 && NW >= 2) {
+            // 2 x 2 blocks, L = [[L11, 0], [L21, L22]] with H = 4 (D / 8) leading rows: X11 = L11^-1 on wave 0 and X22 = L22^-1 on
+            // wave 1 at the same time (lane = column; chains of H (H - 1) / 2 steps instead of D (D - 1) / 2), then
+            // X21 = -X22 (L21 X11) as two small products on all threads
+            constexpr int H = 4 * (DC / 8), H2 = DC - H;
+            float* Tm = La + DC * LA;                                   // [H2][H] scratch behind the aligned image
+            const int wv = __builtin_amdgcn_readfirstlane(t >> 6), ln = t & 63;
+            if (pd.nf_total > 0) {
+                for (int e = t; e < DC * DC; e += NTH) s.Mc[(e / DC) * ld + (e % DC)] = 0.f;      // upper right block stays zero
+                __syncthreads();
+                if (wv == 0 && ln < H) {
+                    float x[H];
+#pragma unroll
+                    for (int i = 0; i < H; ++i) {
+                        float lr[LA];
+#pragma unroll
+                        for (int q4 = 0; q4 <= i / 4; ++q4) {
+                            const float4 v4 = reinterpret_cast<const float4*>(La + i * LA)[q4];
+                            lr[4 * q4] = v4.x; lr[4 * q4 + 1] = v4.y; lr[4 * q4 + 2] = v4.z; lr[4 * q4 + 3] = v4.w;
+                        }
+                        float a = (i == ln) ? 1.f : 0.f;
+#pragma unroll
+                        for (int j = 0; j < i; ++j) a = fmaf(-lr[j], x[j], a);
+                        x[i] = (i >= ln) ? a / lr[i] : 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < H; ++i) s.Mc[i * ld + ln] = x[i];
+                } else if (wv == 1 && ln < H2) {
+                    float x[H2];
+#pragma unroll
+                    for (int i = 0; i < H2; ++i) {
+                        float lr[LA];
+#pragma unroll
+                        for (int q4 = H / 4; q4 <= (H + i) / 4; ++q4) {                   // H is a multiple of 4: aligned reads
+                            const float4 v4 = reinterpret_cast<const float4*>(La + (H + i) * LA)[q4];
+                            lr[4 * q4] = v4.x; lr[4 * q4 + 1] = v4.y; lr[4 * q4 + 2] = v4.z; lr[4 * q4 + 3] = v4.w;
+                        }
+                        float a = (i == ln) ? 1.f : 0.f;
+#pragma unroll
+                        for (int j = 0; j < i; ++j) a = fmaf(-lr[H + j], x[j], a);
+                        x[i] = (i >= ln) ? a / lr[H + i] : 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < H2; ++i) s.Mc[(H + i) * ld + H + ln] = x[i];
+                }
+                __syncthreads();
+                // T = L21 X11  ([H2][H]; X11[m][j] = 0 for m < j)
+                for (int o = t; o < H2 * H; o += NTH) {
+                    const int i = o / H, j = o - i * H;
+                    float a = 0.f;
+#pragma unroll
+                    for (int m2 = 0; m2 < H; ++m2) a = fmaf(La[(H + i) * LA + m2], s.Mc[m2 * ld + j], a);
+                    Tm[o] = a;
+                }
+                __syncthreads();
+                // X21 = -X22 T  (X22[i][m] = 0 for m > i)
+                for (int o = t; o < H2 * H; o += NTH) {
+                    const int i = o / H, j = o - i * H;
+                    float a = 0.f;
+#pragma unroll
+                    for (int m2 = 0; m2 < H2; ++m2) a = fmaf(s.Mc[(H + i) * ld + H + m2], Tm[m2 * H + j], a);
+                    s.Mc[(H + i) * ld + j] = -a;
+                }
+            }
+        } else
         if (pd.nf_total > 0 && t < D) {
             if constexpr (DC > 0) {
                 float x[DC > 0 ? DC : 1];
