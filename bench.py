@@ -330,6 +330,8 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved / roof_peak, "traffic": traffic,
                      "avg_us": kernels[roof_name]["avg_us"], "flops_per_launch": fl,
                      "flops_executed_per_launch": launch_flops(roof_name, kernel_flops_executed),
+                     "selection": "the FLOP-heaviest launch of the step; kernel_roofline prices every FLOP-carrying kernel the same "
+                                  "way and dominant_kernel names the one with the largest share of the step time",
                      "note": "achieved = SURVEY.md 8(d) algorithmic FLOPs of the launch / its mean HIP-event duration; peak = "
                              "fp32 vector == f32 MFMA rate. The Stein kernel (moment form) executes fewer FLOPs than the "
                              "algorithmic figure (flops_executed_per_launch; kernel_roofline.frac_executed). Algorithmic HBM "
