@@ -45,6 +45,13 @@ WORKLOADS = {
     "d32": ("gmm", 32, 100, 100), "d40": ("gmm", 40, 100, 100), "d63": ("gmm", 63, 100, 100),
     "tiny": ("stm", 4, 4, 16),         # host-overhead probe (kernels are empty; time = launch path)
 }
+# Strong-scaling workloads: the BASELINE configurations that NAME a GPU count, as stated -- K is the TOTAL number of
+# components, split evenly over the ranks (K % gpus == 0), the samples per component do not change with the rank count.
+STRONG_WORKLOADS = {
+    "c4_sharded": ("planar", 10, 200, 100),      # BASELINE configs[3]: planar-4, K = 200 over 4 GPUs = 50 / GPU, N = 20 000
+    "c5_sharded": ("gauss300", 300, 512, 39),    # BASELINE configs[4]: D = 300, K = 512 over 8 GPUs = 64 / GPU, N = 19 968
+}
+WORKLOADS.update(STRONG_WORKLOADS)
 
 
 def kernel_flops(name, n, k, d):
@@ -79,8 +86,13 @@ def spec(workload, n_gpus, seed=0):
     from oracle import targets as otargets
     kind, d, k_per_gpu, s1 = WORKLOADS[workload][:4]
     estimator = (WORKLOADS[workload] + ("Stein",))[4]
-    k_total = k_per_gpu * n_gpus
-    s = int(np.ceil(s1 / n_gpus))
+    if workload in STRONG_WORKLOADS:
+        if k_per_gpu % n_gpus:
+            raise SystemExit(f"bench.py: workload {workload} splits K = {k_per_gpu} components evenly; --gpus {n_gpus} does not divide it")
+        k_total, s = k_per_gpu, s1
+    else:
+        k_total = k_per_gpu * n_gpus
+        s = int(np.ceil(s1 / n_gpus))
     rng = np.random.default_rng(seed)
     if kind == "stm":
         ot = otargets.make_stm_target(d, rng)
@@ -174,31 +186,46 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def spawn_ranks(n_ranks, argv, child=None, timeout=None):
+def spawn_ranks(n_ranks, argv, child=None, timeout=900.0, log_dir=None):
     """Start ``n_ranks`` fresh processes of this script (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
-    MASTER_PORT in their environment, as torch.distributed.run would set them), wait for all, relay rank 0's stdout.
+    MASTER_PORT in their environment, as torch.distributed.run would set them) and relay rank 0's stdout.
     The calling process has not touched the GPU and never does (children are new processes, nothing is re-exec'ed).
-    -> exit code: 0 when every rank exited 0, else the first non-zero one (the others are terminated)."""
+    ALL children are polled: the first rank that exits non-zero ends the job -- the others (possibly parked inside an RCCL
+    call that can no longer complete) are terminated and that rank's exit code is returned, its stderr relayed; ``timeout``
+    seconds without completion return 124.  Every rank writes stdout / stderr to its own file (rank{r}.out / rank{r}.err in
+    ``log_dir``, default a fresh temporary directory), so a failing rank's message is not lost among the others.
+    -> exit code: 0 when every rank exited 0."""
     import subprocess
+    import tempfile
     cmd = [sys.executable, child or os.path.abspath(__file__)] + list(argv)
     port = _free_port()
-    procs = []
+    log_dir = log_dir or tempfile.mkdtemp(prefix="gmmvi_bench_ranks_")
+    procs, files = [], []
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    rc = 0
+        fo = open(os.path.join(log_dir, f"rank{r}.out"), "wb")
+        fe = open(os.path.join(log_dir, f"rank{r}.err"), "wb")
+        files += [fo, fe]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=fo, stderr=fe))
+    rc, failed = 0, None
     t_end = None if timeout is None else time.time() + timeout
-    out0 = b""
     try:
-        # rank 0's pipe is drained first (one JSON line: no deadlock); then every rank is waited for
-        out0 = procs[0].communicate(timeout=None if t_end is None else max(1.0, t_end - time.time()))[0]
-        for p in procs:
-            code = p.wait(timeout=None if t_end is None else max(1.0, t_end - time.time()))
-            if code != 0 and rc == 0:
-                rc = code
-    except subprocess.TimeoutExpired:
-        rc = 124
+        pending = set(range(n_ranks))
+        while pending and rc == 0:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc, failed = code, r
+                    break
+            if pending and rc == 0:
+                if t_end is not None and time.time() > t_end:
+                    rc = 124
+                    break
+                time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
@@ -208,11 +235,23 @@ def spawn_ranks(n_ranks, argv, child=None, timeout=None):
                 p.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p.kill()
+                p.wait()
+        for f in files:
+            f.close()
+
+    def read(r, ext):
+        with open(os.path.join(log_dir, f"rank{r}.{ext}"), "rb") as f:
+            return f.read().decode(errors="replace")
     if rc == 0:
-        sys.stdout.write(out0.decode())
+        sys.stdout.write(read(0, "out"))
         sys.stdout.flush()
     else:
-        sys.stderr.write(f"bench.py: a rank failed (exit code {rc}); rank 0 printed: {out0.decode()!r}\n")
+        what = f"timed out after {timeout:.0f} s" if failed is None else f"rank {failed} exited with code {rc}"
+        sys.stderr.write(f"bench.py: {what}; the other ranks were terminated; per-rank logs in {log_dir}\n")
+        for r in ([failed] if failed is not None else range(n_ranks)):
+            tail = read(r, "err")[-4000:]
+            if tail:
+                sys.stderr.write(f"---- rank {r} stderr (tail) ----\n{tail}\n")
     return rc
 
 
@@ -321,7 +360,7 @@ def main():
         "metric": "samples_components_per_sec", "value": n_tot * k_tot / (elapsed / args.steps),
         "unit": "samples*components/s", "train_iter_per_sec": args.steps / elapsed,
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if roof_name == "more_gram" else "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if args.workload in STRONG_WORKLOADS else "weak", "vs_baseline": None, "dtype": "f64" if roof_name == "more_gram" else "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {w['kind']} target D={d}, K={k_tot} components "
                                f"({k_local}/GPU), {w['s']} samples/component, N={n_tot} samples/iter, SAMTRON "
                                f"({w['cfg']['ng_estimator_type']}, fixed K, reuse ratio 0, KL trust regions, improvement-based stepsizes)",

@@ -277,6 +277,241 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// mixture_eval, lockstep scalar-fed form (padded D <= 24)
+// ---------------------------------------------------------------------------------------------------------------
+// The kernel above is a chain of scalar-load round trips: every wave of a workgroup walks its OWN components, the blocks of
+// a chunk (34 x 1.7 KB at the north star) do not stay in the 16 KB scalar cache, the ~22 `s_load` of a component pass each
+// go to the L2 and -- scalar loads return out of order -- each is waited for with lgkmcnt(0): ~22 dependent L2 round trips per
+// (wave, component).  Here the waves of a workgroup are arranged as T sample tiles x G component streams and all walk the
+// chunk in the same order: at any time the workgroup touches G blocks, which therefore stay in the scalar cache for the
+// T waves that share them; only the row-packed triangle is read (forward substitution in dot form over the rows, backward
+// substitution in axpy form over the same rows, descending: 0.9 KB instead of 1.7 KB a block); and the lines of the blocks
+// that come next are touched ahead (`s_load_dword` into a sink register) by one extra FEEDER wave per workgroup that paces
+// itself on the progress counters of the compute waves (or, without it, by every wave for its own next block), so that the
+// L2 latency is paid once per block and off the compute waves.  The G streams of a tile are merged through LDS as above.
+// The block through a CONSTANT-address-space pointer: uniform loads from it are scalar loads whatever else the loop contains
+// (the `asm volatile` touches below count as possible writers of global memory, which turns uniform GLOBAL loads into
+// per-lane vector loads); the blocks are not written during the launch.
+typedef float ls_f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) ls_f32x4* ls_cf4p;
+struct PackRefConst {
+    ls_cf4p p;
+    __device__ __forceinline__ float operator[](int idx) const {
+        const ls_f32x4 v = p[idx >> 2];
+        return v[idx & 3];
+    }
+};
+
+template <int DP>
+__device__ __forceinline__ void ls_touch_block(const float* blk, int& sink) {
+    using PK = Pack<DP>;
+    constexpr int BYTES = (2 * DP + PK::T) * 4;         // mu | 1 / diag | strict lower triangle by rows
+    constexpr int LINES = BYTES / 64 + 2;               // blocks are 16-byte aligned only: a partial line at either end
+#pragma unroll
+    for (int l = 0; l < LINES; ++l)
+        asm volatile("s_load_dword %0, %1, %2" : "+s"(sink) : "s"(blk), "n"(l * 64 < BYTES ? l * 64 : BYTES - 4));
+    asm volatile("s_load_dword %0, %1, %2" : "+s"(sink) : "s"(blk), "n"(PK::CONST * 4));
+}
+// the sink register may be reused only after the touches have landed
+__device__ __forceinline__ void ls_touch_release(int& sink) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink)); }
+
+template <int DP, int FAMILY, bool GRAD>
+__global__ __launch_bounds__(1024) void mixture_eval_ls_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
+                                                               const float* __restrict__ logw, const float* __restrict__ X,
+                                                               int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
+                                                               float* __restrict__ grad_out, const float* __restrict__ logw2,
+                                                               float* __restrict__ lp2_out, CombineJob carried, int T, int G,
+                                                               int feeder, int ahead) {
+    using PK = Pack<DP>;
+    extern __shared__ __align__(16) float sm[];
+    __shared__ int prog[16];                           // components done per compute wave (read by the feeder)
+    if (combine_carried(carried)) return;              // workgroups past the sample tiles: the merge of the previous sweep
+    const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
+    const int k_lo = blockIdx.y * kchunk;
+    const int K = min(K_total, k_lo + kchunk);
+    if (gridDim.y > 1) {
+        if (lp_out) lp_out += (size_t)blockIdx.y * N;
+        if (lp2_out) lp2_out += (size_t)blockIdx.y * N;
+        if (GRAD && grad_out) grad_out += (size_t)blockIdx.y * N * D;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = T * G;                               // compute waves; wave W (if any) is the feeder
+    const bool is_feeder = wave >= W;
+    const int t = is_feeder ? 0 : wave / G, g = is_feeder ? 0 : wave - t * G;
+    const int tile = blockIdx.x * T + t;
+    const int n0 = tile * 64;
+    const int n_here = is_feeder ? 0 : max(0, min(64, N - n0));
+    const int n = n0 + lane;
+    const bool valid = lane < n_here;
+    const int steps = (K - k_lo + G - 1) / G;          // component passes of a stream
+    if (threadIdx.x < 16) prog[threadIdx.x] = 0x7fffffff;
+    __syncthreads();
+    if (!is_feeder && lane == 0) prog[wave] = n_here > 0 ? 0 : 0x7fffffff;
+    __syncthreads();
+
+    float m = -3.0e38f, s = 0.f;
+    float m2 = -3.0e38f, s2 = 0.f;                      // second mixture over the same components (logw2), optional
+    const bool dual = logw2 != nullptr;
+    float acc[GRAD ? DP : 1];
+    if (GRAD) {
+#pragma unroll
+        for (int i = 0; i < DP; ++i) acc[i] = 0.f;
+    }
+    if (is_feeder) {
+        int sink = 0;
+        for (int st = 0; st < steps; ++st) {
+            // stay at most `ahead` passes in front of the slowest compute wave (its counter only grows; a finished or idle
+            // wave reads as infinity, so this loop ends when the compute waves do)
+            while (true) {
+                int p = lane < 16 ? ((volatile int*)prog)[lane] : 0x7fffffff;
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) p = min(p, __shfl_xor(p, o));
+                if (__builtin_amdgcn_readfirstlane(p) >= st - ahead) break;       // (no p + ahead: idle waves read as INT_MAX)
+                __builtin_amdgcn_s_sleep(4);
+            }
+            for (int gg = 0; gg < G; ++gg) {
+                const int k = k_lo + st * G + gg;
+                if (k < K) ls_touch_block<DP>(packed + (size_t)k * PK::STRIDE, sink);
+            }
+            ls_touch_release(sink);
+        }
+    } else if (n_here > 0) {
+        // ---- the lane's sample row: whole 16- / 8-byte pieces where the row allows it (consecutive lanes walk consecutive
+        // rows: the loads of a row share cache lines, the G waves of a tile hit in L1) -------------------------------------
+        float x[DP];
+        const int nr = min(n, N - 1);
+        if (DP % 4 == 0 && D == DP && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+            const float4* xrow = reinterpret_cast<const float4*>(X + (size_t)nr * D);
+#pragma unroll
+            for (int q4 = 0; q4 < DP / 4; ++q4) {
+                const float4 v4 = xrow[q4];
+                x[4 * q4] = v4.x; x[4 * q4 + 1] = v4.y; x[4 * q4 + 2] = v4.z; x[4 * q4 + 3] = v4.w;
+            }
+        } else if (DP % 2 == 0 && D == DP && (reinterpret_cast<uintptr_t>(X) & 7) == 0) {
+            const float2* xrow = reinterpret_cast<const float2*>(X + (size_t)nr * D);
+#pragma unroll
+            for (int q2 = 0; q2 < DP / 2; ++q2) {
+                const float2 v2 = xrow[q2];
+                x[2 * q2] = v2.x; x[2 * q2 + 1] = v2.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < DP; ++i) x[i] = i < D ? X[(size_t)nr * D + i] : 0.f;
+        }
+        if (!valid) {
+#pragma unroll
+            for (int i = 0; i < DP; ++i) x[i] = 0.f;
+        }
+        const float nud = nu + (float)D;
+        int sink = 0;
+        if (!feeder && k_lo + g < K) ls_touch_block<DP>(packed + (size_t)(k_lo + g) * PK::STRIDE, sink);
+        int st = 0;
+        for (int k = k_lo + g; k < K; k += G, ++st) {
+            const float* blk = packed + (size_t)k * PK::STRIDE;
+            if (!feeder && k + G < K) ls_touch_block<DP>(blk + (size_t)G * PK::STRIDE, sink);
+            PackRefConst P;
+            P.p = (ls_cf4p)(uintptr_t)blk;
+            const float lw = ((const __attribute__((address_space(4))) float*)(uintptr_t)logw)[k];
+            // z = L^-1 (x - mu) by the rows of L (dot form), q = |z|^2
+            float z[DP], q = 0.f;
+#pragma unroll
+            for (int i = 0; i < DP; ++i) {
+                float tt = x[i] - P[PK::MU + i];
+#pragma unroll
+                for (int j = 0; j < i; ++j) tt = fmaf(-P[PK::LROW + PK::rowofs(i) + j], z[j], tt);
+                z[i] = tt * P[PK::RD + i];
+                q = fmaf(z[i], z[i], q);
+            }
+            float ld, coef;
+            if (FAMILY == GMMVI_GAUSS) {
+                ld = fmaf(-0.5f, q, P[PK::CONST]);
+                coef = -1.f;
+            } else {
+                ld = P[PK::CONST] - 0.5f * nud * log1pf(q / nu);
+                coef = -nud / (nu + q);
+            }
+            if (ld_out != nullptr && valid) ld_out[(size_t)k * N + n] = ld;
+            const float a = ld + lw;
+            const float mn = fmaxf(m, a);
+            const float sc = __expf(m - mn);
+            const float e = __expf(a - mn);
+            s = fmaf(s, sc, e);
+            m = mn;
+            if (dual) {
+                const float a2 = ld + ((const __attribute__((address_space(4))) float*)(uintptr_t)logw2)[k];
+                const float mn2 = fmaxf(m2, a2);
+                s2 = fmaf(s2, __expf(m2 - mn2), __expf(a2 - mn2));
+                m2 = mn2;
+            }
+            if (GRAD) {
+                // y = L^-T z in place, by the ROWS of L in descending order: y_i = z_i / L_ii, then z_j -= L_ij y_i (j < i)
+#pragma unroll
+                for (int i = DP - 1; i >= 0; --i) {
+                    const float yi = z[i] * P[PK::RD + i];
+                    z[i] = yi;
+#pragma unroll
+                    for (int j = 0; j < i; ++j) z[j] = fmaf(-P[PK::LROW + PK::rowofs(i) + j], yi, z[j]);
+                }
+                const float ec = e * coef;
+#pragma unroll
+                for (int i = 0; i < DP; ++i) acc[i] = fmaf(acc[i], sc, ec * z[i]);
+            }
+            if (!feeder) ls_touch_release(sink);
+            if (lane == 0) ((volatile int*)prog)[wave] = st + 1;
+        }
+        if (lane == 0) ((volatile int*)prog)[wave] = 0x7fffffff;
+    }
+    if (lp_out == nullptr && !GRAD) return;
+
+    // merge the G streams of every tile: sm_m[w][lane], sm_s[w][lane], sm_acc[w][i][lane]   (w = t G + g)
+    const int ldx = D | 1;
+    float* sm_m = sm;
+    float* sm_s = sm + W * 64;
+    float* sm_acc = sm + 2 * W * 64;
+    float* sm_m2 = sm_acc + (GRAD ? (size_t)W * DP * 64 + (size_t)T * 64 * ldx : 0);
+    float* sm_s2 = sm_m2 + W * 64;
+    if (!is_feeder) {
+        sm_m[wave * 64 + lane] = m;
+        sm_s[wave * 64 + lane] = s;
+        if (dual) { sm_m2[wave * 64 + lane] = m2; sm_s2[wave * 64 + lane] = s2; }
+        if (GRAD) {
+#pragma unroll
+            for (int i = 0; i < DP; ++i) sm_acc[(wave * DP + i) * 64 + lane] = acc[i];
+        }
+    }
+    __syncthreads();
+    float M = -3.0e38f, S = 0.f;
+    if (!is_feeder) {
+        for (int w = t * G; w < t * G + G; ++w) M = fmaxf(M, sm_m[w * 64 + lane]);
+        for (int w = t * G; w < t * G + G; ++w) S += sm_s[w * 64 + lane] * __expf(sm_m[w * 64 + lane] - M);
+        if (g == 0 && valid && lp_out != nullptr) lp_out[n] = M + __logf(S);
+        if (dual && g == (G > 1 ? 1 : 0) && valid && lp2_out != nullptr) {
+            float M2 = -3.0e38f, S2 = 0.f;
+            for (int w = t * G; w < t * G + G; ++w) M2 = fmaxf(M2, sm_m2[w * 64 + lane]);
+            for (int w = t * G; w < t * G + G; ++w) S2 += sm_s2[w * 64 + lane] * __expf(sm_m2[w * 64 + lane] - M2);
+            lp2_out[n] = M2 + __logf(S2);
+        }
+    }
+    if (GRAD && grad_out != nullptr) {
+        float* outt = sm_acc + (size_t)W * DP * 64 + (size_t)t * 64 * ldx;
+        if (!is_feeder) {
+            const float inv = 1.f / S;
+            // stream g reduces dimensions g, g + G, ...; results go to the tile's [64][ldx] image and leave coalesced
+            for (int i = g; i < D; i += G) {
+                float gsum = 0.f;
+                for (int w = t * G; w < t * G + G; ++w) gsum += sm_acc[(w * DP + i) * 64 + lane] * __expf(sm_m[w * 64 + lane] - M);
+                outt[lane * ldx + i] = gsum * inv;
+            }
+        }
+        __syncthreads();
+        if (!is_feeder)
+            for (int e = g * 64 + lane; e < n_here * D; e += 64 * G)
+                grad_out[(size_t)n0 * D + e] = outt[(e / D) * ldx + (e % D)];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // mixture_eval on the matrix cores
 // ---------------------------------------------------------------------------------------------------------------
 // z = L^-1 (x - mu) and y = L^-T z as dense contractions with the explicit inverse (operand fragments in the packed block,
@@ -956,6 +1191,89 @@ static int launch_mixture_eval_mfma_ws(gmmvi_ctx* ctx, int family, float nu, int
     return GMMVI_OK;
 }
 
+// lockstep scalar-fed form: T sample tiles x G component streams (+ the feeder wave) per workgroup, ky component chunks
+template <int DP>
+static int launch_mixture_eval_ls(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
+                                  const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
+                                  const float* logw2, float* lp2) {
+    const bool want_grad = grad != nullptr;
+    const bool want_merge = want_grad || lp != nullptr;
+    static const int env_t = getenv("GMMVI_LS_T") ? atoi(getenv("GMMVI_LS_T")) : 0;
+    static const int env_g = getenv("GMMVI_LS_G") ? atoi(getenv("GMMVI_LS_G")) : 0;
+    static const int env_ky = getenv("GMMVI_LS_KY") ? atoi(getenv("GMMVI_LS_KY")) : 0;
+    static const int env_feeder = getenv("GMMVI_LS_FEEDER") ? atoi(getenv("GMMVI_LS_FEEDER")) : 1;
+    static const int env_ahead = getenv("GMMVI_LS_AHEAD") ? atoi(getenv("GMMVI_LS_AHEAD")) : 2;
+    static const int env_wgs = getenv("GMMVI_LS_WGS_PER_CU") ? atoi(getenv("GMMVI_LS_WGS_PER_CU")) : 2;
+    const int tiles = (N + 63) / 64;
+    int T = env_t > 0 ? env_t : 4, G = env_g > 0 ? env_g : 2;
+    if (T > tiles) T = tiles;
+    if (G > K) G = K;
+    if (T * G > 16) T = 16 / G > 0 ? 16 / G : 1;
+    const int tgroups = (tiles + T - 1) / T;
+    // component chunks over blockIdx.y so that ~env_wgs workgroups per CU are in flight; every stream keeps >= 2 passes
+    int ky = 1;
+    if (env_ky > 0) ky = env_ky;
+    else if ((long)tgroups < (long)env_wgs * ctx->num_cus) ky = (int)(((long)env_wgs * ctx->num_cus + tgroups / 2) / tgroups);
+    if (ky > K / (2 * G)) ky = K / (2 * G);
+    if (ky < 1) ky = 1;
+    const int kchunk = (K + ky - 1) / ky;
+    ky = (K + kchunk - 1) / kchunk;
+    if (G > kchunk) G = kchunk;
+    const int W = T * G;
+    const int feeder = (env_feeder && kchunk > G) ? 1 : 0;        // a single pass per stream has nothing to run ahead of
+    const int ldx = D | 1;
+    const size_t shmem = ((size_t)W * 64 * (2 + (want_grad ? DP : 0)) + (want_grad ? (size_t)T * 64 * ldx : 0) +
+                          (logw2 ? (size_t)W * 128 : 0)) * sizeof(float);
+    float* lp_k = lp;
+    float* grad_k = grad;
+    float* lp2_k = lp2;
+    const bool defer = ctx->defer_combine && ky > 1 && want_merge;
+    if (defer) {
+        int rc = gmmvi_flush_pending_combine(ctx);
+        if (rc != GMMVI_OK) return rc;
+    }
+    if (ky > 1 && want_merge) {
+        size_t need = ((size_t)ky * N * (logw2 ? 2 : 1) + (want_grad ? (size_t)ky * N * D : 0)) * sizeof(float);
+        int rc = defer ? gmmvi_defer_reserve(ctx, need) : gmmvi_ws_reserve(ctx, need);
+        if (rc != GMMVI_OK) return rc;
+        lp_k = (float*)(defer ? ctx->defer_ws : ctx->ws);
+        lp2_k = logw2 ? lp_k + (size_t)ky * N : nullptr;
+        grad_k = want_grad ? lp_k + (size_t)ky * N * (logw2 ? 2 : 1) : nullptr;
+    }
+    const int threads = 64 * (W + feeder);
+    const CombineJob carried = gmmvi_take_pending_combine(ctx, threads, tgroups);
+    dim3 grid(tgroups + carried.blocks, ky), block(threads);
+    {
+        GMMVI_PROF_UNITS(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval", (double)N * K);
+#define GMMVI_LAUNCH_LS(FAM, GR)                                                                                    \
+    do {                                                                                                            \
+        if (shmem > 64 * 1024)                                                                                      \
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_ls_kernel<DP, FAM, GR>,              \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
+        hipLaunchKernelGGL((mixture_eval_ls_kernel<DP, FAM, GR>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
+                           logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried, T, G, feeder, env_ahead);             \
+    } while (0)
+        if (family == GMMVI_GAUSS) {
+            if (want_grad) GMMVI_LAUNCH_LS(GMMVI_GAUSS, true); else GMMVI_LAUNCH_LS(GMMVI_GAUSS, false);
+        } else {
+            if (want_grad) GMMVI_LAUNCH_LS(GMMVI_STUDENT_T, true); else GMMVI_LAUNCH_LS(GMMVI_STUDENT_T, false);
+        }
+#undef GMMVI_LAUNCH_LS
+    }
+    GMMVI_LAUNCH_CHECK(ctx);
+    if (defer) {
+        CombineJob& j = ctx->pending;
+        j.R = ky; j.N = N; j.D = D;
+        j.lp_parts = lp_k; j.grad_parts = grad_k; j.lp2_parts = lp2_k;
+        j.lp_out = lp; j.grad_out = grad; j.lp2_out = lp2_k ? lp2 : nullptr;
+    } else if (ky > 1 && want_merge) {
+        GMMVI_PROF(ctx, "mixture_combine");
+        int rc = gmmvi_combine_partials_internal(ctx, ky, N, D, lp_k, grad_k, lp, grad, lp2_k, lp2);
+        if (rc != GMMVI_OK) return rc;
+    }
+    return GMMVI_OK;
+}
+
 template <int DP>
 static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
                                const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
@@ -979,6 +1297,8 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         }
         return launch_mixture_eval_mfma<DP, 4>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
     } else {
+    static const int env_ls = getenv("GMMVI_LS") ? atoi(getenv("GMMVI_LS")) : 1;
+    if (env_ls) return launch_mixture_eval_ls<DP>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
     const bool want_grad = grad != nullptr;
     const bool want_merge = want_grad || lp != nullptr;
     static const int env_nw = getenv("GMMVI_ME_NW") ? atoi(getenv("GMMVI_ME_NW")) : 0;

@@ -36,7 +36,22 @@ static int arena_reserve(gmmvi_ctx* ctx, size_t floats) {
         if (rc__ != GMMVI_OK) return rc__; \
     } while (0)
 
+static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p);
+
 extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) {
+    GMMVI_ARG_CHECK(ctx, ctx != nullptr);
+    // a deferred merge points into defer_ws and the arena: none may survive this call on an error exit (a later public call
+    // on the context would carry or flush it into memory arena_reserve may have freed), none is inherited at entry
+    int rc = gmmvi_flush_pending_combine(ctx);
+    if (rc == GMMVI_OK) rc = train_iter_samtron_body(ctx, p);
+    if (rc != GMMVI_OK) {
+        ctx->pending = CombineJob();
+        ctx->defer_combine = false;
+    }
+    return rc;
+}
+
+static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) {
     GMMVI_ARG_CHECK(ctx, p != nullptr);
     const int K = p->K, D = p->D, N = p->N;
     GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D < GMMVI_MAX_DIM && N >= 1);

@@ -31,6 +31,7 @@
 // pivot marks the component's estimate as NaN, which the component updaters treat as a rejected update.
 #include "common.h"
 #include "subst.h"
+#include "blocked.h"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -857,6 +858,10 @@ extern "C" int gmmvi_more(gmmvi_ctx* ctx, int K, int D, const float* packed_dev,
                           const float* l2_dev, float* H_neg_out_dev, float* g_neg_out_dev) {
     GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && N >= 1);
     GMMVI_ARG_CHECK(ctx, D < GMMVI_MAX_DIM);
+    // the kernels read the register-path block layout (Pack<DP>); dimensions on the blocked path hand over
+    // [mu | log-normaliser | dense L^-1] blocks of another stride
+    if (gmmvi_is_blocked_dim(D))
+        return gmmvi_fail(ctx, GMMVI_ERR_ARG, "gmmvi_more: no MORE route for dimensions on the blocked path (D > GMMVI_BLOCKED_ABOVE)");
     GMMVI_ARG_CHECK(ctx, packed_dev && chols_dev && X_dev && logq_dev && tlp_dev && l2_dev && H_neg_out_dev && g_neg_out_dev);
     if (flags & GMMVI_OWN_SAMPLES_ONLY) GMMVI_ARG_CHECK(ctx, mapping_dev != nullptr);
     else GMMVI_ARG_CHECK(ctx, ld_dev && bg_dev);

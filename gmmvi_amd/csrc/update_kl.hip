@@ -951,7 +951,9 @@ extern "C" int gmmvi_update_components_kl(gmmvi_ctx* ctx, int K, int D, float* m
 
 // C++ linkage (common.h), single-call iteration: the Stein estimate is finished from its partial slab and the components are
 // updated -- in ONE launch where the update kernel carries the prologue (the unrolled single-wave instances D = 4 / 10 / 20),
-// by the stand-alone finalize launch followed by the update otherwise.  H_neg / g_neg receive the estimate either way.
+// by the stand-alone finalize launch followed by the update otherwise.  H_neg / g_neg receive the estimate on the explicit routes
+// (plain importance weights, GMMVI_EXPLICIT_ESTIMATE, the finalize launch) ONLY: on the default direct route (self-normalised
+// weights, D = 4 / 10 / 20 / 32 / 40 / 50) the kernel whitens the moment sums itself and never writes them.
 int gmmvi_update_components_kl_from_slab(gmmvi_ctx* ctx, int K, int D, const SteinSlab& slab, int N, int stein_flags,
                                          const float* packed_old_dev, float* H_neg_dev, float* g_neg_dev, float* means_dev,
                                          float* chols_dev, const float* stepsizes_dev, float temperature, float l2_init,

@@ -72,7 +72,7 @@ class SteinNgEstimator(NgEstimator):
 class MoreNgEstimator(NgEstimator):
     """ng_estimator.py:266-376 (MORE, codename letter "Z"): importance-weighted quadratic ridge regression of the
     rewards on the samples whitened by each component (least_squares.py:126-191), as one f32-MFMA Gram contraction
-    and one fp64 Cholesky solve per component (csrc/more.hip): register-resident up to D = 21, tiled above (D <= 63)."""
+    and one fp64 Cholesky solve per component (csrc/more.hip): register-resident up to D = 21, tiled above (D <= 50 by default: the register-path dimensions)."""
 
     def __init__(self, temperature, model, only_use_own_samples: bool, initial_l2_regularizer: float,
                  use_self_normalized_importance_weights: bool):
@@ -84,8 +84,10 @@ class MoreNgEstimator(NgEstimator):
         if model.diagonal_covs:
             raise ValueError("MoreNgEstimator needs a full-covariance model (the reference's QuadFunc whitening, "
                              "least_squares.py:126-191, has no diagonal branch)")
-        if model.num_dimensions >= 64:
-            raise ValueError("MoreNgEstimator: the HIP kernels support D <= 63 (DESIGN.md section 7)")
+        from ... import _lib
+        if model.num_dimensions >= _lib.MAX_DIM or model.num_dimensions > _lib.blocked_above():
+            raise ValueError(f"MoreNgEstimator: the HIP kernels support D <= {min(_lib.MAX_DIM - 1, _lib.blocked_above())} "
+                             "(the register-path dimensions; GMMVI_BLOCKED_ABOVE moves the limit up to 63: DESIGN.md section 7)")
         self.last_model_densities = None
 
     def get_expected_hessian_and_grad(self, samples, mapping, background_densities, target_lnpdfs,

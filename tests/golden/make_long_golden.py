@@ -1,0 +1,83 @@
+"""Generates the LONG-HORIZON fixtures tests/golden/long_*.npz from the fp64 CPU oracle (the reference cannot run here and
+ships no vectors: SURVEY.md 8c; these files are oracle output, data only -- "parity unpinned" upstream as DESIGN.md 1 says).
+
+  long_c2.npz   BASELINE configs[1] shape: 20-D Student-t mixture target, K = 50 fixed, 100 samples / component, 120 iterations
+  long_c1.npz   BASELINE configs[0] = examples/5_samtron_20D_student-T.py:13-30: K = 45 adaptive (add every 60, delete after
+                100 iterations), 200 samples / component, reuse ratio 0, 260 iterations (adds at 60/120/180/240, deletions
+                from iteration 101)
+  pair_c5.npz   the per-GPU shard shape of BASELINE configs[4] that bench.py --workload c5 composes, cut to K = 8 components:
+                single-Gaussian target D = 300 (gmm.py:148-162 law), 312 samples / component, 2 iterations
+
+Stored per case: the INPUTS (target parameters, initial mixture, seeds, hyper-parameters are in tests/helpers.py LONG_CASES)
+and, every `every` iterations, the oracle's ELBO on a FIXED evaluation set of 20 000 Philox draws (gmmvi_runner.py:131-133
+definition), the standard error of that estimate, the number of components; per iteration the number of components and the
+count of accepted component updates; at the end the mixture.
+
+Run:  python tests/golden/make_long_golden.py [c2 c1 pair_c5]      (about 15 minutes on 8 cores)
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from helpers import LONG_CASES, make_long_oracle, score_elbo, samtron_config, make_oracle  # noqa: E402
+
+
+def run_long(case, dtype=np.float64, verbose=True):
+    o = make_long_oracle(case, dtype=dtype)
+    t = o.target
+    out = {"init_means": o.model.means.astype(np.float32), "init_covs": o.model.model.covs.astype(np.float32),
+           "target_weights": t.weights, "target_means": t.means, "target_covs": t.covs}
+    cp_it, cp_elbo, cp_sigma, cp_k, k_trace, n_success = [], [], [], [], [], []
+    t0 = time.time()
+    for it in range(1, case["iters"] + 1):
+        info = o.train_iter()
+        k_trace.append(o.model.num_components)
+        n_success.append(int(np.sum(info["success"])))
+        if it % case["every"] == 0:
+            m = o.model.model
+            e, sg = score_elbo(t, m.log_weights, m.means, m.chol_cov)
+            cp_it.append(it); cp_elbo.append(e); cp_sigma.append(sg); cp_k.append(m.num_components)
+            if verbose:
+                print(f"  it {it:4d}  K {m.num_components:3d}  elbo {e:12.4f} +- {sg:.4f}  ({time.time() - t0:.0f} s)", flush=True)
+    m = o.model.model
+    out.update(checkpoint_iters=np.array(cp_it), checkpoint_elbo=np.array(cp_elbo), checkpoint_sigma=np.array(cp_sigma),
+               checkpoint_k=np.array(cp_k), k_trace=np.array(k_trace), n_success=np.array(n_success),
+               final_log_weights=m.log_weights.copy(), final_means=m.means.copy(), final_chols=m.chol_cov.copy(),
+               final_component_ids=np.array(o.model.unique_component_ids))
+    return out
+
+
+def run_pair_c5():
+    """D = 300, K = 8, S = 312: the state after each of 2 iterations (what tests/helpers.run_pair compares)."""
+    cfg = samtron_config(312, initial_stepsize=0.1)
+    o = make_oracle("gauss", 300, 8, 312, 7, cfg)
+    t = o.target
+    out = {"init_means": o.model.means.astype(np.float32), "init_covs": o.model.model.covs.astype(np.float32),
+           "target_weights": t.weights, "target_means": t.means, "target_covs": t.covs}
+    rec = {key: [] for key in ("means", "chols", "log_weights", "stepsizes", "success", "n_probes", "rewards", "elr")}
+    for _ in range(2):
+        info = o.train_iter()
+        rec["means"].append(o.model.means.copy()); rec["chols"].append(o.model.chol_cov.copy())
+        rec["log_weights"].append(o.model.log_weights.copy()); rec["stepsizes"].append(o.model.stepsizes.copy())
+        rec["success"].append(info["success"].copy()); rec["n_probes"].append(info["n_probes"].copy())
+        rec["rewards"].append(o.model.reward_history[:, -1].copy()); rec["elr"].append(info["expected_log_ratios"].copy())
+    out.update({key: np.array(v) for key, v in rec.items()})
+    for key in ("chols", "init_covs", "target_covs"):
+        out[key] = np.asarray(out[key], np.float32)        # 8 x 300 x 300 per iteration: keep the file small
+    return out
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c1", "pair_c5"]
+    for name in which:
+        print("case", name, flush=True)
+        res = run_pair_c5() if name == "pair_c5" else run_long(LONG_CASES[name])
+        path = os.path.join(HERE, ("" if name == "pair_c5" else "long_") + f"{name}.npz")
+        np.savez_compressed(path, **res)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB", flush=True)

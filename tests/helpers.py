@@ -68,9 +68,10 @@ def init_params(kind, d, k, seed):
     return 5.0, 10.0
 
 
-def make_oracle(kind, d, k, s, seed, cfg, dtype=np.float64):
+def make_oracle(kind, d, k, s, seed, cfg, dtype=np.float64, init=None):
+    """``init`` = (prior_scale, initial_cov) of an experiment config where the scaled-down test defaults are not wanted."""
     tgt = make_oracle_target(kind, d, seed)
-    ps, ic = init_params(kind, d, k, seed)
+    ps, ic = init if init is not None else init_params(kind, d, k, seed)
     model = otrain.construct_initial_mixture(d, k, 0.0, ps, ic, np.random.default_rng(seed + 1), dtype=dtype,
                                              use_diagonal_covs=cfg["model_initialization"]["use_diagonal_covs"])
     algo = otrain.OracleGMMVI(
@@ -92,7 +93,7 @@ def make_oracle(kind, d, k, s, seed, cfg, dtype=np.float64):
     return algo
 
 
-def make_device(kind, d, k, s, seed, cfg, oracle_algo):
+def make_device(kind, d, k, s, seed, cfg, oracle_algo, init=None):
     """Device GMMVI initialised with exactly the oracle's target / initial mixture / seed."""
     from gmmvi_amd.models.full_cov_gmm import FullCovGMM
     from gmmvi_amd.models.gmm_wrapper import GmmWrapper
@@ -119,9 +120,53 @@ def make_device(kind, d, k, s, seed, cfg, oracle_algo):
     model.seed = seed
     wrapper = GmmWrapper(model, cfg["component_stepsize_adapter_config"]["initial_stepsize"], 1e-12, 400)
     cfg = dict(cfg)
-    ps, ic = init_params(kind, d, k, seed)
+    ps, ic = init if init is not None else init_params(kind, d, k, seed)
     cfg["model_initialization"] = dict(cfg["model_initialization"], prior_mean=0.0, initial_cov=ic)
     g = GMMVI.build_from_config(cfg, tgt, wrapper)
     if cfg["num_component_adapter_type"] == "adaptive":
         g.num_component_adapter.rng = np.random.default_rng(seed)
     return g
+
+
+# ---- long-horizon cases (tests/golden/make_long_golden.py, tests/test_hip_long_horizon.py) ---------------------------
+EXAMPLE5_ADAPTIVE = {"del_iters": 100, "add_iters": 60, "max_components": 1000,            # examples/5...:16, adaptive.yml
+                     "thresholds_for_add_heuristic": [5000., 1000., 500., 200., 100., 50.],
+                     "min_weight_for_del_heuristic": 1e-6, "num_database_samples": 100000, "num_prior_samples": 0}
+
+LONG_CASES = {
+    # name: kind, D, K, samples / component, seed, iterations, checkpoint interval, adaptive config, (prior scale, initial cov)
+    # BASELINE configs[1] ("C2": 20-D Student-t mixture, K = 50 fixed, N = 5000) with the stm20.yml initial mixture
+    "c2": dict(kind="stm", d=20, k=50, s=100, seed=3, iters=120, every=10, adaptive=None, init=(100.0, 300.0)),
+    # BASELINE configs[0] = examples/5_samtron_20D_student-T.py:13-30: K = 45 adaptive (add every 60, delete after 100),
+    # 200 samples per component, reuse ratio 0, initial stepsize 0.1, weight stepsize 1
+    "c1": dict(kind="stm", d=20, k=45, s=200, seed=5, iters=260, every=10, adaptive=EXAMPLE5_ADAPTIVE,
+               init=(100.0, 300.0)),
+}
+
+
+def long_case_config(case):
+    return samtron_config(case["s"], initial_stepsize=0.1, adaptive=case["adaptive"], wstep=1.0)
+
+
+def make_long_oracle(case, dtype=np.float64):
+    return make_oracle(case["kind"], case["d"], case["k"], case["s"], case["seed"], long_case_config(case), dtype=dtype,
+                       init=case["init"])
+
+
+def make_long_device(case, oracle_algo):
+    return make_device(case["kind"], case["d"], case["k"], case["s"], case["seed"], long_case_config(case), oracle_algo,
+                       init=case["init"])
+
+
+def score_elbo(target, log_weights, means, chols, temperature=1.0, num_samples=20000, seed=12345):
+    """ELBO of the mixture (log_weights, means, chols) as the runner defines it (gmmvi_runner.py:131-133: mean target
+    log-density + temperature * entropy estimate, x ~ q) on a FIXED set of Philox draws, scored in fp64 by the oracle's
+    model class -> (elbo, sigma_mc = standard error of that mean)."""
+    from oracle import gmm as ogmm
+    k, d = np.asarray(means).shape
+    m = ogmm.FullCovGMM(np.ones(k) / k, np.asarray(means, np.float64), np.broadcast_to(np.eye(d), (k, d, d)))
+    m.log_weights = np.asarray(log_weights, np.float64).copy()
+    m.chol_cov = np.asarray(chols, np.float64).copy()
+    x, _ = m.sample(num_samples, seed, 0)
+    per = target.log_density(x) - temperature * m.log_density(x)
+    return float(np.mean(per)), float(np.std(per) / np.sqrt(num_samples))

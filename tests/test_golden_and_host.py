@@ -200,6 +200,34 @@ def test_bench_spawns_its_own_ranks(tmp_path, capsys):
     assert rc == 7 and capsys.readouterr().out == ""
 
 
+def test_bench_launcher_ends_the_job_when_one_rank_dies(tmp_path, capsys):
+    """Rank 0 parked forever (as inside an RCCL call whose peer is gone), rank 1 exits 7 with a message on stderr: the
+    launcher must return 7 within seconds, terminate rank 0 and relay the failing rank's stderr."""
+    import time
+    bench = _bench_module()
+    child = tmp_path / "hang.py"
+    child.write_text(
+        "import os, sys, time\n"
+        "if os.environ['RANK'] == '0':\n"
+        "    open(os.path.join(sys.argv[1], 'pid0'), 'w').write(str(os.getpid()))\n"
+        "    time.sleep(3600)\n"
+        "time.sleep(0.5)\n"
+        "sys.stderr.write('rank 1: ncclCommInitRank failed (stub)\\n')\n"
+        "sys.exit(7)\n")
+    t0 = time.time()
+    rc = bench.spawn_ranks(2, [str(tmp_path)], child=str(child), timeout=120, log_dir=str(tmp_path))
+    took = time.time() - t0
+    cap = capsys.readouterr()
+    assert rc == 7 and took < 30 and cap.out == ""
+    assert "rank 1 exited with code 7" in cap.err and "ncclCommInitRank failed (stub)" in cap.err
+    pid0 = int((tmp_path / "pid0").read_text())
+    with pytest.raises(ProcessLookupError):
+        os.kill(pid0, 0)                                                   # rank 0 is gone (terminated and reaped)
+    # a job nobody finishes ends at the timeout with 124
+    child.write_text("import time\ntime.sleep(3600)\n")
+    assert bench.spawn_ranks(2, [], child=str(child), timeout=1.0, log_dir=str(tmp_path)) == 124
+
+
 def test_bench_main_delegates_before_touching_the_gpu(monkeypatch):
     """With --gpus N > 1 and no WORLD_SIZE, main() must hand over to spawn_ranks before any device call."""
     bench = _bench_module()

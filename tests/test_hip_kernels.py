@@ -263,6 +263,29 @@ def test_more_beyond_the_register_resident_system(ctx, rng, k, d, n, snis):
     assert np.all(np.abs(g - rg) <= 1e-2 * scale_g + 1e-5), np.abs(g - rg).max() / scale_g.max()
 
 
+def test_more_refuses_blocked_path_dimensions(ctx, rng):
+    """50 < D <= 63 under the default GMMVI_BLOCKED_ABOVE = 50: the model's component blocks come from the blocked pack
+    ([mu | log-normaliser | dense L^-1], another stride) which the MORE kernels cannot read -- a clean GMMVI_ERR_ARG through
+    the C ABI and a ValueError from the Python mirror, never a launch on a mis-sized block."""
+    from gmmvi_amd import _lib
+    if _lib.blocked_above() >= 56:
+        pytest.skip("GMMVI_BLOCKED_ABOVE moved: D = 56 is a register-path dimension in this process")
+    k, d, n = 2, 56, 512
+    m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    xd = ctx.asarray(x)
+    ld, lp, _ = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_lp=True)
+    l2 = ctx.asarray(np.full(k, 1e-6))
+    with pytest.raises(ValueError, match="MORE"):
+        ops().more(ctx, packed, chols, xd, ld, lp, ctx.asarray(bg), ctx.asarray(tlp), l2, d)
+    h, g = ctx.empty((k, d, d)), ctx.empty((k, d))
+    rc = ctx.lib.gmmvi_more(ctx.handle, k, d, packed.ptr, chols.ptr, xd.ptr, n, ld.ptr, lp.ptr, ctx.asarray(bg).ptr,
+                            ctx.asarray(tlp).ptr, None, 0, 1, l2.ptr, h.ptr, g.ptr)
+    assert rc == -2                                                      # GMMVI_ERR_ARG (include/gmmvi_hip.h)
+    assert b"blocked path" in ctx.lib.gmmvi_last_error(ctx.handle)
+
+
 @pytest.mark.parametrize("k,d,n", [(2, 10, 40), (3, 20, 150), (4, 20, 240)])
 def test_more_fewer_samples_than_features(ctx, rng, k, d, n):
     """Rank-deficient ridge systems (N < F = D(D+1)/2 + D + 1), the state early in a run.  With a ridge that fp64 resolves

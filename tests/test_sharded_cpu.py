@@ -225,3 +225,19 @@ def test_single_rank_sharded_equals_unsharded_oracle():
     algo.flush()
     np.testing.assert_allclose(algo.means, o.model.means, rtol=1e-10)
     np.testing.assert_allclose(algo.log_weights, o.model.log_weights, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("change,word", [
+    (dict(adaptive={"del_iters": 6, "add_iters": 3, "max_components": 6, "thresholds_for_add_heuristic": [50.],
+                    "min_weight_for_del_heuristic": 1e-6, "num_database_samples": 10, "num_prior_samples": 0}), "adaptive"),
+    (dict(reuse_ratio=2.0), "reuse"), (dict(estimator="MORE"), "MORE"), (dict(updater="direct"), "direct"),
+    (dict(diag=True), "diagonal")])
+def test_sharded_path_refuses_configurations_outside_its_scope(change, word):
+    """Adaptive K (component_adaptation.py:177-300) would need the shards re-balanced after every add / delete; it is not
+    built for the sharded path, which says so instead of running something else."""
+    from gmmvi_amd.sharded import ShardedGMMVI, LocalExchange
+    cfg = samtron_config(S, **change)
+    o = make_oracle(KIND, D, K, S, SEED, samtron_config(S))
+    om = o.model.model
+    with pytest.raises(NotImplementedError, match=word):
+        ShardedGMMVI(OracleOps(o.target), LocalExchange(), D, K, om.means.copy(), om.chol_cov.copy(), S, SEED, cfg)
