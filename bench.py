@@ -40,6 +40,7 @@ WORKLOADS = {
     # = 64 components per GPU, N = 20k samples/iter; blocked path (csrc/blocked.hip).  No CPU baseline: the oracle's
     # [K,N,D] fp64 temporaries make one iteration take minutes ("C5 infeasible on CPU")
     "c5": ("gauss300", 300, 64, 312),
+    "c5_k8": ("gauss300", 300, 8, 312),      # the c5 shard cut to 8 components: what tests/test_hip_blocked.py checks against the oracle
     "c5_full": ("gauss300", 300, 512, 39),   # all of BASELINE configs[4] on ONE GPU (component chunks: Z of 512 components > scratch budget)
     # dimension sweep at the C3 shape (crossover of the register-resident and the blocked kernels, GMMVI_BLOCKED_ABOVE)
     "d32": ("gmm", 32, 100, 100), "d40": ("gmm", 40, 100, 100), "d63": ("gmm", 63, 100, 100),
@@ -59,8 +60,12 @@ def kernel_flops(name, n, k, d):
     algorithm needs for that step, whatever route the kernel takes."""
     p = float(n) * k
     return {
-        "mixture_eval": p * (d * d + 4 * d),              # forward substitution + square-sum + LSE
-        "mixture_eval_grad": p * (2 * d * d + 8 * d),     # + backward substitution + responsibility-weighted gradient
+        # density sweeps (csrc/density.hip names its launches: the single-call iteration tags them, the plug-in path by shape)
+        "sweep_values": p * (d * d + 4 * d),              # forward substitution + square-sum + LSE
+        "sweep_post": p * (d * d + 4 * d),                # the post-update sweep of the weight step (log values only)
+        "sweep_grad": p * (2 * d * d + 8 * d),            # + backward substitution + responsibility-weighted gradient
+        "sweep_target": p * (2 * d * d + 8 * d),          # the target evaluation (mixture targets: log value + gradient)
+        "sweep_dual": p * (2 * d * d + 8 * d),            # model log q + gradient + background in one pass over the components
         "stein_partial": p * (4 * d * d + 6 * d),         # SURVEY 8d, a9: y per sample (2D^2) + rank-1 accumulate (2D^2)
         # MORE: lower triangle of the (F+1)x(F+1) Gram matrix of [phi; reward], F = D(D+1)/2 + D + 1 (2 flop per MAC)
         "more_gram": p * ((d * (d + 1) // 2 + d + 2) * (d * (d + 1) // 2 + d + 3) + d * d),
@@ -255,6 +260,47 @@ def spawn_ranks(n_ranks, argv, child=None, timeout=900.0, log_dir=None):
     return rc
 
 
+def matched_elbo(workload, w):
+    """"At matched ELBO": a fresh device run from the workload's seed against the fp64 oracle's trajectory.  Where a
+    committed oracle fixture exists for the workload (tests/golden/long_<workload>.npz, made by
+    tests/golden/make_long_golden.py: ELBO of the oracle every 10 iterations on a fixed set of 20 000 Philox draws) the
+    device runs the fixture's full horizon (60 iterations at the north star) and is scored at every checkpoint by the same
+    fp64 scorer -- no oracle iterations inside the bench run; otherwise oracle and device run 6 iterations side by side.
+    Tolerance: |dELBO| <= 3 sigma_MC + 1e-2 nats."""
+    from helpers import score_elbo
+    g = make_gmmvi(build(workload, 1, 0), 1, 0)
+    path = os.path.join(ROOT, "tests", "golden", f"long_{workload}.npz")
+    if os.path.exists(path):
+        fx = np.load(path)
+        if np.array_equal(fx["init_means"], w["means"]):        # the fixture belongs to this very workload construction
+            cps = {int(i): j for j, i in enumerate(fx["checkpoint_iters"])}
+            rows, ok = [], True
+            for it in range(1, int(fx["checkpoint_iters"][-1]) + 1):
+                g.train_iter()
+                if it in cps:
+                    j = cps[it]
+                    e, _ = score_elbo(w["oracle_target"], g.model.log_weights.numpy(), g.model.means.numpy(),
+                                      g.model.chol_cov.numpy())
+                    tol = 3.0 * float(fx["checkpoint_sigma"][j]) + 1e-2
+                    rows.append({"iter": it, "gpu_fp32": e, "cpu_fp64": float(fx["checkpoint_elbo"][j]),
+                                 "abs_diff": abs(e - float(fx["checkpoint_elbo"][j])), "tol": tol})
+                    ok = ok and rows[-1]["abs_diff"] <= tol
+            return {"iters": rows[-1]["iter"], "gpu_fp32": rows[-1]["gpu_fp32"], "cpu_fp64": rows[-1]["cpu_fp64"],
+                    "abs_diff": rows[-1]["abs_diff"], "max_abs_diff": max(r["abs_diff"] for r in rows),
+                    "within_tolerance": bool(ok), "checkpoints": rows,
+                    "oracle": f"committed fixture tests/golden/long_{workload}.npz (fp64 oracle, same seeds)"}
+    iters = 6
+    o = make_oracle(w)
+    for _ in range(iters):
+        o.train_iter()
+        g.train_iter()
+    om = o.model.model
+    e_cpu, sg = score_elbo(w["oracle_target"], om.log_weights, om.means, om.chol_cov)
+    e_gpu, _ = score_elbo(w["oracle_target"], g.model.log_weights.numpy(), g.model.means.numpy(), g.model.chol_cov.numpy())
+    return {"iters": iters, "gpu_fp32": e_gpu, "cpu_fp64": e_cpu, "abs_diff": abs(e_gpu - e_cpu),
+            "within_tolerance": bool(abs(e_gpu - e_cpu) <= 3 * sg + 1e-2), "oracle": "fp64 oracle run side by side"}
+
+
 def parse_profile(ctx):
     import ctypes
     buf = ctypes.create_string_buffer(1 << 16)
@@ -320,16 +366,21 @@ def main():
     kernels = {name: {"launches_per_step": c / prof_steps, "avg_us": 1e3 * ms / c, **({"pairs_per_launch": pr / c} if pr else {})}
                for name, (c, ms, pr) in prof.items()}
     k_local = w["k_total"] // n_gpus
-    dominant = max(kernels, key=lambda nme: kernels[nme]["avg_us"] * kernels[nme]["launches_per_step"])
-    # kernels that report the pairs they processed (launches of different sizes share a name: the target has 10 components,
-    # the model 100) are priced on those pairs; the others on the workload's N x K
+    step_us = sum(v["avg_us"] * v["launches_per_step"] for v in kernels.values())
+    for v in kernels.values():
+        v["share_of_step"] = v["avg_us"] * v["launches_per_step"] / step_us
+    dominant = max(kernels, key=lambda nme: kernels[nme]["share_of_step"])
+    # every launch name stands for ONE kind of launch (the dual sweep, the target evaluation and the post-update sweep have
+    # their own names); kernels that report the pairs they processed are priced on those pairs, the others on N x K
     def launch_flops(nme, fn=kernel_flops):
         if "pairs_per_launch" in kernels[nme]:
             return fn(nme, kernels[nme]["pairs_per_launch"], 1, w["d"])
         return fn(nme, w["n_total"], k_local, w["d"])
     priced = [nme for nme in kernels if kernel_flops(nme, 1, 1, 1) is not None]
-    # roofline kernel: the FLOP-heaviest launch of the step (algorithmic FLOPs); every priced kernel is listed in kernel_roofline
-    roof_name = max(priced, key=lambda nme: launch_flops(nme) * kernels[nme]["launches_per_step"])
+    # roofline kernel: the TIME-dominant launch of the step (largest share of the step time) among the kernels that carry
+    # algorithmic FLOPs -- normally dominant_kernel itself; a latency-chain kernel without a per-pair FLOP figure (the
+    # KL-constrained update, one workgroup per component) cannot be priced and is then named in roofline.note
+    roof_name = max(priced, key=lambda nme: kernels[nme]["share_of_step"])
     fl = launch_flops(roof_name)
     achieved = fl / (kernels[roof_name]["avg_us"] * 1e-6) / 1e12
     kernel_roofline = {}
@@ -337,6 +388,7 @@ def main():
         pk = PEAK_FP64_MFMA_TFLOPS if nme == "more_gram" else PEAK_FP32_TFLOPS
         t = kernels[nme]["avg_us"] * 1e-6
         kernel_roofline[nme] = {"avg_us": kernels[nme]["avg_us"], "launches_per_step": kernels[nme]["launches_per_step"],
+                                "share_of_step": kernels[nme]["share_of_step"],
                                 "flops_alg_per_launch": launch_flops(nme), "frac": launch_flops(nme) / t / 1e12 / pk,
                                 "frac_executed": launch_flops(nme, kernel_flops_executed) / t / 1e12 / pk}
     roof_peak = PEAK_FP64_MFMA_TFLOPS if roof_name == "more_gram" else PEAK_FP32_TFLOPS
@@ -369,11 +421,14 @@ def main():
                      "unit": "TFLOP/s", "frac": achieved / roof_peak, "traffic": traffic,
                      "avg_us": kernels[roof_name]["avg_us"], "flops_per_launch": fl,
                      "flops_executed_per_launch": launch_flops(roof_name, kernel_flops_executed),
-                     "selection": "the FLOP-heaviest launch of the step; kernel_roofline prices every FLOP-carrying kernel the same "
-                                  "way and dominant_kernel names the one with the largest share of the step time",
-                     "note": "achieved = SURVEY.md 8(d) algorithmic FLOPs of the launch / its mean HIP-event duration; peak = "
-                             "fp32 vector == f32 MFMA rate. The Stein kernel (moment form) executes fewer FLOPs than the "
-                             "algorithmic figure (flops_executed_per_launch; kernel_roofline.frac_executed). Algorithmic HBM "
+                     "selection": "the launch with the largest share of the step time among the FLOP-carrying kernels"
+                                  + ("" if roof_name == dominant else f" (dominant_kernel {dominant} is a latency chain without a "
+                                     "per-pair FLOP figure)") + "; kernel_roofline prices every FLOP-carrying kernel the same way",
+                     "share_of_step": kernels[roof_name]["share_of_step"],
+                     "note": "achieved = algorithmic FLOPs of the launch (pairs x per-pair figure of bench.kernel_flops, SURVEY.md "
+                             "8(d)) / its mean HIP-event duration; peak = fp32 vector == f32 MFMA rate. The Stein kernel "
+                             "(moment form) executes fewer FLOPs than its algorithmic figure (kernel_roofline.stein_partial."
+                             "frac_executed). Algorithmic HBM "
                              "bytes per iteration are tiny (see iter_roofline): the north star's >=50% HBM roofline is "
                              "unreachable on algorithmic bytes (SURVEY.md 8d)."},
         "kernel_roofline": kernel_roofline,
@@ -396,22 +451,7 @@ def main():
                                   "sample": f"3 warm-up + {cpu_iters} timed train_iter() of the same workload (fp32 "
                                             f"NumPy/SciPy restatement of the reference's algorithm, the reference's own "
                                             f"arithmetic), median iteration time"}
-        # matched ELBO: fp64 oracle and a fresh device run, the same number of iterations from the same seed, both models
-        # scored by the fp64 oracle on the same 20 000 Philox draws
-        elbo_iters = 6
-        o = make_oracle(w)
-        g = make_gmmvi(build(args.workload, 1, 0), 1, 0)
-        for _ in range(elbo_iters):
-            o.train_iter()
-            g.train_iter()
-        elbo_cpu = o.elbo(20000, seed=12345)[0]
-        om = o.model.model
-        om.means = g.model.means.numpy().astype(np.float64)
-        om.chol_cov = g.model.chol_cov.numpy().astype(np.float64)
-        om.log_weights = g.model.log_weights.numpy().astype(np.float64)
-        elbo_gpu = o.elbo(20000, seed=12345)[0]
-        result["matched_elbo"] = {"iters": elbo_iters, "gpu_fp32": elbo_gpu, "cpu_fp64": elbo_cpu,
-                                  "abs_diff": abs(elbo_gpu - elbo_cpu)}
+        result["matched_elbo"] = matched_elbo(args.workload, w)
     if rank == 0:
         print(json.dumps(result))
 

@@ -40,6 +40,7 @@ struct gmmvi_ctx {
     int num_cus = 256;
     // optional per-kernel HIP-event timing (bench.py roofline leg): events are recorded on ctx->stream
     bool prof = false;
+    const char* prof_tag = nullptr;   // set by a caller that knows which sweep of the iteration a density launch is (fused.hip)
     struct ProfRec { const char* name; hipEvent_t start, stop; double units; };   // units: (sample, component) pairs of the launch
     std::vector<ProfRec> prof_recs;
 };

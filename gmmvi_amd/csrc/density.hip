@@ -11,6 +11,7 @@
 #include "subst.h"
 #include "blocked.h"
 #include <cmath>
+#include <type_traits>
 #include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -123,6 +124,12 @@ __global__ __launch_bounds__(64) void cholesky_kernel(int D, const float* __rest
 #ifndef GMMVI_ME_WIDE_DP
 #define GMMVI_ME_WIDE_DP 40
 #endif
+#ifdef GMMVI_ME_STAMPS
+__device__ long long g_me_wg[2 * 8192];    // experiment builds: wall-clock (100 MHz) start / end of every workgroup of the last launch
+extern "C" int gmmvi_debug_wg_times(long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_wg), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 template <int DP, int FAMILY, bool GRAD>
 __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GMMVI_ME_MINW) void mixture_eval_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
                                                             const float* __restrict__ logw, const float* __restrict__ X,
@@ -148,6 +155,16 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
     const int n = n0 + lane;
     const bool valid = lane < n_here;
     float* sm_merge = sm;                              // staging, then the merge area
+#ifdef GMMVI_ME_STAMPS             // experiment builds (tools/bench_sweep.py): phase time stamps of one wave
+    if (threadIdx.x == 0) g_me_wg[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
+    unsigned long long stamp[16];
+    int nstamp = 0;
+    const long long wc0 = wall_clock64();
+#define ME_STAMP() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (nstamp < 16) stamp[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+    ME_STAMP();
+#else
+#define ME_STAMP()
+#endif
 
     // ---- x tile: rows that are a whole number of 16- or 8-byte pieces are read straight into the lane's registers (lane = sample:
     // the loads of a row walk the same cache lines, the W waves of the workgroup hit in L1); other shapes are staged
@@ -193,8 +210,10 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
         for (int i = 0; i < DP; ++i) acc[i] = 0.f;
     }
     const float nud = nu + (float)D;
+    ME_STAMP();
 
     for (int k = k_lo + wave; k < K; k += nwaves) {
+        ME_STAMP();
         PackRef P;
         P.p = reinterpret_cast<const float4*>(packed + (size_t)k * PK::STRIDE);
         const float lw = logw[k];
@@ -229,6 +248,7 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
             for (int i = 0; i < DP; ++i) acc[i] = fmaf(acc[i], sc, ec * y[i]);
         }
     }
+    ME_STAMP();
     if (lp_out == nullptr && !GRAD) return;
 
     // merge the W waves' partials: sm_m[w][lane], sm_s[w][lane], sm_acc[w][i][lane]
@@ -274,6 +294,16 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
         for (int e = threadIdx.x; e < n_here * D; e += blockDim.x)
             grad_out[(size_t)n0 * D + e] = outt[(e / D) * ldx + (e % D)];
     }
+#ifdef GMMVI_ME_STAMPS
+    ME_STAMP();
+    if (threadIdx.x == 0) g_me_wg[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
+    if (GRAD && logw2 && blockIdx.x == 60 && blockIdx.y == 1 && threadIdx.x == 64 * 3 && g_me_wg[2 * 8192 - 1]++ < 2) {
+        const long long wc1 = wall_clock64();
+        printf("me stamps (shader cycles; kernel %lld x 10 ns by the 100 MHz clock):", wc1 - wc0);
+        for (int i = 1; i < nstamp; ++i) printf(" %llu", stamp[i] - stamp[i - 1]);
+        printf("  total %llu\n", stamp[nstamp - 1] - stamp[0]);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -287,8 +317,9 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
 // T waves that share them; only the row-packed triangle is read (forward substitution in dot form over the rows, backward
 // substitution in axpy form over the same rows, descending: 0.9 KB instead of 1.7 KB a block); and the lines of the blocks
 // that come next are touched ahead (`s_load_dword` into a sink register) by one extra FEEDER wave per workgroup that paces
-// itself on the progress counters of the compute waves (or, without it, by every wave for its own next block), so that the
-// L2 latency is paid once per block and off the compute waves.  The G streams of a tile are merged through LDS as above.
+// itself on the progress counters of the compute waves, so that the L2 latency is paid once per block and off the compute
+// waves.  (The touches cannot live in the compute waves: the compiler may spill the sink and reuse its physical register
+// while touches are still in flight -- a late return then overwrites a live value.)  The G streams of a tile are merged through LDS as above.
 // The block through a CONSTANT-address-space pointer: uniform loads from it are scalar loads whatever else the loop contains
 // (the `asm volatile` touches below count as possible writers of global memory, which turns uniform GLOBAL loads into
 // per-lane vector loads); the blocks are not written during the launch.
@@ -301,6 +332,75 @@ struct PackRefConst {
         return v[idx & 3];
     }
 };
+
+// ---- phased component pass: the row stream of L in pieces of 32 floats, the next piece in flight while the current one is
+// multiplied.  Scalar loads return out of order, so every wait is lgkmcnt(0): the wait for a piece must come BEFORE the loads
+// of the next piece are issued (an empty asm that takes the piece's registers as operands forces it there), and scheduling
+// barriers keep the compiler from moving the loads back down to their first use.
+template <int B, int E, typename F>
+__device__ __forceinline__ void ls_static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        ls_static_for<B + 1, E>(f);
+    }
+}
+template <int B, int E, typename F>
+__device__ __forceinline__ void ls_static_for_down(F&& f) {         // E - 1, E - 2, ..., B
+    if constexpr (B < E) {
+        f(std::integral_constant<int, E - 1>{});
+        ls_static_for_down<B, E - 1>(f);
+    }
+}
+__host__ __device__ constexpr int ls_row(int e) { int i = 1; while ((i + 1) * i / 2 <= e) ++i; return i; }   // element e of the strict lower triangle, row-major
+__host__ __device__ constexpr int ls_col(int e) { return e - ls_row(e) * (ls_row(e) - 1) / 2; }
+#define LS_S4(a, o) "s"(a[o]), "s"(a[(o) + 1]), "s"(a[(o) + 2]), "s"(a[(o) + 3])
+template <int NL>
+__device__ __forceinline__ void ls_landed(const float (&a)[32]) {   // the registers of a piece hold its data from here on
+    static_assert(NL % 4 == 0 && NL >= 4 && NL <= 32, "piece length");
+    asm volatile("" ::LS_S4(a, 0));
+    if constexpr (NL > 4) asm volatile("" ::LS_S4(a, 4));
+    if constexpr (NL > 8) asm volatile("" ::LS_S4(a, 8));
+    if constexpr (NL > 12) asm volatile("" ::LS_S4(a, 12));
+    if constexpr (NL > 16) asm volatile("" ::LS_S4(a, 16));
+    if constexpr (NL > 20) asm volatile("" ::LS_S4(a, 20));
+    if constexpr (NL > 24) asm volatile("" ::LS_S4(a, 24));
+    if constexpr (NL > 28) asm volatile("" ::LS_S4(a, 28));
+}
+// the values of a register array are complete HERE (an empty asm that reads and "writes" them): keeps the optimiser from
+// sinking the multiply-adds of a piece below the loads of the following pieces, towards their last use
+#define LS_V4(a, o) "+v"(a[o]), "+v"(a[(o) + 1]), "+v"(a[(o) + 2]), "+v"(a[(o) + 3])
+template <int N>
+__device__ __forceinline__ void ls_pin(float (&a)[N]) {
+    static_assert(N % 2 == 0 && N <= 24, "padded dimension");
+    if constexpr (N >= 4) asm volatile("" : LS_V4(a, 0));
+    if constexpr (N >= 8) asm volatile("" : LS_V4(a, 4));
+    if constexpr (N >= 12) asm volatile("" : LS_V4(a, 8));
+    if constexpr (N >= 16) asm volatile("" : LS_V4(a, 12));
+    if constexpr (N >= 20) asm volatile("" : LS_V4(a, 16));
+    if constexpr (N >= 24) asm volatile("" : LS_V4(a, 20));
+    if constexpr (N % 4 == 2) asm volatile("" : "+v"(a[N - 2]), "+v"(a[N - 1]));
+}
+template <int N, int O = 0>
+__device__ __forceinline__ void ls_landed_arr(const float (&a)[N]) {
+    static_assert(N % 4 == 0, "array length");
+    if constexpr (O < N) {
+        asm volatile("" ::LS_S4(a, O));
+        ls_landed_arr<N, O + 4>(a);
+    }
+}
+template <int DP, int PIECE>
+struct LsPiece {
+    static constexpr int T = DP * (DP - 1) / 2;
+    static constexpr int NP = (T + 31) / 32;                                   // pieces of the row stream
+    static constexpr int NV = T - 32 * PIECE < 32 ? T - 32 * PIECE : 32;       // elements of this piece
+    static constexpr int NL = (NV + 3) / 4 * 4;                                // floats fetched (whole 16-byte words; the tail lies in the block)
+};
+template <int DP, int PIECE, typename PR>
+__device__ __forceinline__ void ls_fetch_piece(const PR& P, float (&a)[32]) {
+    using PK = Pack<DP>;
+#pragma unroll
+    for (int u = 0; u < LsPiece<DP, PIECE>::NL; ++u) a[u] = P[PK::LROW + 32 * PIECE + u];
+}
 
 template <int DP>
 __device__ __forceinline__ void ls_touch_block(const float* blk, int& sink) {
@@ -315,7 +415,7 @@ __device__ __forceinline__ void ls_touch_block(const float* blk, int& sink) {
 // the sink register may be reused only after the touches have landed
 __device__ __forceinline__ void ls_touch_release(int& sink) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink)); }
 
-template <int DP, int FAMILY, bool GRAD>
+template <int DP, int FAMILY, bool GRAD, bool PHASED>
 __global__ __launch_bounds__(1024) void mixture_eval_ls_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
                                                                const float* __restrict__ logw, const float* __restrict__ X,
                                                                int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
@@ -325,6 +425,8 @@ __global__ __launch_bounds__(1024) void mixture_eval_ls_kernel(float nu, int K_t
     using PK = Pack<DP>;
     extern __shared__ __align__(16) float sm[];
     __shared__ int prog[16];                           // components done per compute wave (read by the feeder)
+    const bool samek = (ahead & 256) != 0;             // experiment: every pass reads the chunk's first block
+    ahead &= 255;
     if (combine_carried(carried)) return;              // workgroups past the sample tiles: the merge of the previous sweep
     const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
     const int k_lo = blockIdx.y * kchunk;
@@ -404,17 +506,101 @@ __global__ __launch_bounds__(1024) void mixture_eval_ls_kernel(float nu, int K_t
             for (int i = 0; i < DP; ++i) x[i] = 0.f;
         }
         const float nud = nu + (float)D;
-        int sink = 0;
-        if (!feeder && k_lo + g < K) ls_touch_block<DP>(packed + (size_t)(k_lo + g) * PK::STRIDE, sink);
         int st = 0;
         for (int k = k_lo + g; k < K; k += G, ++st) {
-            const float* blk = packed + (size_t)k * PK::STRIDE;
-            if (!feeder && k + G < K) ls_touch_block<DP>(blk + (size_t)G * PK::STRIDE, sink);
+            const float* blk = packed + (size_t)(samek ? k_lo : k) * PK::STRIDE;
             PackRefConst P;
             P.p = (ls_cf4p)(uintptr_t)blk;
             const float lw = ((const __attribute__((address_space(4))) float*)(uintptr_t)logw)[k];
-            // z = L^-1 (x - mu) by the rows of L (dot form), q = |z|^2
+            const float lw2 = dual ? ((const __attribute__((address_space(4))) float*)(uintptr_t)logw2)[k] : 0.f;
             float z[DP], q = 0.f;
+            float ld, coef, e, sc;
+            if constexpr (PHASED && DP >= 4) {
+                constexpr int T = PK::T, NP = LsPiece<DP, 0>::NP;
+                // mu | 1 / diag and the first piece of the row stream: one wait
+                float head[2 * DP], vrd[DP];
+                float pc[2][32];
+#pragma unroll
+                for (int u = 0; u < 2 * DP; ++u) head[u] = P[u];
+                ls_fetch_piece<DP, 0>(P, pc[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                ls_landed_arr<2 * DP>(head);
+                ls_landed<LsPiece<DP, 0>::NL>(pc[0]);
+#pragma unroll
+                for (int i = 0; i < DP; ++i) {
+                    z[i] = x[i] - head[PK::MU + i];
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(vrd[i]) : "s"(head[PK::RD + i]));     // a VGPR copy: frees the SGPRs
+                }
+                z[0] *= vrd[0];
+                q = z[0] * z[0];
+                // forward, dot form over the rows: u_i -= L_ij z_j;  at the end of row i: z_i = u_i / L_ii
+                ls_static_for<0, NP>([&](auto PCE) {
+                    constexpr int pce = PCE;
+                    if constexpr (pce + 1 < NP) ls_fetch_piece<DP, pce + 1>(P, pc[(pce + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ls_static_for<0, LsPiece<DP, pce>::NV>([&](auto U) {
+                        constexpr int el = 32 * pce + U, i = ls_row(el), j = ls_col(el);
+                        z[i] = fmaf(-pc[pce & 1][U], z[j], z[i]);
+                        if constexpr (j == i - 1) {
+                            z[i] *= vrd[i];
+                            q = fmaf(z[i], z[i], q);
+                        }
+                    });
+                    ls_pin<DP>(z);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (pce + 1 < NP) ls_landed<LsPiece<DP, pce + 1>::NL>(pc[(pce + 1) & 1]);
+                });
+                const float cst = P[PK::CONST];
+                // the same rows again for the backward pass, through a pointer the compiler cannot identify with the first one:
+                // otherwise it keeps all T values of the forward pass alive (spilled to VGPR lanes) instead of loading them again
+                PackRefConst Pb = P;
+                asm volatile("" : "+s"(Pb.p));
+                if constexpr (GRAD) ls_fetch_piece<DP, NP - 1>(Pb, pc[(NP - 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (FAMILY == GMMVI_GAUSS) {
+                    ld = fmaf(-0.5f, q, cst);
+                    coef = -1.f;
+                } else {
+                    ld = cst - 0.5f * nud * log1pf(q / nu);
+                    coef = -nud / (nu + q);
+                }
+                const float a = ld + lw;
+                const float mn = fmaxf(m, a);
+                sc = __expf(m - mn);
+                e = __expf(a - mn);
+                s = fmaf(s, sc, e);
+                m = mn;
+                if (dual) {
+                    const float a2 = ld + lw2;
+                    const float mn2 = fmaxf(m2, a2);
+                    s2 = fmaf(s2, __expf(m2 - mn2), __expf(a2 - mn2));
+                    m2 = mn2;
+                }
+                if constexpr (GRAD) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    ls_landed<LsPiece<DP, NP - 1>::NL>(pc[(NP - 1) & 1]);
+                    // backward, axpy form over the same rows in descending order: y_i = z_i / L_ii, then z_j -= L_ij y_i
+                    ls_static_for_down<0, NP>([&](auto PCE) {
+                        constexpr int pce = PCE;
+                        if constexpr (pce > 0) ls_fetch_piece<DP, pce - 1>(Pb, pc[(pce - 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ls_static_for_down<0, LsPiece<DP, pce>::NV>([&](auto U) {
+                            constexpr int el = 32 * pce + U, i = ls_row(el), j = ls_col(el);
+                            if constexpr (j == i - 1) z[i] *= vrd[i];
+                            z[j] = fmaf(-pc[pce & 1][U], z[i], z[j]);
+                        });
+                        ls_pin<DP>(z);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (pce > 0) ls_landed<LsPiece<DP, pce - 1>::NL>(pc[(pce - 1) & 1]);
+                    });
+                    z[0] *= vrd[0];
+                    const float ec = e * coef;
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) acc[i] = fmaf(acc[i], sc, ec * z[i]);
+                    ls_pin<DP>(acc);
+                }
+            } else {
+            // z = L^-1 (x - mu) by the rows of L (dot form), q = |z|^2
 #pragma unroll
             for (int i = 0; i < DP; ++i) {
                 float tt = x[i] - P[PK::MU + i];
@@ -423,7 +609,6 @@ __global__ __launch_bounds__(1024) void mixture_eval_ls_kernel(float nu, int K_t
                 z[i] = tt * P[PK::RD + i];
                 q = fmaf(z[i], z[i], q);
             }
-            float ld, coef;
             if (FAMILY == GMMVI_GAUSS) {
                 ld = fmaf(-0.5f, q, P[PK::CONST]);
                 coef = -1.f;
@@ -431,33 +616,37 @@ __global__ __launch_bounds__(1024) void mixture_eval_ls_kernel(float nu, int K_t
                 ld = P[PK::CONST] - 0.5f * nud * log1pf(q / nu);
                 coef = -nud / (nu + q);
             }
-            if (ld_out != nullptr && valid) ld_out[(size_t)k * N + n] = ld;
             const float a = ld + lw;
             const float mn = fmaxf(m, a);
-            const float sc = __expf(m - mn);
-            const float e = __expf(a - mn);
+            sc = __expf(m - mn);
+            e = __expf(a - mn);
             s = fmaf(s, sc, e);
             m = mn;
             if (dual) {
-                const float a2 = ld + ((const __attribute__((address_space(4))) float*)(uintptr_t)logw2)[k];
+                const float a2 = ld + lw2;
                 const float mn2 = fmaxf(m2, a2);
                 s2 = fmaf(s2, __expf(m2 - mn2), __expf(a2 - mn2));
                 m2 = mn2;
             }
             if (GRAD) {
                 // y = L^-T z in place, by the ROWS of L in descending order: y_i = z_i / L_ii, then z_j -= L_ij y_i (j < i)
+                PackRefConst Pb = P;                   // (an opaque copy: see the phased branch)
+                asm volatile("" : "+s"(Pb.p));
 #pragma unroll
                 for (int i = DP - 1; i >= 0; --i) {
-                    const float yi = z[i] * P[PK::RD + i];
+                    const float yi = z[i] * Pb[PK::RD + i];
                     z[i] = yi;
 #pragma unroll
-                    for (int j = 0; j < i; ++j) z[j] = fmaf(-P[PK::LROW + PK::rowofs(i) + j], yi, z[j]);
+                    for (int j = 0; j < i; ++j) z[j] = fmaf(-Pb[PK::LROW + PK::rowofs(i) + j], yi, z[j]);
                 }
                 const float ec = e * coef;
 #pragma unroll
                 for (int i = 0; i < DP; ++i) acc[i] = fmaf(acc[i], sc, ec * z[i]);
             }
-            if (!feeder) ls_touch_release(sink);
+            }
+            // (the store comes last: a branch in the middle of the pass splits it into basic blocks and the backward
+            // multiply-adds then end up behind all the loads of their pieces)
+            if (ld_out != nullptr && valid) ld_out[(size_t)k * N + n] = ld;
             if (lane == 0) ((volatile int*)prog)[wave] = st + 1;
         }
         if (lane == 0) ((volatile int*)prog)[wave] = 0x7fffffff;
@@ -1039,6 +1228,14 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_ws_kernel(float nu, int
     }
 }
 
+// profile name of a density launch: the caller's tag (fused.hip knows which sweep of the iteration it issues), else by shape:
+// the dual sweep (model + background over the same components), a sweep with the gradient (target evaluation or model
+// density + gradient), a log-value sweep (post-update densities)
+static const char* sweep_prof_name(const gmmvi_ctx* ctx, bool want_grad, bool dual) {
+    if (ctx->prof_tag) return ctx->prof_tag;
+    return dual ? "sweep_dual" : (want_grad ? "sweep_grad" : "sweep_values");
+}
+
 template <int DP, int NTS>
 static int launch_mixture_eval_mfma(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
                                     const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
@@ -1092,7 +1289,7 @@ static int launch_mixture_eval_mfma(gmmvi_ctx* ctx, int family, float nu, int K,
     const CombineJob carried = gmmvi_take_pending_combine(ctx, nw * 64, tiles);
     dim3 grid(tiles + carried.blocks, ky), block(nw * 64);
     {
-        GMMVI_PROF_UNITS(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval", (double)N * K);
+        GMMVI_PROF_UNITS(ctx, sweep_prof_name(ctx, want_grad, logw2 != nullptr), (double)N * K);
 #define GMMVI_LAUNCH_MM(FAM, G)                                                                                     \
     do {                                                                                                            \
         if (shmem > 64 * 1024)                                                                                      \
@@ -1161,7 +1358,7 @@ static int launch_mixture_eval_mfma_ws(gmmvi_ctx* ctx, int family, float nu, int
     const CombineJob carried = gmmvi_take_pending_combine(ctx, 512, tiles);
     dim3 grid(tiles + carried.blocks, ky), block(512);
     {
-        GMMVI_PROF_UNITS(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval", (double)N * K);
+        GMMVI_PROF_UNITS(ctx, sweep_prof_name(ctx, want_grad, logw2 != nullptr), (double)N * K);
 #define GMMVI_LAUNCH_WS(FAM, G)                                                                                     \
     do {                                                                                                            \
         if (shmem > 64 * 1024)                                                                                      \
@@ -1202,8 +1399,10 @@ static int launch_mixture_eval_ls(gmmvi_ctx* ctx, int family, float nu, int K, i
     static const int env_g = getenv("GMMVI_LS_G") ? atoi(getenv("GMMVI_LS_G")) : 0;
     static const int env_ky = getenv("GMMVI_LS_KY") ? atoi(getenv("GMMVI_LS_KY")) : 0;
     static const int env_feeder = getenv("GMMVI_LS_FEEDER") ? atoi(getenv("GMMVI_LS_FEEDER")) : 1;
-    static const int env_ahead = getenv("GMMVI_LS_AHEAD") ? atoi(getenv("GMMVI_LS_AHEAD")) : 2;
+    static const int env_ahead = (getenv("GMMVI_LS_AHEAD") ? atoi(getenv("GMMVI_LS_AHEAD")) : 2) |
+                                 (getenv("GMMVI_LS_SAMEK") && atoi(getenv("GMMVI_LS_SAMEK")) ? 256 : 0);
     static const int env_wgs = getenv("GMMVI_LS_WGS_PER_CU") ? atoi(getenv("GMMVI_LS_WGS_PER_CU")) : 2;
+    static const int env_phased = getenv("GMMVI_LS_PHASED") ? atoi(getenv("GMMVI_LS_PHASED")) : 1;
     const int tiles = (N + 63) / 64;
     int T = env_t > 0 ? env_t : 4, G = env_g > 0 ? env_g : 2;
     if (T > tiles) T = tiles;
@@ -1244,14 +1443,18 @@ static int launch_mixture_eval_ls(gmmvi_ctx* ctx, int family, float nu, int K, i
     const CombineJob carried = gmmvi_take_pending_combine(ctx, threads, tgroups);
     dim3 grid(tgroups + carried.blocks, ky), block(threads);
     {
-        GMMVI_PROF_UNITS(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval", (double)N * K);
-#define GMMVI_LAUNCH_LS(FAM, GR)                                                                                    \
+        GMMVI_PROF_UNITS(ctx, sweep_prof_name(ctx, want_grad, logw2 != nullptr), (double)N * K);
+#define GMMVI_LAUNCH_LS2(FAM, GR, PH)                                                                               \
     do {                                                                                                            \
         if (shmem > 64 * 1024)                                                                                      \
-            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_ls_kernel<DP, FAM, GR>,              \
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_ls_kernel<DP, FAM, GR, PH>,          \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
-        hipLaunchKernelGGL((mixture_eval_ls_kernel<DP, FAM, GR>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
-                           logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried, T, G, feeder, env_ahead);             \
+        hipLaunchKernelGGL((mixture_eval_ls_kernel<DP, FAM, GR, PH>), grid, block, shmem, ctx->stream, nu, K, D,    \
+                           packed, logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried, T, G, feeder, env_ahead);    \
+    } while (0)
+#define GMMVI_LAUNCH_LS(FAM, GR)                                                                                    \
+    do {                                                                                                            \
+        if (env_phased) GMMVI_LAUNCH_LS2(FAM, GR, true); else GMMVI_LAUNCH_LS2(FAM, GR, false);                     \
     } while (0)
         if (family == GMMVI_GAUSS) {
             if (want_grad) GMMVI_LAUNCH_LS(GMMVI_GAUSS, true); else GMMVI_LAUNCH_LS(GMMVI_GAUSS, false);
@@ -1259,6 +1462,7 @@ static int launch_mixture_eval_ls(gmmvi_ctx* ctx, int family, float nu, int K, i
             if (want_grad) GMMVI_LAUNCH_LS(GMMVI_STUDENT_T, true); else GMMVI_LAUNCH_LS(GMMVI_STUDENT_T, false);
         }
 #undef GMMVI_LAUNCH_LS
+#undef GMMVI_LAUNCH_LS2
     }
     GMMVI_LAUNCH_CHECK(ctx);
     if (defer) {
@@ -1350,7 +1554,7 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     const CombineJob carried = gmmvi_take_pending_combine(ctx, nw * 64, tiles);
     dim3 grid(tiles + carried.blocks, ky), block(nw * 64);
     {
-        GMMVI_PROF_UNITS(ctx, want_grad ? "mixture_eval_grad" : "mixture_eval", (double)N * K);
+        GMMVI_PROF_UNITS(ctx, sweep_prof_name(ctx, want_grad, logw2 != nullptr), (double)N * K);
 #define GMMVI_LAUNCH_ME(FAM, G)                                                                                     \
     do {                                                                                                            \
         if (shmem > 64 * 1024)                                                                                      \

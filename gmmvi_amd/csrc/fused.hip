@@ -47,6 +47,7 @@ extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan
     if (rc != GMMVI_OK) {
         ctx->pending = CombineJob();
         ctx->defer_combine = false;
+        ctx->prof_tag = nullptr;
     }
     return rc;
 }
@@ -98,16 +99,21 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
     // issued BEFORE the target evaluation, which does not depend on it: the merge of the sweep's component-chunk partials
     // rides as extra workgroups in the target launch instead of a launch of its own (combine.h; same arithmetic)
     ctx->defer_combine = true;
+    ctx->prof_tag = "sweep_dual";
     int rc_dual = gmmvi_mixture_eval_dual(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, p->logw, p->bg_logw, x, N, a.ld, a.lq,
                                           a.qgrad, a.bg);
     ctx->defer_combine = false;
+    ctx->prof_tag = nullptr;
     GMMVI_TRY(rc_dual);
     if (p->target_kind == 1) {
         GMMVI_TRY(gmmvi_target_planar(ctx, D, p->planar_prior_std, p->planar_goals_count, p->planar_goals,
                                       p->planar_likelihood_std, x, N, p->db_tlp, p->db_tgrad));
     } else {
-        GMMVI_TRY(gmmvi_mixture_eval(ctx, p->target_family, p->target_nu, p->target_K, D, p->target_packed,
-                                     p->target_logw, x, N, nullptr, p->db_tlp, p->db_tgrad));
+        ctx->prof_tag = "sweep_target";
+        int rc_t = gmmvi_mixture_eval(ctx, p->target_family, p->target_nu, p->target_K, D, p->target_packed,
+                                      p->target_logw, x, N, nullptr, p->db_tlp, p->db_tgrad);
+        ctx->prof_tag = nullptr;
+        GMMVI_TRY(rc_t);
     }
     GMMVI_TRY(gmmvi_flush_pending_combine(ctx));       // nothing left unless the target launch could not carry it
     // ---- component update (gmmvi.py:165-169) -----------------------------------------------------------------------------
@@ -121,8 +127,10 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
     // ---- weight update (gmmvi.py:172-173) ---------------------------------------------------------------------------------
     // (the merge of this sweep's log-density partials happens inside the expected-log-ratio kernel)
     ctx->defer_combine = true;
+    ctx->prof_tag = "sweep_post";
     int rc_post = gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed_new, p->logw, x, N, a.ld, a.lq, nullptr);
     ctx->defer_combine = false;
+    ctx->prof_tag = nullptr;
     GMMVI_TRY(rc_post);
     GMMVI_TRY(gmmvi_expected_log_ratios(ctx, K, N, a.ld, a.bg, p->db_tlp, a.lq, p->temperature, p->logw,
                                         (p->stein_flags & GMMVI_SELF_NORMALIZED) ? 1 : 0, a.E, p->reward_next, nullptr));

@@ -5,6 +5,9 @@ ships no vectors: SURVEY.md 8c; these files are oracle output, data only -- "par
   long_c1.npz   BASELINE configs[0] = examples/5_samtron_20D_student-T.py:13-30: K = 45 adaptive (add every 60, delete after
                 100 iterations), 200 samples / component, reuse ratio 0, 260 iterations (adds at 60/120/180/240, deletions
                 from iteration 101)
+  long_ns.npz   the north-star workload exactly as bench.py builds it (bench.spec("ns"): K = 100, D = 20, N = 10 000), 60
+                iterations: what bench.py's matched_elbo leg compares the device trajectory with (no oracle iterations
+                inside the bench run)
   pair_c5.npz   the per-GPU shard shape of BASELINE configs[4] that bench.py --workload c5 composes, cut to K = 8 components:
                 single-Gaussian target D = 300 (gmm.py:148-162 law), 312 samples / component, 2 iterations
 
@@ -53,6 +56,28 @@ def run_long(case, dtype=np.float64, verbose=True):
     return out
 
 
+def run_bench_workload(workload, iters, every):
+    """ELBO checkpoints of the fp64 oracle on a bench.py workload (same construction as bench.make_oracle)."""
+    import bench
+    w = bench.spec(workload, 1)
+    o = bench.make_oracle(w)
+    t = o.target
+    out = {"init_means": w["means"], "target_means": t.means, "workload": workload}
+    cp_it, cp_elbo, cp_sigma = [], [], []
+    t0 = time.time()
+    for it in range(1, iters + 1):
+        o.train_iter()
+        if it % every == 0:
+            m = o.model.model
+            e, sg = score_elbo(t, m.log_weights, m.means, m.chol_cov)
+            cp_it.append(it); cp_elbo.append(e); cp_sigma.append(sg)
+            print(f"  it {it:4d}  elbo {e:12.4f} +- {sg:.4f}  ({time.time() - t0:.0f} s)", flush=True)
+    m = o.model.model
+    out.update(checkpoint_iters=np.array(cp_it), checkpoint_elbo=np.array(cp_elbo), checkpoint_sigma=np.array(cp_sigma),
+               final_log_weights=m.log_weights.copy(), final_means=m.means.copy())
+    return out
+
+
 def run_pair_c5():
     """D = 300, K = 8, S = 312: the state after each of 2 iterations (what tests/helpers.run_pair compares)."""
     cfg = samtron_config(312, initial_stepsize=0.1)
@@ -74,10 +99,11 @@ def run_pair_c5():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c1", "pair_c5"]
+    which = sys.argv[1:] or ["c2", "c1", "ns"]
     for name in which:
         print("case", name, flush=True)
-        res = run_pair_c5() if name == "pair_c5" else run_long(LONG_CASES[name])
+        res = (run_pair_c5() if name == "pair_c5" else run_bench_workload("ns", 60, 10) if name == "ns"
+               else run_long(LONG_CASES[name]))
         path = os.path.join(HERE, ("" if name == "pair_c5" else "long_") + f"{name}.npz")
         np.savez_compressed(path, **res)
         print("wrote", path, os.path.getsize(path) // 1024, "KiB", flush=True)

@@ -233,6 +233,32 @@ def test_blocked_trajectory_matches_oracle(kind, d, k, s, iters):
     assert abs(elbo_g - elbo_o) < 1e-2 + 1e-3 * abs(elbo_o), (elbo_g, elbo_o, worst)
 
 
+def test_c5_shard_shape_matches_oracle():
+    """The composition bench.py --workload c5 times (BASELINE configs[4] per GPU: single-Gaussian target D = 300 with the
+    gmm.py:148-162 law, stm300.yml initial mixture, 312 samples per component, single-call path not eligible -> modular
+    path on the blocked kernels), cut from 64 to 8 components so that the fp64 oracle finishes in seconds: two iterations,
+    state compared after each (parameters 1e-3 of the parameter scale, identical accept / reject decisions)."""
+    import importlib, os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    w = bench.build("c5_k8", 1, 0)
+    assert (w["d"], w["k_total"], w["s"]) == (300, 8, 312)
+    o = bench.make_oracle(w)
+    g = bench.make_gmmvi(w, 1, 0)
+    g.ng_based_updater.want_info = True
+    for it in range(2):
+        info = o.train_iter()
+        g.train_iter()
+        om, gm = o.model, g.model
+        for key, got, ref in (("means", gm.means.numpy(), om.means), ("chols", gm.chol_cov.numpy(), om.chol_cov)):
+            dev = np.abs(got - ref).max() / max(1.0, np.abs(ref).max())
+            assert dev <= 1e-3, f"iteration {it}: {key} deviate by {dev:.2e}"
+        np.testing.assert_allclose(np.exp(gm.log_weights.numpy()), om.weights, atol=1e-3)
+        np.testing.assert_array_equal(g.ng_based_updater.last_success.numpy().astype(bool), info["success"])
+        np.testing.assert_allclose(gm.last_log_etas.numpy(), om.last_log_etas, rtol=1e-2, atol=1e-6)
+        np.testing.assert_allclose(gm.stepsizes.numpy(), om.stepsizes, rtol=1e-6)
+
+
 def test_blocked_runner_flow_stm300():
     """The shipped 300-dimensional Student-t experiment (stm300.yml) through GmmviRunner with the SAMTRON defaults:
     sample reuse, adaptive number of components, Student-t target -- every module on the blocked kernels."""

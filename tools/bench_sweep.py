@@ -40,6 +40,22 @@ def timed(fn):
     return ctx.elapsed_ms(e0, e1) / REPS * 1e3
 
 
+def kernel_only(fn, reps=30):
+    """per-launch HIP-event times of the kernels fn issues (gmmvi_profile_*), us"""
+    import ctypes
+    ctx.check(ctx.lib.gmmvi_profile_enable(ctx.handle, 1))
+    for _ in range(reps):
+        fn()
+    buf = ctypes.create_string_buffer(1 << 16)
+    ctx.check(ctx.lib.gmmvi_profile_report(ctx.handle, buf, len(buf)))
+    ctx.check(ctx.lib.gmmvi_profile_enable(ctx.handle, 0))
+    out = []
+    for line in buf.value.decode().splitlines():
+        name, cnt, ms, _ = line.split()
+        out.append(f"{name} {1e3 * float(ms) / int(cnt):.1f}")
+    return ", ".join(out)
+
+
 t_dual = timed(lambda: hip_ops.mixture_eval_dual(ctx, packed, logw, logw2, x, D))
 t_post = timed(lambda: hip_ops.mixture_eval(ctx, packed, logw, x, D, want_ld=True, want_lp=True))
 t_tgt = timed(lambda: hip_ops.mixture_eval(ctx, tpacked, tlogw, x, D, family=_lib.STUDENT_T, nu=2.0, want_lp=True, want_grad=True))
@@ -55,5 +71,23 @@ err_ld = np.abs(ld.numpy()[:, sub] - cld_o).max() / np.abs(cld_o).max()
 err_lp = np.abs(lp.numpy()[sub] - lq_o).max()
 err_g = np.abs(grad.numpy()[sub] - g_o).max() / np.abs(g_o).max()
 cfg = " ".join(f"{k[6:]}={v}" for k, v in sorted(os.environ.items()) if k.startswith("GMMVI_"))
+k_dual = kernel_only(lambda: hip_ops.mixture_eval_dual(ctx, packed, logw, logw2, x, D))
+k_post = kernel_only(lambda: hip_ops.mixture_eval(ctx, packed, logw, x, D, want_ld=True, want_lp=True))
+k_tgt = kernel_only(lambda: hip_ops.mixture_eval(ctx, tpacked, tlogw, x, D, family=_lib.STUDENT_T, nu=2.0, want_lp=True, want_grad=True))
+print(f"    kernels: dual [{k_dual}]  post [{k_post}]  target [{k_tgt}]")
 print(f"[{cfg}] K={K} D={D} N={N}: dual {t_dual:.1f} us  post {t_post:.1f} us  target {t_tgt:.1f} us | rel err ld {err_ld:.1e} lp {err_lp:.1e} grad {err_g:.1e}",
       flush=True)
+
+if hasattr(ctx.lib, "gmmvi_debug_wg_times"):       # experiment build (-DGMMVI_ME_STAMPS): dispatch ramp of the last dual sweep
+    import ctypes
+    hip_ops.mixture_eval_dual(ctx, packed, logw, logw2, x, D)
+    ctx.sync()
+    nwg = int(os.environ.get("TNWG", 471))
+    buf = (ctypes.c_longlong * (2 * nwg))()
+    ctx.lib.gmmvi_debug_wg_times.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    assert ctx.lib.gmmvi_debug_wg_times(buf, 2 * nwg) == 0
+    t = np.array(buf[:], dtype=np.int64).reshape(nwg, 2)
+    t0 = t[:, 0].min()
+    st, en = (t[:, 0] - t0) * 0.01, (t[:, 1] - t0) * 0.01
+    print(f"workgroup starts (us after the first): median {np.median(st):.2f} p90 {np.percentile(st, 90):.2f} max {st.max():.2f}; "
+          f"ends: min {en.min():.2f} median {np.median(en):.2f} max {en.max():.2f}; life median {np.median(en - st):.2f} max {(en - st).max():.2f}")
