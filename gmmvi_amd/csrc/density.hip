@@ -9,9 +9,9 @@
 #include "common.h"
 #include "combine.h"
 #include "subst.h"
+#include "subst_phased.h"
 #include "blocked.h"
 #include <cmath>
-#include <type_traits>
 #include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -115,6 +115,14 @@ __global__ __launch_bounds__(64) void cholesky_kernel(int D, const float* __rest
 // ---------------------------------------------------------------------------------------------------------------
 // gridDim.y > 1: the components are split over blockIdx.y; lp_out / grad_out then receive per-chunk partials
 // ([chunk][N], [chunk][N][D]) that combine_partials merges.
+typedef float me_f32x4 __attribute__((ext_vector_type(4)));
+// a workgroup barrier for data that travels through LDS only
+#define ME_LDS_BARRIER()                                       \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                          \
+        asm volatile("" ::: "memory");                         \
+    } while (0)
 #ifndef GMMVI_ME_THREADS
 #define GMMVI_ME_THREADS 1024
 #define GMMVI_ME_MINW 1
@@ -158,9 +166,9 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
 #ifdef GMMVI_ME_STAMPS             // experiment builds (tools/bench_sweep.py): phase time stamps of one wave
     if (threadIdx.x == 0) g_me_wg[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
     unsigned long long stamp[16];
-    int nstamp = 0;
+    int nstamp = 0, nbackward = 0;
     const long long wc0 = wall_clock64();
-#define ME_STAMP() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (nstamp < 16) stamp[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ME_STAMP() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (nstamp < 16) stamp[nstamp++] = __builtin_amdgcn_s_memtime(); } while (0)
     ME_STAMP();
 #else
 #define ME_STAMP()
@@ -214,20 +222,26 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
 
     for (int k = k_lo + wave; k < K; k += nwaves) {
         ME_STAMP();
-        PackRef P;
-        P.p = reinterpret_cast<const float4*>(packed + (size_t)k * PK::STRIDE);
-        const float lw = logw[k];
-        float z[DP], q;
-        forward_subst<DP>(P, x, z, q);
+        // the block through a constant-address-space pointer, its loads software-pipelined (subst_phased.h)
+        const sp_block_ptr blk = sp_block(packed + (size_t)k * PK::STRIDE);
+        const float lw = ((sp_const_f32)(uintptr_t)logw)[k];
+        const float lw2 = dual ? ((sp_const_f32)(uintptr_t)logw2)[k] : 0.f;
+        float z[DP], vrd[DP], q, cst;
+        float pc[2][32];
+        SpPass<DP>::forward(blk, x, z, vrd, q, cst, pc);
+        // the rows again for the backward pass, through a pointer the compiler cannot identify with the first one: otherwise it
+        // keeps the values both passes share alive in VGPR lanes instead of loading them again
+        sp_block_ptr blkb = blk;
+        asm volatile("" : "+s"(blkb));
+        if constexpr (GRAD) SpPass<DP>::backward_prefetch(blkb, pc);
         float ld, coef;
         if (FAMILY == GMMVI_GAUSS) {
-            ld = fmaf(-0.5f, q, P[PK::CONST]);
+            ld = fmaf(-0.5f, q, cst);
             coef = -1.f;
         } else {
-            ld = P[PK::CONST] - 0.5f * nud * log1pf(q / nu);
+            ld = cst - 0.5f * nud * log1pf(q / nu);
             coef = -nud / (nu + q);
         }
-        if (ld_out != nullptr && valid) ld_out[(size_t)k * N + n] = ld;
         const float a = ld + lw;
         const float mn = fmaxf(m, a);
         const float sc = __expf(m - mn);
@@ -235,469 +249,95 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
         s = fmaf(s, sc, e);
         m = mn;
         if (dual) {
-            const float a2 = ld + logw2[k];
+            const float a2 = ld + lw2;
             const float mn2 = fmaxf(m2, a2);
             s2 = fmaf(s2, __expf(m2 - mn2), __expf(a2 - mn2));
             m2 = mn2;
         }
-        if (GRAD) {
-            float y[DP];
-            backward_subst<DP>(P, z, y);
+        if constexpr (GRAD) {
+            SpPass<DP>::backward(blkb, z, vrd, pc);
             const float ec = e * coef;
 #pragma unroll
-            for (int i = 0; i < DP; ++i) acc[i] = fmaf(acc[i], sc, ec * y[i]);
+            for (int i = 0; i < DP; ++i) acc[i] = fmaf(acc[i], sc, ec * z[i]);
+            sp_pin<DP>(acc);
         }
+        // (the store comes last: a branch in the middle of the pass would split it into basic blocks, and the optimiser then
+        // sinks the multiply-adds of the backward substitution behind all the loads of its pieces)
+        if (ld_out != nullptr && valid) ld_out[(size_t)k * N + n] = ld;
     }
     ME_STAMP();
     if (lp_out == nullptr && !GRAD) return;
 
-    // merge the W waves' partials: sm_m[w][lane], sm_s[w][lane], sm_acc[w][i][lane]
+    // merge the W waves' partials.  Round 1: the running maxima meet in LDS, every wave rescales ITS sums to the common
+    // maximum (one exp per lane instead of one per (wave, dimension) pair in the reduction); round 2: plain sums in wave
+    // order.  sm_m[w][lane], sm_s[w][lane], sm_acc[w][quad][lane] (four dimensions per 16-byte LDS access).
+    // The barriers wait for LDS traffic only (ME_LDS_BARRIER): __syncthreads() also drains the global stores of the log
+    // densities, ~4 000 cycles at the first barrier (profiles/r03_notes.md).
+    constexpr int NQ = (DP + 3) / 4;
     float* sm_m = sm_merge;
     float* sm_s = sm_merge + nwaves * 64;
-    float* sm_acc = sm_merge + 2 * nwaves * 64;
+    me_f32x4* sm_acc = reinterpret_cast<me_f32x4*>(sm_merge + 2 * nwaves * 64);
+    float* outt = sm_merge + 2 * nwaves * 64 + (GRAD ? (size_t)nwaves * NQ * 256 : 0);       // [64][ldx] tile of the result
+    float* sm_m2 = outt + (GRAD ? 64 * ldx : 0);
+    float* sm_s2 = sm_m2 + nwaves * 64;
     sm_m[wave * 64 + lane] = m;
-    sm_s[wave * 64 + lane] = s;
+    if (dual) sm_m2[wave * 64 + lane] = m2;
+    ME_LDS_BARRIER();
+    ME_STAMP();
+    float M = -3.0e38f, M2 = -3.0e38f;
+    for (int w = 0; w < nwaves; ++w) M = fmaxf(M, sm_m[w * 64 + lane]);
+    const float f = __expf(m - M);
+    sm_s[wave * 64 + lane] = s * f;
+    if (dual) {
+        for (int w = 0; w < nwaves; ++w) M2 = fmaxf(M2, sm_m2[w * 64 + lane]);
+        sm_s2[wave * 64 + lane] = s2 * __expf(m2 - M2);
+    }
     if (GRAD) {
 #pragma unroll
-        for (int i = 0; i < DP; ++i) sm_acc[(wave * DP + i) * 64 + lane] = acc[i];
-    }
-    __syncthreads();
-    float M = -3.0e38f;
-    for (int w = 0; w < nwaves; ++w) M = fmaxf(M, sm_m[w * 64 + lane]);
-    float S = 0.f;
-    for (int w = 0; w < nwaves; ++w) S += sm_s[w * 64 + lane] * __expf(sm_m[w * 64 + lane] - M);
-    if (wave == 0 && valid && lp_out != nullptr) lp_out[n] = M + __logf(S);
-    if (dual) {
-        float* sm_m2 = sm_merge + (size_t)nwaves * 64 * ((GRAD ? DP : 0) + 2) + (GRAD ? 64 * ldx : 0);
-        float* sm_s2 = sm_m2 + nwaves * 64;
-        sm_m2[wave * 64 + lane] = m2;
-        sm_s2[wave * 64 + lane] = s2;
-        __syncthreads();
-        if (wave == 0 && valid && lp2_out != nullptr) {
-            float M2 = -3.0e38f;
-            for (int w = 0; w < nwaves; ++w) M2 = fmaxf(M2, sm_m2[w * 64 + lane]);
-            float S2 = 0.f;
-            for (int w = 0; w < nwaves; ++w) S2 += sm_s2[w * 64 + lane] * __expf(sm_m2[w * 64 + lane] - M2);
-            lp2_out[n] = M2 + __logf(S2);
+        for (int q4 = 0; q4 < NQ; ++q4) {
+            me_f32x4 v4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v4[c] = 4 * q4 + c < DP ? acc[4 * q4 + c] * f : 0.f;
+            sm_acc[(wave * NQ + q4) * 64 + lane] = v4;
         }
+    }
+    ME_STAMP();
+    ME_LDS_BARRIER();
+    ME_STAMP();
+    float S = 0.f;
+    for (int w = 0; w < nwaves; ++w) S += sm_s[w * 64 + lane];
+    if (wave == 0 && valid && lp_out != nullptr) lp_out[n] = M + __logf(S);
+    if (dual && wave == (nwaves > 1 ? 1 : 0) && valid && lp2_out != nullptr) {
+        float S2 = 0.f;
+        for (int w = 0; w < nwaves; ++w) S2 += sm_s2[w * 64 + lane];
+        lp2_out[n] = M2 + __logf(S2);
     }
     if (GRAD && grad_out != nullptr) {
         const float inv = 1.f / S;
-        // wave w reduces dimensions w, w + W, ...; results go to a [64][ldx] tile and leave coalesced
-        float* outt = sm_acc + (size_t)nwaves * DP * 64;
-        for (int i = wave; i < D; i += nwaves) {
-            float g = 0.f;
-            for (int w = 0; w < nwaves; ++w) g += sm_acc[(w * DP + i) * 64 + lane] * __expf(sm_m[w * 64 + lane] - M);
-            outt[lane * ldx + i] = g * inv;
+        // wave w reduces the dimension quads w, w + W, ...; results go to the [64][ldx] tile and leave coalesced
+        for (int q4 = wave; q4 < NQ; q4 += nwaves) {
+            me_f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
+            for (int w = 0; w < nwaves; ++w) g4 += sm_acc[(w * NQ + q4) * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (4 * q4 + c < D) outt[lane * ldx + 4 * q4 + c] = g4[c] * inv;
         }
-        __syncthreads();
+        ME_STAMP();
+        ME_LDS_BARRIER();
+        ME_STAMP();
         for (int e = threadIdx.x; e < n_here * D; e += blockDim.x)
             grad_out[(size_t)n0 * D + e] = outt[(e / D) * ldx + (e % D)];
     }
 #ifdef GMMVI_ME_STAMPS
     ME_STAMP();
     if (threadIdx.x == 0) g_me_wg[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
-    if (GRAD && logw2 && blockIdx.x == 60 && blockIdx.y == 1 && threadIdx.x == 64 * 3 && g_me_wg[2 * 8192 - 1]++ < 2) {
+    if (GRAD && logw2 && blockIdx.x == 60 && blockIdx.y == 1 && threadIdx.x == 64 * 3 && (g_me_wg[2 * 8192 - 1]++ & 15) == 12) {
         const long long wc1 = wall_clock64();
         printf("me stamps (shader cycles; kernel %lld x 10 ns by the 100 MHz clock):", wc1 - wc0);
         for (int i = 1; i < nstamp; ++i) printf(" %llu", stamp[i] - stamp[i - 1]);
-        printf("  total %llu\n", stamp[nstamp - 1] - stamp[0]);
+        printf("  total %llu, backward passes %d\n", stamp[nstamp - 1] - stamp[0], nbackward);
     }
 #endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// mixture_eval, lockstep scalar-fed form (padded D <= 24)
-// ---------------------------------------------------------------------------------------------------------------
-// The kernel above is a chain of scalar-load round trips: every wave of a workgroup walks its OWN components, the blocks of
-// a chunk (34 x 1.7 KB at the north star) do not stay in the 16 KB scalar cache, the ~22 `s_load` of a component pass each
-// go to the L2 and -- scalar loads return out of order -- each is waited for with lgkmcnt(0): ~22 dependent L2 round trips per
-// (wave, component).  Here the waves of a workgroup are arranged as T sample tiles x G component streams and all walk the
-// chunk in the same order: at any time the workgroup touches G blocks, which therefore stay in the scalar cache for the
-// T waves that share them; only the row-packed triangle is read (forward substitution in dot form over the rows, backward
-// substitution in axpy form over the same rows, descending: 0.9 KB instead of 1.7 KB a block); and the lines of the blocks
-// that come next are touched ahead (`s_load_dword` into a sink register) by one extra FEEDER wave per workgroup that paces
-// itself on the progress counters of the compute waves, so that the L2 latency is paid once per block and off the compute
-// waves.  (The touches cannot live in the compute waves: the compiler may spill the sink and reuse its physical register
-// while touches are still in flight -- a late return then overwrites a live value.)  The G streams of a tile are merged through LDS as above.
-// The block through a CONSTANT-address-space pointer: uniform loads from it are scalar loads whatever else the loop contains
-// (the `asm volatile` touches below count as possible writers of global memory, which turns uniform GLOBAL loads into
-// per-lane vector loads); the blocks are not written during the launch.
-typedef float ls_f32x4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(4))) ls_f32x4* ls_cf4p;
-struct PackRefConst {
-    ls_cf4p p;
-    __device__ __forceinline__ float operator[](int idx) const {
-        const ls_f32x4 v = p[idx >> 2];
-        return v[idx & 3];
-    }
-};
-
-// ---- phased component pass: the row stream of L in pieces of 32 floats, the next piece in flight while the current one is
-// multiplied.  Scalar loads return out of order, so every wait is lgkmcnt(0): the wait for a piece must come BEFORE the loads
-// of the next piece are issued (an empty asm that takes the piece's registers as operands forces it there), and scheduling
-// barriers keep the compiler from moving the loads back down to their first use.
-template <int B, int E, typename F>
-__device__ __forceinline__ void ls_static_for(F&& f) {
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        ls_static_for<B + 1, E>(f);
-    }
-}
-template <int B, int E, typename F>
-__device__ __forceinline__ void ls_static_for_down(F&& f) {         // E - 1, E - 2, ..., B
-    if constexpr (B < E) {
-        f(std::integral_constant<int, E - 1>{});
-        ls_static_for_down<B, E - 1>(f);
-    }
-}
-__host__ __device__ constexpr int ls_row(int e) { int i = 1; while ((i + 1) * i / 2 <= e) ++i; return i; }   // element e of the strict lower triangle, row-major
-__host__ __device__ constexpr int ls_col(int e) { return e - ls_row(e) * (ls_row(e) - 1) / 2; }
-#define LS_S4(a, o) "s"(a[o]), "s"(a[(o) + 1]), "s"(a[(o) + 2]), "s"(a[(o) + 3])
-template <int NL>
-__device__ __forceinline__ void ls_landed(const float (&a)[32]) {   // the registers of a piece hold its data from here on
-    static_assert(NL % 4 == 0 && NL >= 4 && NL <= 32, "piece length");
-    asm volatile("" ::LS_S4(a, 0));
-    if constexpr (NL > 4) asm volatile("" ::LS_S4(a, 4));
-    if constexpr (NL > 8) asm volatile("" ::LS_S4(a, 8));
-    if constexpr (NL > 12) asm volatile("" ::LS_S4(a, 12));
-    if constexpr (NL > 16) asm volatile("" ::LS_S4(a, 16));
-    if constexpr (NL > 20) asm volatile("" ::LS_S4(a, 20));
-    if constexpr (NL > 24) asm volatile("" ::LS_S4(a, 24));
-    if constexpr (NL > 28) asm volatile("" ::LS_S4(a, 28));
-}
-// the values of a register array are complete HERE (an empty asm that reads and "writes" them): keeps the optimiser from
-// sinking the multiply-adds of a piece below the loads of the following pieces, towards their last use
-#define LS_V4(a, o) "+v"(a[o]), "+v"(a[(o) + 1]), "+v"(a[(o) + 2]), "+v"(a[(o) + 3])
-template <int N>
-__device__ __forceinline__ void ls_pin(float (&a)[N]) {
-    static_assert(N % 2 == 0 && N <= 24, "padded dimension");
-    if constexpr (N >= 4) asm volatile("" : LS_V4(a, 0));
-    if constexpr (N >= 8) asm volatile("" : LS_V4(a, 4));
-    if constexpr (N >= 12) asm volatile("" : LS_V4(a, 8));
-    if constexpr (N >= 16) asm volatile("" : LS_V4(a, 12));
-    if constexpr (N >= 20) asm volatile("" : LS_V4(a, 16));
-    if constexpr (N >= 24) asm volatile("" : LS_V4(a, 20));
-    if constexpr (N % 4 == 2) asm volatile("" : "+v"(a[N - 2]), "+v"(a[N - 1]));
-}
-template <int N, int O = 0>
-__device__ __forceinline__ void ls_landed_arr(const float (&a)[N]) {
-    static_assert(N % 4 == 0, "array length");
-    if constexpr (O < N) {
-        asm volatile("" ::LS_S4(a, O));
-        ls_landed_arr<N, O + 4>(a);
-    }
-}
-template <int DP, int PIECE>
-struct LsPiece {
-    static constexpr int T = DP * (DP - 1) / 2;
-    static constexpr int NP = (T + 31) / 32;                                   // pieces of the row stream
-    static constexpr int NV = T - 32 * PIECE < 32 ? T - 32 * PIECE : 32;       // elements of this piece
-    static constexpr int NL = (NV + 3) / 4 * 4;                                // floats fetched (whole 16-byte words; the tail lies in the block)
-};
-template <int DP, int PIECE, typename PR>
-__device__ __forceinline__ void ls_fetch_piece(const PR& P, float (&a)[32]) {
-    using PK = Pack<DP>;
-#pragma unroll
-    for (int u = 0; u < LsPiece<DP, PIECE>::NL; ++u) a[u] = P[PK::LROW + 32 * PIECE + u];
-}
-
-template <int DP>
-__device__ __forceinline__ void ls_touch_block(const float* blk, int& sink) {
-    using PK = Pack<DP>;
-    constexpr int BYTES = (2 * DP + PK::T) * 4;         // mu | 1 / diag | strict lower triangle by rows
-    constexpr int LINES = BYTES / 64 + 2;               // blocks are 16-byte aligned only: a partial line at either end
-#pragma unroll
-    for (int l = 0; l < LINES; ++l)
-        asm volatile("s_load_dword %0, %1, %2" : "+s"(sink) : "s"(blk), "n"(l * 64 < BYTES ? l * 64 : BYTES - 4));
-    asm volatile("s_load_dword %0, %1, %2" : "+s"(sink) : "s"(blk), "n"(PK::CONST * 4));
-}
-// the sink register may be reused only after the touches have landed
-__device__ __forceinline__ void ls_touch_release(int& sink) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink)); }
-
-template <int DP, int FAMILY, bool GRAD, bool PHASED>
-__global__ __launch_bounds__(1024) void mixture_eval_ls_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
-                                                               const float* __restrict__ logw, const float* __restrict__ X,
-                                                               int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
-                                                               float* __restrict__ grad_out, const float* __restrict__ logw2,
-                                                               float* __restrict__ lp2_out, CombineJob carried, int T, int G,
-                                                               int feeder, int ahead) {
-    using PK = Pack<DP>;
-    extern __shared__ __align__(16) float sm[];
-    __shared__ int prog[16];                           // components done per compute wave (read by the feeder)
-    const bool samek = (ahead & 256) != 0;             // experiment: every pass reads the chunk's first block
-    ahead &= 255;
-    if (combine_carried(carried)) return;              // workgroups past the sample tiles: the merge of the previous sweep
-    const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
-    const int k_lo = blockIdx.y * kchunk;
-    const int K = min(K_total, k_lo + kchunk);
-    if (gridDim.y > 1) {
-        if (lp_out) lp_out += (size_t)blockIdx.y * N;
-        if (lp2_out) lp2_out += (size_t)blockIdx.y * N;
-        if (GRAD && grad_out) grad_out += (size_t)blockIdx.y * N * D;
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int W = T * G;                               // compute waves; wave W (if any) is the feeder
-    const bool is_feeder = wave >= W;
-    const int t = is_feeder ? 0 : wave / G, g = is_feeder ? 0 : wave - t * G;
-    const int tile = blockIdx.x * T + t;
-    const int n0 = tile * 64;
-    const int n_here = is_feeder ? 0 : max(0, min(64, N - n0));
-    const int n = n0 + lane;
-    const bool valid = lane < n_here;
-    const int steps = (K - k_lo + G - 1) / G;          // component passes of a stream
-    if (threadIdx.x < 16) prog[threadIdx.x] = 0x7fffffff;
-    __syncthreads();
-    if (!is_feeder && lane == 0) prog[wave] = n_here > 0 ? 0 : 0x7fffffff;
-    __syncthreads();
-
-    float m = -3.0e38f, s = 0.f;
-    float m2 = -3.0e38f, s2 = 0.f;                      // second mixture over the same components (logw2), optional
-    const bool dual = logw2 != nullptr;
-    float acc[GRAD ? DP : 1];
-    if (GRAD) {
-#pragma unroll
-        for (int i = 0; i < DP; ++i) acc[i] = 0.f;
-    }
-    if (is_feeder) {
-        int sink = 0;
-        for (int st = 0; st < steps; ++st) {
-            // stay at most `ahead` passes in front of the slowest compute wave (its counter only grows; a finished or idle
-            // wave reads as infinity, so this loop ends when the compute waves do)
-            while (true) {
-                int p = lane < 16 ? ((volatile int*)prog)[lane] : 0x7fffffff;
-#pragma unroll
-                for (int o = 8; o >= 1; o >>= 1) p = min(p, __shfl_xor(p, o));
-                if (__builtin_amdgcn_readfirstlane(p) >= st - ahead) break;       // (no p + ahead: idle waves read as INT_MAX)
-                __builtin_amdgcn_s_sleep(4);
-            }
-            for (int gg = 0; gg < G; ++gg) {
-                const int k = k_lo + st * G + gg;
-                if (k < K) ls_touch_block<DP>(packed + (size_t)k * PK::STRIDE, sink);
-            }
-            ls_touch_release(sink);
-        }
-    } else if (n_here > 0) {
-        // ---- the lane's sample row: whole 16- / 8-byte pieces where the row allows it (consecutive lanes walk consecutive
-        // rows: the loads of a row share cache lines, the G waves of a tile hit in L1) -------------------------------------
-        float x[DP];
-        const int nr = min(n, N - 1);
-        if (DP % 4 == 0 && D == DP && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
-            const float4* xrow = reinterpret_cast<const float4*>(X + (size_t)nr * D);
-#pragma unroll
-            for (int q4 = 0; q4 < DP / 4; ++q4) {
-                const float4 v4 = xrow[q4];
-                x[4 * q4] = v4.x; x[4 * q4 + 1] = v4.y; x[4 * q4 + 2] = v4.z; x[4 * q4 + 3] = v4.w;
-            }
-        } else if (DP % 2 == 0 && D == DP && (reinterpret_cast<uintptr_t>(X) & 7) == 0) {
-            const float2* xrow = reinterpret_cast<const float2*>(X + (size_t)nr * D);
-#pragma unroll
-            for (int q2 = 0; q2 < DP / 2; ++q2) {
-                const float2 v2 = xrow[q2];
-                x[2 * q2] = v2.x; x[2 * q2 + 1] = v2.y;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < DP; ++i) x[i] = i < D ? X[(size_t)nr * D + i] : 0.f;
-        }
-        if (!valid) {
-#pragma unroll
-            for (int i = 0; i < DP; ++i) x[i] = 0.f;
-        }
-        const float nud = nu + (float)D;
-        int st = 0;
-        for (int k = k_lo + g; k < K; k += G, ++st) {
-            const float* blk = packed + (size_t)(samek ? k_lo : k) * PK::STRIDE;
-            PackRefConst P;
-            P.p = (ls_cf4p)(uintptr_t)blk;
-            const float lw = ((const __attribute__((address_space(4))) float*)(uintptr_t)logw)[k];
-            const float lw2 = dual ? ((const __attribute__((address_space(4))) float*)(uintptr_t)logw2)[k] : 0.f;
-            float z[DP], q = 0.f;
-            float ld, coef, e, sc;
-            if constexpr (PHASED && DP >= 4) {
-                constexpr int T = PK::T, NP = LsPiece<DP, 0>::NP;
-                // mu | 1 / diag and the first piece of the row stream: one wait
-                float head[2 * DP], vrd[DP];
-                float pc[2][32];
-#pragma unroll
-                for (int u = 0; u < 2 * DP; ++u) head[u] = P[u];
-                ls_fetch_piece<DP, 0>(P, pc[0]);
-                __builtin_amdgcn_sched_barrier(0);
-                ls_landed_arr<2 * DP>(head);
-                ls_landed<LsPiece<DP, 0>::NL>(pc[0]);
-#pragma unroll
-                for (int i = 0; i < DP; ++i) {
-                    z[i] = x[i] - head[PK::MU + i];
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(vrd[i]) : "s"(head[PK::RD + i]));     // a VGPR copy: frees the SGPRs
-                }
-                z[0] *= vrd[0];
-                q = z[0] * z[0];
-                // forward, dot form over the rows: u_i -= L_ij z_j;  at the end of row i: z_i = u_i / L_ii
-                ls_static_for<0, NP>([&](auto PCE) {
-                    constexpr int pce = PCE;
-                    if constexpr (pce + 1 < NP) ls_fetch_piece<DP, pce + 1>(P, pc[(pce + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    ls_static_for<0, LsPiece<DP, pce>::NV>([&](auto U) {
-                        constexpr int el = 32 * pce + U, i = ls_row(el), j = ls_col(el);
-                        z[i] = fmaf(-pc[pce & 1][U], z[j], z[i]);
-                        if constexpr (j == i - 1) {
-                            z[i] *= vrd[i];
-                            q = fmaf(z[i], z[i], q);
-                        }
-                    });
-                    ls_pin<DP>(z);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (pce + 1 < NP) ls_landed<LsPiece<DP, pce + 1>::NL>(pc[(pce + 1) & 1]);
-                });
-                const float cst = P[PK::CONST];
-                // the same rows again for the backward pass, through a pointer the compiler cannot identify with the first one:
-                // otherwise it keeps all T values of the forward pass alive (spilled to VGPR lanes) instead of loading them again
-                PackRefConst Pb = P;
-                asm volatile("" : "+s"(Pb.p));
-                if constexpr (GRAD) ls_fetch_piece<DP, NP - 1>(Pb, pc[(NP - 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                if (FAMILY == GMMVI_GAUSS) {
-                    ld = fmaf(-0.5f, q, cst);
-                    coef = -1.f;
-                } else {
-                    ld = cst - 0.5f * nud * log1pf(q / nu);
-                    coef = -nud / (nu + q);
-                }
-                const float a = ld + lw;
-                const float mn = fmaxf(m, a);
-                sc = __expf(m - mn);
-                e = __expf(a - mn);
-                s = fmaf(s, sc, e);
-                m = mn;
-                if (dual) {
-                    const float a2 = ld + lw2;
-                    const float mn2 = fmaxf(m2, a2);
-                    s2 = fmaf(s2, __expf(m2 - mn2), __expf(a2 - mn2));
-                    m2 = mn2;
-                }
-                if constexpr (GRAD) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    ls_landed<LsPiece<DP, NP - 1>::NL>(pc[(NP - 1) & 1]);
-                    // backward, axpy form over the same rows in descending order: y_i = z_i / L_ii, then z_j -= L_ij y_i
-                    ls_static_for_down<0, NP>([&](auto PCE) {
-                        constexpr int pce = PCE;
-                        if constexpr (pce > 0) ls_fetch_piece<DP, pce - 1>(Pb, pc[(pce - 1) & 1]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        ls_static_for_down<0, LsPiece<DP, pce>::NV>([&](auto U) {
-                            constexpr int el = 32 * pce + U, i = ls_row(el), j = ls_col(el);
-                            if constexpr (j == i - 1) z[i] *= vrd[i];
-                            z[j] = fmaf(-pc[pce & 1][U], z[i], z[j]);
-                        });
-                        ls_pin<DP>(z);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (pce > 0) ls_landed<LsPiece<DP, pce - 1>::NL>(pc[(pce - 1) & 1]);
-                    });
-                    z[0] *= vrd[0];
-                    const float ec = e * coef;
-#pragma unroll
-                    for (int i = 0; i < DP; ++i) acc[i] = fmaf(acc[i], sc, ec * z[i]);
-                    ls_pin<DP>(acc);
-                }
-            } else {
-            // z = L^-1 (x - mu) by the rows of L (dot form), q = |z|^2
-#pragma unroll
-            for (int i = 0; i < DP; ++i) {
-                float tt = x[i] - P[PK::MU + i];
-#pragma unroll
-                for (int j = 0; j < i; ++j) tt = fmaf(-P[PK::LROW + PK::rowofs(i) + j], z[j], tt);
-                z[i] = tt * P[PK::RD + i];
-                q = fmaf(z[i], z[i], q);
-            }
-            if (FAMILY == GMMVI_GAUSS) {
-                ld = fmaf(-0.5f, q, P[PK::CONST]);
-                coef = -1.f;
-            } else {
-                ld = P[PK::CONST] - 0.5f * nud * log1pf(q / nu);
-                coef = -nud / (nu + q);
-            }
-            const float a = ld + lw;
-            const float mn = fmaxf(m, a);
-            sc = __expf(m - mn);
-            e = __expf(a - mn);
-            s = fmaf(s, sc, e);
-            m = mn;
-            if (dual) {
-                const float a2 = ld + lw2;
-                const float mn2 = fmaxf(m2, a2);
-                s2 = fmaf(s2, __expf(m2 - mn2), __expf(a2 - mn2));
-                m2 = mn2;
-            }
-            if (GRAD) {
-                // y = L^-T z in place, by the ROWS of L in descending order: y_i = z_i / L_ii, then z_j -= L_ij y_i (j < i)
-                PackRefConst Pb = P;                   // (an opaque copy: see the phased branch)
-                asm volatile("" : "+s"(Pb.p));
-#pragma unroll
-                for (int i = DP - 1; i >= 0; --i) {
-                    const float yi = z[i] * Pb[PK::RD + i];
-                    z[i] = yi;
-#pragma unroll
-                    for (int j = 0; j < i; ++j) z[j] = fmaf(-Pb[PK::LROW + PK::rowofs(i) + j], yi, z[j]);
-                }
-                const float ec = e * coef;
-#pragma unroll
-                for (int i = 0; i < DP; ++i) acc[i] = fmaf(acc[i], sc, ec * z[i]);
-            }
-            }
-            // (the store comes last: a branch in the middle of the pass splits it into basic blocks and the backward
-            // multiply-adds then end up behind all the loads of their pieces)
-            if (ld_out != nullptr && valid) ld_out[(size_t)k * N + n] = ld;
-            if (lane == 0) ((volatile int*)prog)[wave] = st + 1;
-        }
-        if (lane == 0) ((volatile int*)prog)[wave] = 0x7fffffff;
-    }
-    if (lp_out == nullptr && !GRAD) return;
-
-    // merge the G streams of every tile: sm_m[w][lane], sm_s[w][lane], sm_acc[w][i][lane]   (w = t G + g)
-    const int ldx = D | 1;
-    float* sm_m = sm;
-    float* sm_s = sm + W * 64;
-    float* sm_acc = sm + 2 * W * 64;
-    float* sm_m2 = sm_acc + (GRAD ? (size_t)W * DP * 64 + (size_t)T * 64 * ldx : 0);
-    float* sm_s2 = sm_m2 + W * 64;
-    if (!is_feeder) {
-        sm_m[wave * 64 + lane] = m;
-        sm_s[wave * 64 + lane] = s;
-        if (dual) { sm_m2[wave * 64 + lane] = m2; sm_s2[wave * 64 + lane] = s2; }
-        if (GRAD) {
-#pragma unroll
-            for (int i = 0; i < DP; ++i) sm_acc[(wave * DP + i) * 64 + lane] = acc[i];
-        }
-    }
-    __syncthreads();
-    float M = -3.0e38f, S = 0.f;
-    if (!is_feeder) {
-        for (int w = t * G; w < t * G + G; ++w) M = fmaxf(M, sm_m[w * 64 + lane]);
-        for (int w = t * G; w < t * G + G; ++w) S += sm_s[w * 64 + lane] * __expf(sm_m[w * 64 + lane] - M);
-        if (g == 0 && valid && lp_out != nullptr) lp_out[n] = M + __logf(S);
-        if (dual && g == (G > 1 ? 1 : 0) && valid && lp2_out != nullptr) {
-            float M2 = -3.0e38f, S2 = 0.f;
-            for (int w = t * G; w < t * G + G; ++w) M2 = fmaxf(M2, sm_m2[w * 64 + lane]);
-            for (int w = t * G; w < t * G + G; ++w) S2 += sm_s2[w * 64 + lane] * __expf(sm_m2[w * 64 + lane] - M2);
-            lp2_out[n] = M2 + __logf(S2);
-        }
-    }
-    if (GRAD && grad_out != nullptr) {
-        float* outt = sm_acc + (size_t)W * DP * 64 + (size_t)t * 64 * ldx;
-        if (!is_feeder) {
-            const float inv = 1.f / S;
-            // stream g reduces dimensions g, g + G, ...; results go to the tile's [64][ldx] image and leave coalesced
-            for (int i = g; i < D; i += G) {
-                float gsum = 0.f;
-                for (int w = t * G; w < t * G + G; ++w) gsum += sm_acc[(w * DP + i) * 64 + lane] * __expf(sm_m[w * 64 + lane] - M);
-                outt[lane * ldx + i] = gsum * inv;
-            }
-        }
-        __syncthreads();
-        if (!is_feeder)
-            for (int e = g * 64 + lane; e < n_here * D; e += 64 * G)
-                grad_out[(size_t)n0 * D + e] = outt[(e / D) * ldx + (e % D)];
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -712,7 +352,6 @@ __global__ __launch_bounds__(1024) void mixture_eval_ls_kernel(float nu, int K_t
 // lane's k-steps are contiguous) to become the B operand of the transposed contraction.  Structural zeros of the triangle
 // are skipped per 16 x 4 fragment.  The log-sum-exp over the components, the K split over blockIdx.y and the merge of the
 // workgroup's waves are those of the scalar-fed kernel.
-typedef float me_f32x4 __attribute__((ext_vector_type(4)));
 
 #define ME_WAVE_LDS_SYNC()                                     \
     do {                                                       \
@@ -1388,96 +1027,6 @@ static int launch_mixture_eval_mfma_ws(gmmvi_ctx* ctx, int family, float nu, int
     return GMMVI_OK;
 }
 
-// lockstep scalar-fed form: T sample tiles x G component streams (+ the feeder wave) per workgroup, ky component chunks
-template <int DP>
-static int launch_mixture_eval_ls(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
-                                  const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
-                                  const float* logw2, float* lp2) {
-    const bool want_grad = grad != nullptr;
-    const bool want_merge = want_grad || lp != nullptr;
-    static const int env_t = getenv("GMMVI_LS_T") ? atoi(getenv("GMMVI_LS_T")) : 0;
-    static const int env_g = getenv("GMMVI_LS_G") ? atoi(getenv("GMMVI_LS_G")) : 0;
-    static const int env_ky = getenv("GMMVI_LS_KY") ? atoi(getenv("GMMVI_LS_KY")) : 0;
-    static const int env_feeder = getenv("GMMVI_LS_FEEDER") ? atoi(getenv("GMMVI_LS_FEEDER")) : 1;
-    static const int env_ahead = (getenv("GMMVI_LS_AHEAD") ? atoi(getenv("GMMVI_LS_AHEAD")) : 2) |
-                                 (getenv("GMMVI_LS_SAMEK") && atoi(getenv("GMMVI_LS_SAMEK")) ? 256 : 0);
-    static const int env_wgs = getenv("GMMVI_LS_WGS_PER_CU") ? atoi(getenv("GMMVI_LS_WGS_PER_CU")) : 2;
-    static const int env_phased = getenv("GMMVI_LS_PHASED") ? atoi(getenv("GMMVI_LS_PHASED")) : 1;
-    const int tiles = (N + 63) / 64;
-    int T = env_t > 0 ? env_t : 4, G = env_g > 0 ? env_g : 2;
-    if (T > tiles) T = tiles;
-    if (G > K) G = K;
-    if (T * G > 16) T = 16 / G > 0 ? 16 / G : 1;
-    const int tgroups = (tiles + T - 1) / T;
-    // component chunks over blockIdx.y so that ~env_wgs workgroups per CU are in flight; every stream keeps >= 2 passes
-    int ky = 1;
-    if (env_ky > 0) ky = env_ky;
-    else if ((long)tgroups < (long)env_wgs * ctx->num_cus) ky = (int)(((long)env_wgs * ctx->num_cus + tgroups / 2) / tgroups);
-    if (ky > K / (2 * G)) ky = K / (2 * G);
-    if (ky < 1) ky = 1;
-    const int kchunk = (K + ky - 1) / ky;
-    ky = (K + kchunk - 1) / kchunk;
-    if (G > kchunk) G = kchunk;
-    const int W = T * G;
-    const int feeder = (env_feeder && kchunk > G) ? 1 : 0;        // a single pass per stream has nothing to run ahead of
-    const int ldx = D | 1;
-    const size_t shmem = ((size_t)W * 64 * (2 + (want_grad ? DP : 0)) + (want_grad ? (size_t)T * 64 * ldx : 0) +
-                          (logw2 ? (size_t)W * 128 : 0)) * sizeof(float);
-    float* lp_k = lp;
-    float* grad_k = grad;
-    float* lp2_k = lp2;
-    const bool defer = ctx->defer_combine && ky > 1 && want_merge;
-    if (defer) {
-        int rc = gmmvi_flush_pending_combine(ctx);
-        if (rc != GMMVI_OK) return rc;
-    }
-    if (ky > 1 && want_merge) {
-        size_t need = ((size_t)ky * N * (logw2 ? 2 : 1) + (want_grad ? (size_t)ky * N * D : 0)) * sizeof(float);
-        int rc = defer ? gmmvi_defer_reserve(ctx, need) : gmmvi_ws_reserve(ctx, need);
-        if (rc != GMMVI_OK) return rc;
-        lp_k = (float*)(defer ? ctx->defer_ws : ctx->ws);
-        lp2_k = logw2 ? lp_k + (size_t)ky * N : nullptr;
-        grad_k = want_grad ? lp_k + (size_t)ky * N * (logw2 ? 2 : 1) : nullptr;
-    }
-    const int threads = 64 * (W + feeder);
-    const CombineJob carried = gmmvi_take_pending_combine(ctx, threads, tgroups);
-    dim3 grid(tgroups + carried.blocks, ky), block(threads);
-    {
-        GMMVI_PROF_UNITS(ctx, sweep_prof_name(ctx, want_grad, logw2 != nullptr), (double)N * K);
-#define GMMVI_LAUNCH_LS2(FAM, GR, PH)                                                                               \
-    do {                                                                                                            \
-        if (shmem > 64 * 1024)                                                                                      \
-            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_ls_kernel<DP, FAM, GR, PH>,          \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
-        hipLaunchKernelGGL((mixture_eval_ls_kernel<DP, FAM, GR, PH>), grid, block, shmem, ctx->stream, nu, K, D,    \
-                           packed, logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried, T, G, feeder, env_ahead);    \
-    } while (0)
-#define GMMVI_LAUNCH_LS(FAM, GR)                                                                                    \
-    do {                                                                                                            \
-        if (env_phased) GMMVI_LAUNCH_LS2(FAM, GR, true); else GMMVI_LAUNCH_LS2(FAM, GR, false);                     \
-    } while (0)
-        if (family == GMMVI_GAUSS) {
-            if (want_grad) GMMVI_LAUNCH_LS(GMMVI_GAUSS, true); else GMMVI_LAUNCH_LS(GMMVI_GAUSS, false);
-        } else {
-            if (want_grad) GMMVI_LAUNCH_LS(GMMVI_STUDENT_T, true); else GMMVI_LAUNCH_LS(GMMVI_STUDENT_T, false);
-        }
-#undef GMMVI_LAUNCH_LS
-#undef GMMVI_LAUNCH_LS2
-    }
-    GMMVI_LAUNCH_CHECK(ctx);
-    if (defer) {
-        CombineJob& j = ctx->pending;
-        j.R = ky; j.N = N; j.D = D;
-        j.lp_parts = lp_k; j.grad_parts = grad_k; j.lp2_parts = lp2_k;
-        j.lp_out = lp; j.grad_out = grad; j.lp2_out = lp2_k ? lp2 : nullptr;
-    } else if (ky > 1 && want_merge) {
-        GMMVI_PROF(ctx, "mixture_combine");
-        int rc = gmmvi_combine_partials_internal(ctx, ky, N, D, lp_k, grad_k, lp, grad, lp2_k, lp2);
-        if (rc != GMMVI_OK) return rc;
-    }
-    return GMMVI_OK;
-}
-
 template <int DP>
 static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
                                const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
@@ -1501,14 +1050,12 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         }
         return launch_mixture_eval_mfma<DP, 4>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
     } else {
-    static const int env_ls = getenv("GMMVI_LS") ? atoi(getenv("GMMVI_LS")) : 1;
-    if (env_ls) return launch_mixture_eval_ls<DP>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
     const bool want_grad = grad != nullptr;
     const bool want_merge = want_grad || lp != nullptr;
     static const int env_nw = getenv("GMMVI_ME_NW") ? atoi(getenv("GMMVI_ME_NW")) : 0;
     static const int env_ky = getenv("GMMVI_ME_KY") ? atoi(getenv("GMMVI_ME_KY")) : 0;
     auto lds_floats = [&](int nw) {
-        size_t merge = (size_t)nw * 64 * ((want_grad ? DP : 0) + 2) + (want_grad ? 64 * (size_t)(D | 1) : 0) +
+        size_t merge = (size_t)nw * 64 * ((want_grad ? (DP + 3) / 4 * 4 : 0) + 2) + (want_grad ? 64 * (size_t)(D | 1) : 0) +
                        (logw2 ? (size_t)nw * 128 : 0);
         size_t stage = 64 * (size_t)(D | 1);
         return merge > stage ? merge : stage;
@@ -1534,6 +1081,8 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     if (nw > nw_max) nw = nw_max;
     while (nw > 1 && lds_floats(nw) * 4 > 96 * 1024) --nw;
     size_t shmem = lds_floats(nw) * 4;
+    static const size_t env_shmem_min = getenv("GMMVI_ME_SHMEM_MIN") ? (size_t)atol(getenv("GMMVI_ME_SHMEM_MIN")) : 0;   // experiments: caps the workgroups per CU
+    if (shmem < env_shmem_min) shmem = env_shmem_min;
     float* lp_k = lp;
     float* grad_k = grad;
     float* lp2_k = lp2;
