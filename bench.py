@@ -34,6 +34,9 @@ WORKLOADS = {
     "c2": ("stm", 20, 50, 100),        # BASELINE configs[1]: K=50, N=5000
     "c3": ("gmm", 50, 100, 100),       # BASELINE configs[2]: GMM target D=50, K=100, N=10k
     "c4": ("planar", 10, 200, 100),    # BASELINE configs[3] on one GPU: planar-4, K=200, N=20k
+    # the north-star shape with the reference's DEFAULT selector (component-based.yml:3-4: reuse ratio 2): ~3 N active samples,
+    # data-dependent numbers of new samples (one [K] read-back per iteration), separate background sweep over ~3 K snapshots
+    "ns_reuse2": ("stm", 20, 100, 100, "Stein", 2.0),
     "ns_more": ("stm", 20, 100, 100, "MORE"),   # north-star shape with the MORE estimator ("ZAMTRON") instead of Stein
     "c3_more": ("gmm", 50, 100, 100, "MORE"),   # C3 shape with MORE: F = 1326 features per component (tiled Gram + blocked fp64 Cholesky)
     # BASELINE configs[4] per GPU: D=300 single-Gaussian target (make_target_with_scale, gmm.py:148-162), K=512 over 8 GPUs
@@ -91,6 +94,7 @@ def spec(workload, n_gpus, seed=0):
     from oracle import targets as otargets
     kind, d, k_per_gpu, s1 = WORKLOADS[workload][:4]
     estimator = (WORKLOADS[workload] + ("Stein",))[4]
+    reuse = (WORKLOADS[workload] + ("Stein", 0.0))[5]
     if workload in STRONG_WORKLOADS:
         if k_per_gpu % n_gpus:
             raise SystemExit(f"bench.py: workload {workload} splits K = {k_per_gpu} components evenly; --gpus {n_gpus} does not divide it")
@@ -114,7 +118,7 @@ def spec(workload, n_gpus, seed=0):
     init_rng = np.random.default_rng(seed + 1)
     means = (np.asarray(prior_scale) * init_rng.standard_normal((k_total, d))).astype(np.float32)
     covs = np.broadcast_to((np.asarray(initial_cov) * np.eye(d)).astype(np.float32), (k_total, d, d))
-    cfg = samtron_config(s, initial_stepsize=0.1, estimator=estimator)
+    cfg = samtron_config(s, initial_stepsize=0.1, estimator=estimator, reuse_ratio=reuse)
     cfg["model_initialization"].update(prior_mean=0.0, initial_cov=initial_cov)
     return dict(kind=kind, d=d, k_total=k_total, s=s, n_total=k_total * s, cfg=cfg, oracle_target=ot,
                 means=means, covs=np.ascontiguousarray(covs), seed=seed + 2)
@@ -157,7 +161,8 @@ def make_oracle(w, dtype=np.float64):
     cfg = w["cfg"]
     model = ogmm.FullCovGMM(np.ones(w["k_total"]) / w["k_total"], w["means"], w["covs"], dtype=dtype)
     return otrain.OracleGMMVI(w["oracle_target"], model, seed=w["seed"], ng_estimator=cfg["ng_estimator_type"],
-                              desired_samples_per_component=w["s"], ratio_reused_samples_to_desired=0.0,
+                              desired_samples_per_component=w["s"],
+                              ratio_reused_samples_to_desired=cfg["sample_selector_config"]["ratio_reused_samples_to_desired"],
                               component_stepsize_config=cfg["component_stepsize_adapter_config"],
                               weight_stepsize_config=cfg["weight_stepsize_adapter_config"])
 
@@ -415,7 +420,9 @@ def main():
         "higher_is_better": True, "scaling": "strong" if args.workload in STRONG_WORKLOADS else "weak", "vs_baseline": None, "dtype": "f64" if roof_name == "more_gram" else "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {w['kind']} target D={d}, K={k_tot} components "
                                f"({k_local}/GPU), {w['s']} samples/component, N={n_tot} samples/iter, SAMTRON "
-                               f"({w['cfg']['ng_estimator_type']}, fixed K, reuse ratio 0, KL trust regions, improvement-based stepsizes)",
+                               f"({w['cfg']['ng_estimator_type']}, fixed K, reuse ratio "
+                               f"{w['cfg']['sample_selector_config']['ratio_reused_samples_to_desired']:g}, KL trust regions, "
+                               f"improvement-based stepsizes)",
                    "K": k_tot, "D": d, "N": n_tot, "parallelism": f"component-shard x{n_gpus}"},
         "roofline": {"kernel": roof_name, "bound": "mfma", "achieved": achieved, "peak": roof_peak,
                      "unit": "TFLOP/s", "frac": achieved / roof_peak, "traffic": traffic,

@@ -134,8 +134,12 @@ typedef float me_f32x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifdef GMMVI_ME_STAMPS
 __device__ long long g_me_wg[2 * 8192];    // experiment builds: wall-clock (100 MHz) start / end of every workgroup of the last launch
+__device__ unsigned long long g_me_hw[8192];   // and where it ran (HW_ID, XCC_ID)
 extern "C" int gmmvi_debug_wg_times(long long* out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_wg), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+extern "C" int gmmvi_debug_wg_hw(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_hw), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
 }
 #endif
 template <int DP, int FAMILY, bool GRAD>
@@ -164,7 +168,13 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
     const bool valid = lane < n_here;
     float* sm_merge = sm;                              // staging, then the merge area
 #ifdef GMMVI_ME_STAMPS             // experiment builds (tools/bench_sweep.py): phase time stamps of one wave
-    if (threadIdx.x == 0) g_me_wg[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
+    if (threadIdx.x == 0) {
+        g_me_wg[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_me_hw[blockIdx.y * gridDim.x + blockIdx.x] = ((unsigned long long)xcc << 32) | hw;
+    }
     unsigned long long stamp[16];
     int nstamp = 0, nbackward = 0;
     const long long wc0 = wall_clock64();

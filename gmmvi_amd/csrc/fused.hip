@@ -59,26 +59,32 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
     GMMVI_ARG_CHECK(ctx, p->means && p->chols && p->logw && p->packed && p->packed_new && p->stepsizes && p->last_eta &&
                              p->l2 && p->num_updates && p->offsets && p->bg_logw && p->db_samples && p->db_tlp &&
                              p->db_tgrad && p->db_mapping && p->reward_next && p->wstate);
-    const size_t KN = (size_t)K * N, ND = (size_t)N * D;
-    const size_t floats = KN + 2 * (size_t)N + ND + (size_t)K * D * D + (size_t)K * D + 3 * (size_t)K + N + 64;
+    GMMVI_ARG_CHECK(ctx, p->n_old >= 0 && p->max_per_component >= 0);
+    GMMVI_ARG_CHECK(ctx, p->n_old == 0 || (p->bg_packed != nullptr && p->bg_K >= 1));
+    const int n_old = p->n_old;
+    const int Na = n_old + N;                          // active samples: the reused ones followed by the new ones
+    const size_t KN = (size_t)K * Na, ND = (size_t)Na * D;
+    const size_t floats = KN + 2 * (size_t)Na + ND + (size_t)K * D * D + (size_t)K * D + 3 * (size_t)K + Na + 64;
     GMMVI_TRY(arena_reserve(ctx, floats));
     Arena a;
     float* base = (float*)ctx->arena;
     a.ld = base; base += KN;
-    a.lq = base; base += N;
-    a.bg = base; base += N;
+    a.lq = base; base += Na;
+    a.bg = base; base += Na;
     a.qgrad = base; base += ND;
     a.H = base; base += (size_t)K * D * D;
     a.g = base; base += (size_t)K * D;
     a.E = base; base += K;
     a.success = (int32_t*)base; base += K;
-    a.mapping = (int32_t*)base; base += N;
+    a.mapping = (int32_t*)base; base += Na;
 
-    float* x = p->db_samples;          // the new samples ARE the active samples (reuse ratio 0): no copy
+    float* x = p->db_samples;          // the new samples are written straight into the database
+    float* xa = x - (size_t)n_old * D; // the active samples: the n_old database rows in front of them and the new ones
+    const float* tlp_a = p->db_tlp - n_old;
+    const float* tgrad_a = p->db_tgrad - (size_t)n_old * D;
     // ---- sample selection: draw, evaluate the target, append to the DB (sample_selector.py:160-219) --------------------
-    // every component draws N / K samples on this path (optimization/fused.py: equal counts); the element-wise bookkeeping
-    // (model snapshot into the DB, the two stepsize rules) rides in extra blocks of the same launch, and the sampling blocks
-    // write the DB mapping (component index + base) directly
+    // the element-wise bookkeeping (model snapshot into the DB, the two stepsize rules) rides in extra blocks of the
+    // sampling launch, and the sampling blocks write the DB mapping (component index + base) directly
     {
         PrepArgs q{};
         if (p->db_means && p->db_chols && p->db_packed) {
@@ -92,19 +98,37 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
         q.cs_min = p->cs_min; q.cs_max = p->cs_max; q.cs_inc = p->cs_inc; q.cs_dec = p->cs_dec;
         q.ws_mode = p->weight_stepsize_mode; q.logw = p->logw; q.wstate = p->wstate;
         q.ws_min = p->ws_min; q.ws_max = p->ws_max; q.ws_inc = p->ws_inc; q.ws_dec = p->ws_dec;
-        GMMVI_TRY(gmmvi_sample_components_prep(ctx, K, D, p->means, p->chols, p->offsets, N, (N + K - 1) / K, p->seed,
+        const int max_pc = p->max_per_component > 0 ? p->max_per_component : (N + K - 1) / K;
+        GMMVI_TRY(gmmvi_sample_components_prep(ctx, K, D, p->means, p->chols, p->offsets, N, max_pc, p->seed,
                                                p->first_index, x, p->db_mapping, p->mapping_base, q));
     }
-    // ---- background + model density / gradient in one sweep (sample_db.py:194-228, gmm.py:274-300) ------------------------
-    // issued BEFORE the target evaluation, which does not depend on it: the merge of the sweep's component-chunk partials
-    // rides as extra workgroups in the target launch instead of a launch of its own (combine.h; same arithmetic)
-    ctx->defer_combine = true;
-    ctx->prof_tag = "sweep_dual";
-    int rc_dual = gmmvi_mixture_eval_dual(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, p->logw, p->bg_logw, x, N, a.ld, a.lq,
-                                          a.qgrad, a.bg);
-    ctx->defer_combine = false;
-    ctx->prof_tag = nullptr;
-    GMMVI_TRY(rc_dual);
+    // ---- background + model density / gradient (sample_db.py:194-228, gmm.py:274-300) ------------------------------------
+    // issued BEFORE the target evaluation, which does not depend on them: the merge of the model sweep's component-chunk
+    // partials rides as extra workgroups in the target launch instead of a launch of its own (combine.h; same arithmetic)
+    if (p->bg_packed == nullptr) {
+        // nothing reused: the background components are the model's own -- one sweep for both mixtures
+        ctx->defer_combine = true;
+        ctx->prof_tag = "sweep_dual";
+        int rc_dual = gmmvi_mixture_eval_dual(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, p->logw, p->bg_logw, x, N, a.ld, a.lq,
+                                              a.qgrad, a.bg);
+        ctx->defer_combine = false;
+        ctx->prof_tag = nullptr;
+        GMMVI_TRY(rc_dual);
+    } else {
+        // reused samples: the background mixture runs over the database's snapshots of the window (bg_K of them), the model
+        // sweep over the current components; both on all active samples
+        ctx->prof_tag = "sweep_background";
+        int rc_bg = gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, p->bg_K, D, p->bg_packed, p->bg_logw, xa, Na, nullptr, a.bg,
+                                       nullptr);
+        ctx->prof_tag = nullptr;
+        GMMVI_TRY(rc_bg);
+        ctx->defer_combine = true;
+        ctx->prof_tag = "sweep_model";
+        int rc_m = gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, p->logw, xa, Na, a.ld, a.lq, a.qgrad);
+        ctx->defer_combine = false;
+        ctx->prof_tag = nullptr;
+        GMMVI_TRY(rc_m);
+    }
     if (p->target_kind == 1) {
         GMMVI_TRY(gmmvi_target_planar(ctx, D, p->planar_prior_std, p->planar_goals_count, p->planar_goals,
                                       p->planar_likelihood_std, x, N, p->db_tlp, p->db_tgrad));
@@ -120,19 +144,19 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
     // the Stein estimate stops at its partial slab; its last step (slab sum, Sigma^-1, normalisation) is the prologue of the
     // update kernel where that is instantiated, the stand-alone launch otherwise -- the same arithmetic either way
     SteinSlab slab{nullptr, nullptr, 0};
-    GMMVI_TRY(gmmvi_stein_partials(ctx, K, D, p->packed, x, N, a.ld, a.qgrad, a.bg, p->db_tgrad, p->stein_flags, &slab));
-    GMMVI_TRY(gmmvi_update_components_kl_from_slab(ctx, K, D, slab, N, p->stein_flags, p->packed, a.H, a.g, p->means, p->chols,
+    GMMVI_TRY(gmmvi_stein_partials(ctx, K, D, p->packed, xa, Na, a.ld, a.qgrad, a.bg, tgrad_a, p->stein_flags, &slab));
+    GMMVI_TRY(gmmvi_update_components_kl_from_slab(ctx, K, D, slab, Na, p->stein_flags, p->packed, a.H, a.g, p->means, p->chols,
                                                    p->stepsizes, p->temperature, p->l2_init, p->last_eta, p->l2, p->num_updates,
                                                    p->success_out ? p->success_out : a.success, p->packed_new));
     // ---- weight update (gmmvi.py:172-173) ---------------------------------------------------------------------------------
     // (the merge of this sweep's log-density partials happens inside the expected-log-ratio kernel)
     ctx->defer_combine = true;
     ctx->prof_tag = "sweep_post";
-    int rc_post = gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed_new, p->logw, x, N, a.ld, a.lq, nullptr);
+    int rc_post = gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed_new, p->logw, xa, Na, a.ld, a.lq, nullptr);
     ctx->defer_combine = false;
     ctx->prof_tag = nullptr;
     GMMVI_TRY(rc_post);
-    GMMVI_TRY(gmmvi_expected_log_ratios(ctx, K, N, a.ld, a.bg, p->db_tlp, a.lq, p->temperature, p->logw,
+    GMMVI_TRY(gmmvi_expected_log_ratios(ctx, K, Na, a.ld, a.bg, tlp_a, a.lq, p->temperature, p->logw,
                                         (p->stein_flags & GMMVI_SELF_NORMALIZED) ? 1 : 0, a.E, p->reward_next, nullptr));
     if (K > 1) {
         GMMVI_TRY(gmmvi_update_weights_internal(ctx, p->weight_update_mode == 0 ? 0 : 1, K, p->logw, a.E, p->wstate,

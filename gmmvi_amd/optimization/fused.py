@@ -1,11 +1,16 @@
 """Single-call fast path of GMMVI.train_iter() (reference: src/gmmvi/optimization/gmmvi.py:146-174).
 
-When every plug-in module is one of the built-in SAMTRON-style choices (component-based selector at reuse ratio 0,
-Stein estimator, KL-constrained component updater, improvement-based or fixed stepsizes, trust-region or direct weight
-updater, built-in target), the iteration is issued by ONE C call (``gmmvi_train_iter_samtron``) that composes the same
-entry points the modules call, on the same state arrays.  Python only does the bookkeeping the reference keeps in
-``tf.Variable``s (DB length, ring positions, counters).  Anything else -- reuse ratio > 0, MORE, direct/iBLR updaters,
-own-samples-only, user targets, diagonal GMMs, want_info -- takes the modular path.  Disable with ``GMMVI_FAST_PATH=0``.
+When every plug-in module is one of the built-in SAMTRON-style choices (component-based selector, Stein estimator,
+KL-constrained component updater, improvement-based or fixed stepsizes, trust-region or direct weight updater, built-in
+target), the iteration is issued by ONE C call (``gmmvi_train_iter_samtron``) that composes the same entry points the
+modules call, on the same state arrays.  Python only does the bookkeeping the reference keeps in ``tf.Variable``s (DB
+length, ring positions, counters).
+Sample reuse (``ratio_reused_samples_to_desired`` > 0, the reference's default ``component-based.yml:3-4``): the number
+of new samples per component follows from the effective sample sizes of the reused ones (sample_selector.py:160-202);
+those K numbers are computed on the device by the same three launches the selector module issues and read back (the one
+host synchronisation of such an iteration, as upstream's ``tf.floor`` implies), then the rest of the iteration is the one
+C call.  Anything else -- MORE, direct/iBLR updaters, own-samples-only, user targets, diagonal GMMs, want_info, an
+iteration in which the database has to be thinned out -- takes the modular path.  Disable with ``GMMVI_FAST_PATH=0``.
 """
 import ctypes as C
 import os
@@ -33,7 +38,8 @@ class SamtronPlan(C.Structure):
         ("planar_goals_count", _i), ("planar_likelihood_std", _f),
         ("means", _p), ("chols", _p), ("logw", _p), ("packed", _p), ("packed_new", _p),
         ("stepsizes", _p), ("last_eta", _p), ("l2", _p), ("num_updates", _p), ("success_out", _p),
-        ("offsets", _p), ("bg_logw", _p), ("seed", C.c_uint64), ("first_index", C.c_uint64),
+        ("offsets", _p), ("max_per_component", _i), ("n_old", _i), ("bg_K", _i), ("bg_packed", _p), ("bg_logw", _p),
+        ("seed", C.c_uint64), ("first_index", C.c_uint64),
         ("db_samples", _p), ("db_tlp", _p), ("db_tgrad", _p), ("db_mapping", _p), ("mapping_base", _i),
         ("db_means", _p), ("db_chols", _p), ("db_packed", _p),
         ("reward_prev", _p), ("reward_last", _p), ("reward_next", _p), ("weight_slot", _p), ("wstate", _p),
@@ -86,14 +92,31 @@ class SamtronFastPath:
             return False
         g = self.g
         sel, db = g.sample_selector, g.sample_db
-        if sel.reused_samples_per_component != 0 or sel.eps_override is not None or not sel.fuse_background:
+        if sel.eps_override is not None or not sel.fuse_background:
             return False
         if g.ng_based_updater.want_info or g.weight_updater.want_info:
             return False
+        # worst case of this iteration's append: every component draws its full share
         n_new = sel.desired_samples_per_component * g.model.num_components
         if db.max_samples is not None and n_new + db._samples.n > db.max_samples:
             return False                                   # the modular path thins the DB out first (sample_db.py:111-112)
         return sel.desired_samples_per_component >= 1
+
+    def _new_sample_counts(self):
+        """Per-component numbers of new samples and the window of reused ones (sample_selector.py:160-219).
+        -> (counts [K] int64, n_old).  Reuse ratio 0: every component draws its full share, nothing is read back."""
+        g = self.g
+        sel, db, model = g.sample_selector, g.sample_db, g.model.model
+        k, s = model.num_components, sel.desired_samples_per_component
+        n_reuse = sel.reused_samples_per_component * k
+        if n_reuse == 0 or db._samples.n == 0:
+            return np.full(k, s, np.int64), 0
+        # exactly the selector's launches: background density of the newest n_reuse samples, component log-densities of the
+        # current model on them, effective sample sizes; the [K] result is read back (host synchronisation)
+        bg_old, xs_old, _, _, _ = db.get_newest_samples(n_reuse)
+        ld_old = model.component_log_densities(xs_old)
+        n_eff = np.floor(sel.get_effective_samples(ld_old, bg_old).numpy()).astype(np.int64)
+        return np.maximum(1, s - n_eff), int(xs_old.shape[0])
 
     # ---- one iteration -----------------------------------------------------------------------------------------------------
     def step(self):
@@ -103,19 +126,17 @@ class SamtronFastPath:
         ctx = model.ctx
         sel, db = g.sample_selector, g.sample_db
         k, d = model.num_components, model.num_dimensions
-        s = sel.desired_samples_per_component
-        n = k * s
         p = self.plan
 
-        counts = np.full(k, s, np.int64)
+        counts, n_old = self._new_sample_counts()
+        n = int(counts.sum())
         key = counts.tobytes()
-        offsets = np.arange(k + 1, dtype=np.int32) * np.int32(s)
+        offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         offsets_dev = ctx.cached_const(("offsets", offsets.tobytes()), lambda: ctx.asarray(offsets, np.int32))
-        bg_logw = ctx.cached_const(("bg_logw", key),
-                                   lambda: ctx.asarray(np.full(k, -np.log(k), np.float32)))
         if getattr(sel, "_mapping_key", None) != key:
             sel._mapping_key = key
             sel._last_mapping_host = np.repeat(np.arange(k, dtype=np.int32), counts)
+        sel._last_counts = counts
 
         # SampleDB: reserve room, remember the append position (sample_db.py:113-124)
         for grow, rows in ((db._samples, n), (db._target_lnpdfs, n), (db._target_grads, n), (db._mapping_dev, n),
@@ -126,6 +147,33 @@ class SamtronFastPath:
         packed_cur = model.packed
         packed_new = ctx.empty((k, stride))
         success = ctx.empty((k,), np.int32)
+
+        # background mixture of the active window (sample_db.py:216-227): with nothing reused its components are the
+        # model's own and share the model's sweep; otherwise the snapshots of the window's sampling components (the new
+        # ones, appended by this call at row c0, included), weighted by their sample counts
+        # (the host mirror of the mapping and the append log get this iteration's entry first: the window below includes it)
+        db._mapping_host.append(sel._last_mapping_host + np.int32(c0))
+        db._segments.append((s0, c0, counts))
+        if n_old == 0:
+            bg_logw = ctx.cached_const(("bg_logw", key), lambda: ctx.asarray(np.log(counts / counts.sum()).astype(np.float32)))
+            p.n_old, p.bg_K, p.bg_packed = 0, 0, None
+        else:
+            active, acounts = db._active_components(s0 - n_old)
+            lo, hi = int(active[0]), int(active[-1]) + 1
+            if hi - lo == len(active) and (len(active) == 1 or np.all(np.diff(active) == 1)):
+                bg_packed_ptr = db._packed.buf.ptr + lo * stride * 4        # contiguous snapshot range: no gather
+                self._bg_keepalive = None
+            else:
+                # snapshots of the reused part gathered; the new components' rows are written by the call itself, so their
+                # blocks are taken from the model (identical contents)
+                old_rows = active[active < c0].astype(np.int32)
+                assert len(active) - len(old_rows) == k, "every current component draws at least one new sample"
+                self._bg_keepalive = hip_ops.concat(ctx, [hip_ops.gather_rows(ctx, db._packed.view(), old_rows), packed_cur])
+                bg_packed_ptr = self._bg_keepalive.ptr
+            bg_logw = ctx.cached_const(("bg_logw", acounts.tobytes()),
+                                       lambda: ctx.asarray(np.log(acounts.astype(np.float64) / acounts.sum()).astype(np.float32)))
+            p.n_old, p.bg_K, p.bg_packed = n_old, len(active), bg_packed_ptr
+        p.max_per_component = int(counts.max())
 
         tgt = sel.target_distribution._fast_path_target()
         p.K, p.D, p.N = k, d, n
@@ -177,8 +225,6 @@ class SamtronFastPath:
                            (db._means, k), (db._chols, k), (db._packed, k)):
             grow.n += rows
         db._num_samples_written += n
-        db._mapping_host.append(sel._last_mapping_host + np.int32(c0))
-        db._segments.append((s0, c0, counts))
         m.commit_rewards()
         if k > 1:
             m._t_weight += 1

@@ -242,9 +242,15 @@ int gmmvi_weight_stepsize_improvement(gmmvi_ctx* ctx, int K, const float* logw_d
 
 /* ---- single-call iteration ------------------------------------------------------------------------------------- */
 /* GMMVI.train_iter() (optimization/gmmvi.py:146-174) for the SAMTRON design choices with a component-based sample
- * selector at reuse ratio 0: Stein estimator, KL-constrained component update, trust-region or direct weight update,
- * improvement-based or fixed stepsizes, built-in target.  The call is exactly the composition of the entry points above
- * in the order the plug-in modules invoke them (one host call instead of ~20), operating on the caller's state arrays. */
+ * selector: Stein estimator, KL-constrained component update, trust-region or direct weight update, improvement-based or
+ * fixed stepsizes, built-in target.  The call is exactly the composition of the entry points above in the order the plug-in
+ * modules invoke them (one host call instead of ~20), operating on the caller's state arrays.
+ * Sample reuse (sample_selector.py:204-219, ratio_reused_samples_to_desired > 0): the caller has chosen the per-component
+ * counts of the NEW samples (`offsets`; they follow from the effective sample sizes of the reused ones, sample_selector.py:
+ * 160-202) and passes the number of reused samples `n_old`: the active samples are the n_old database rows in front of the
+ * append position followed by the N new ones (contiguous in the database), the background mixture is given by
+ * (bg_K, bg_packed, bg_logw) over the database's component snapshots of that window (sample_db.py:216-227).  With
+ * n_old == 0 and bg_packed == NULL the background components are the model's own (one sweep for both). */
 typedef struct gmmvi_samtron_plan {
     int32_t K, D, N;                      /* components, dimension, samples of this iteration (sum of the counts) */
     int32_t target_kind;                  /* 0: mixture family (gmmvi_mixture_eval), 1: planar robot */
@@ -264,7 +270,11 @@ typedef struct gmmvi_samtron_plan {
     int32_t* success_out;                 /* [K] or NULL */
     /* sampling */
     const int32_t* offsets;               /* [K+1] prefix sums of the per-component sample counts */
-    const float* bg_logw;                 /* [K] log(count_k / N): background mixture weights (sample_db.py:225-226) */
+    int32_t max_per_component;            /* largest per-component count (0: N / K rounded up) */
+    int32_t n_old;                        /* reused samples in front of the append position (0: none) */
+    int32_t bg_K;                         /* background components (ignored when bg_packed is NULL: the model's own) */
+    const float* bg_packed;               /* [bg_K, stride] snapshot blocks of the window's sampling components, or NULL */
+    const float* bg_logw;                 /* [bg_K or K] log(count / (n_old + N)): background weights (sample_db.py:225-226) */
     uint64_t seed, first_index;           /* Philox key / global index of the first new sample */
     /* SampleDB append targets, already offset to the first free row (sample_db.py:115-124); snapshots may be NULL */
     float* db_samples; float* db_tlp; float* db_tgrad; int32_t* db_mapping; int32_t mapping_base;

@@ -26,6 +26,11 @@ def _pair(kind, d, k, s, seed, cfg):
     ("gmm", 32, 4, 80, samtron_config(80)),            # tiled Stein kernel + wide mixture_eval (what bench.py c3 composes)
     ("gmm", 50, 5, 100, samtron_config(100)),
     ("gmm", 32, 4, 80, samtron_config(80, snis=False, initial_stepsize=0.01)),   # plain weights: finalize launch + update
+    # sample reuse (the reference's default selector, component-based.yml:3-4: ratio 2): data-dependent numbers of new samples
+    ("stm", 4, 3, 32, samtron_config(32, reuse_ratio=2.0)),
+    ("gmm", 20, 8, 64, samtron_config(64, reuse_ratio=2.0)),
+    ("planar", 10, 4, 50, samtron_config(50, reuse_ratio=1.0)),
+    ("gmm", 32, 4, 80, samtron_config(80, reuse_ratio=2.0)),
 ])
 def test_fast_path_equals_modular_path(kind, d, k, s, cfg):
     o, fast, slow = _pair(kind, d, k, s, 23, cfg)
@@ -89,10 +94,43 @@ def test_fast_path_with_adaptive_components_and_oracle():
     np.testing.assert_allclose(fast.model.means.numpy(), o.model.means, rtol=0.05, atol=0.05)
 
 
+def test_default_samtron_config_takes_the_single_call_path():
+    """get_default_algorithm_config("SAMTRON") as shipped (sample reuse ratio 2, adaptive number of components) through the
+    runner: every iteration is eligible for the single-call path; the database thinning iteration alone falls back."""
+    from gmmvi.gmmvi_runner import GmmviRunner
+    from gmmvi.configs import update_config, get_default_experiment_config, get_default_algorithm_config
+    config = update_config(update_config(get_default_experiment_config("stm20"), {"start_seed": 0}),
+                           update_config(get_default_algorithm_config("SAMTRON"),
+                                         {"model_initialization": {"num_initial_components": 6},
+                                          "gmmvi_runner_config": {"log_metrics_interval": 100}}))
+    assert config["sample_selector_config"]["ratio_reused_samples_to_desired"] == 2.0
+    runner = GmmviRunner.build_from_config(config=config)
+    fp = runner.gmmvi._fast_path
+    for n in range(8):
+        assert fp.eligible()
+        runner.iterate_and_log(n)
+    db = runner.gmmvi.sample_db
+    assert int(db.num_samples_written) == db.samples.shape[0] > 6 * 100
+
+
+def test_fast_path_with_reuse_and_database_thinning():
+    """A small database limit: the iteration that has to thin the database out runs module by module, the others in one
+    call; the trajectory equals the all-modular one bit for bit."""
+    cfg = samtron_config(40, reuse_ratio=2.0, max_database_size=700)
+    o, fast, slow = _pair("gmm", 4, 3, 40, 31, cfg)
+    fast._fast_path.explicit_estimate = True
+    took_fast = 0
+    for it in range(14):
+        took_fast += bool(fast._fast_path.eligible())
+        fast.train_iter()
+        slow.train_iter()
+        np.testing.assert_array_equal(fast.model.means.numpy(), slow.model.means.numpy(), err_msg=f"iteration {it}")
+        np.testing.assert_array_equal(fast.sample_db.mapping.numpy(), slow.sample_db.mapping.numpy())
+    assert 0 < took_fast < 14
+    np.testing.assert_array_equal(fast.sample_db.samples.numpy(), slow.sample_db.samples.numpy())
+
+
 def test_fast_path_steps_aside():
-    cfg = samtron_config(30, reuse_ratio=2.0)
-    o, fast, _ = _pair("stm", 4, 3, 30, 5, cfg)
-    assert not fast._fast_path.eligible()                       # sample reuse needs the ESS on the host
     cfg = samtron_config(30, updater="direct", initial_stepsize=0.01)
     o, fast, _ = _pair("gmm", 4, 3, 30, 5, cfg)
     assert not fast._fast_path.eligible()

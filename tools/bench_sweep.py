@@ -91,3 +91,21 @@ if hasattr(ctx.lib, "gmmvi_debug_wg_times"):       # experiment build (-DGMMVI_M
     st, en = (t[:, 0] - t0) * 0.01, (t[:, 1] - t0) * 0.01
     print(f"workgroup starts (us after the first): median {np.median(st):.2f} p90 {np.percentile(st, 90):.2f} max {st.max():.2f}; "
           f"ends: min {en.min():.2f} median {np.median(en):.2f} max {en.max():.2f}; life median {np.median(en - st):.2f} max {(en - st).max():.2f}")
+    if hasattr(ctx.lib, "gmmvi_debug_wg_hw"):
+        hb = (ctypes.c_ulonglong * nwg)()
+        ctx.lib.gmmvi_debug_wg_hw.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        assert ctx.lib.gmmvi_debug_wg_hw(hb, nwg) == 0
+        h = np.array(hb[:], dtype=np.uint64)
+        hw, xcc = (h & np.uint64(0xffffffff)).astype(np.int64), (h >> np.uint64(32)).astype(np.int64) & 0xf
+        cu, sh, se = (hw >> 8) & 0xf, (hw >> 12) & 0x1, (hw >> 13) & 0x7          # gfx9 HW_ID: CU_ID [11:8], SH_ID [12], SE_ID [15:13]
+        place = xcc * 1000 + se * 100 + sh * 50 + cu
+        import collections
+        cnt = collections.Counter(place.tolist())
+        per_cu = np.array([cnt[q] for q in place.tolist()])
+        life = en - st
+        for c in sorted(set(per_cu.tolist())):
+            sel = per_cu == c
+            print(f"  workgroups on a CU shared by {c}: {sel.sum()} (CUs {len([1 for v in cnt.values() if v == c])}), life median {np.median(life[sel]):.2f} max {life[sel].max():.2f} us, end median {np.median(en[sel]):.2f} max {en[sel].max():.2f}")
+        print("  distinct CUs used:", len(cnt), " XCC histogram:", np.bincount(xcc, minlength=8).tolist())
+        order = np.argsort(en)[-8:]
+        print("  last to end: " + ", ".join(f"wg{int(i)}(x{i % 157},y{i // 157}) cu{int(place[i])} start {st[i]:.1f} end {en[i]:.1f}" for i in order))
