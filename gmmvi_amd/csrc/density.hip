@@ -573,71 +573,85 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_kernel(float nu, int K_
     }
     if (lp_out == nullptr && !GRAD) return;
 
-    // merge the W waves' partials: sm_m[w][sample], sm_s[w][sample], sm_acc[w][i][sample]  (sample = 16 t + n)
+    // merge the W waves' partials: sm_m[w][sample], sm_s[w][sample], sm_acc[w][i][sample]  (sample = 16 t + n).
+    // Round 1: the running maxima meet in LDS and every wave rescales ITS sums to the common maximum (one exp per lane and
+    // sub-tile instead of one per (dimension, sample, wave) in the reduction); round 2: plain sums in wave order.  The
+    // barriers wait for LDS traffic only (ME_LDS_BARRIER): __syncthreads() would also drain the stores of the log densities.
     float* sm_m = sm_merge;
     float* sm_s = sm_merge + nwaves * TS;
     float* sm_acc = sm_merge + 2 * nwaves * TS;
-    if constexpr (!GRAD && NTS == 4) {
-        sm_m[wave * TS + lane] = m[0]; sm_s[wave * TS + lane] = sv[0];          // lane = sample
+    float* sm_m2 = sm_merge + (size_t)nwaves * TS * ((GRAD ? DP : 0) + 2) + (GRAD ? TS * ldx : 0);
+    float* sm_s2 = sm_m2 + nwaves * TS;
+    constexpr bool LANE_SAMPLE = !GRAD && NTS == 4;    // lane = sample (16 g + n of sub-tile g) instead of one column per lane group
+    if constexpr (LANE_SAMPLE) {
+        sm_m[wave * TS + lane] = m[0];
+        if (dual) sm_m2[wave * TS + lane] = m2[0];
     } else if (g == 0) {
 #pragma unroll
-        for (int t = 0; t < NTS; ++t) { sm_m[wave * TS + 16 * t + n16] = m[t]; sm_s[wave * TS + 16 * t + n16] = sv[t]; }
+        for (int t = 0; t < NTS; ++t) {
+            sm_m[wave * TS + 16 * t + n16] = m[t];
+            if (dual) sm_m2[wave * TS + 16 * t + n16] = m2[t];
+        }
     }
-    if (GRAD) {
+    ME_LDS_BARRIER();
+    if constexpr (LANE_SAMPLE) {
+        float M = -3.0e38f;
+        for (int w = 0; w < nwaves; ++w) M = fmaxf(M, sm_m[w * TS + lane]);
+        sm_s[wave * TS + lane] = sv[0] * __expf(m[0] - M);
+        if (dual) {
+            float M2 = -3.0e38f;
+            for (int w = 0; w < nwaves; ++w) M2 = fmaxf(M2, sm_m2[w * TS + lane]);
+            sm_s2[wave * TS + lane] = s2[0] * __expf(m2[0] - M2);
+        }
+    } else {
 #pragma unroll
-        for (int t = 0; t < NTS; ++t)
+        for (int t = 0; t < NTS; ++t) {
+            const int sidx = 16 * t + n16;
+            float M = -3.0e38f;
+            for (int w = 0; w < nwaves; ++w) M = fmaxf(M, sm_m[w * TS + sidx]);
+            const float f = __expf(m[t] - M);
+            if (g == 0) sm_s[wave * TS + sidx] = sv[t] * f;
+            if (dual && g == 1) {
+                float M2 = -3.0e38f;
+                for (int w = 0; w < nwaves; ++w) M2 = fmaxf(M2, sm_m2[w * TS + sidx]);
+                sm_s2[wave * TS + sidx] = s2[t] * __expf(m2[t] - M2);
+            }
+            if (GRAD) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * mt + 4 * g + r;
-                    if (i < DP) sm_acc[(wave * DP + i) * TS + 16 * t + n16] = acc[t][mt][r];
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * mt + 4 * g + r;
+                        if (i < DP) sm_acc[(wave * DP + i) * TS + sidx] = acc[t][mt][r] * f;
+                    }
+            }
+        }
     }
-    __syncthreads();
-    // sample si = threadIdx.x (one thread per sample for the log values)
-    float M = -3.0e38f, S = 1.f;
+    ME_LDS_BARRIER();
+    // sample si = threadIdx.x (one thread per sample for the log values); 1 / S goes back to LDS for the gradient
     const int si = threadIdx.x;
     if (si < TS) {
-        for (int w = 0; w < nwaves; ++w) M = fmaxf(M, sm_m[w * TS + si]);
-        S = 0.f;
-        for (int w = 0; w < nwaves; ++w) S += sm_s[w * TS + si] * __expf(sm_m[w * TS + si] - M);
+        float M = -3.0e38f, S = 0.f;
+        for (int w = 0; w < nwaves; ++w) { M = fmaxf(M, sm_m[w * TS + si]); S += sm_s[w * TS + si]; }
         if (si < n_here && lp_out != nullptr) lp_out[n0 + si] = M + __logf(S);
-    }
-    if (dual) {
-        float* sm_m2 = sm_merge + (size_t)nwaves * TS * ((GRAD ? DP : 0) + 2) + (GRAD ? TS * ldx : 0);
-        float* sm_s2 = sm_m2 + nwaves * TS;
-        if constexpr (!GRAD && NTS == 4) {
-            sm_m2[wave * TS + lane] = m2[0]; sm_s2[wave * TS + lane] = s2[0];
-        } else if (g == 0) {
-#pragma unroll
-            for (int t = 0; t < NTS; ++t) { sm_m2[wave * TS + 16 * t + n16] = m2[t]; sm_s2[wave * TS + 16 * t + n16] = s2[t]; }
-        }
-        __syncthreads();
-        if (si < n_here && lp2_out != nullptr) {
-            float M2 = -3.0e38f;
-            for (int w = 0; w < nwaves; ++w) M2 = fmaxf(M2, sm_m2[w * TS + si]);
-            float S2 = 0.f;
-            for (int w = 0; w < nwaves; ++w) S2 += sm_s2[w * TS + si] * __expf(sm_m2[w * TS + si] - M2);
+        if (dual && si < n_here && lp2_out != nullptr) {
+            float M2 = -3.0e38f, S2 = 0.f;
+            for (int w = 0; w < nwaves; ++w) { M2 = fmaxf(M2, sm_m2[w * TS + si]); S2 += sm_s2[w * TS + si]; }
             lp2_out[n0 + si] = M2 + __logf(S2);
         }
+        if (GRAD) sm_s[si] = 1.f / S;                  // (row 0 of sm_s is read by this thread only: no hazard)
     }
     if (GRAD && grad_out != nullptr) {
-        // thread (dimension i, sample si2) pairs spread over the workgroup; results go to a [TS][ldx] tile and leave coalesced
+        ME_LDS_BARRIER();
+        // thread (dimension i, sample s_i) pairs spread over the workgroup; results go to a [TS][ldx] tile and leave coalesced
         float* outt = sm_acc + (size_t)nwaves * DP * TS;
         for (int e = threadIdx.x; e < D * TS; e += blockDim.x) {
             const int i = e / TS, s_i = e - i * TS;
-            float Ms = -3.0e38f;
-            for (int w = 0; w < nwaves; ++w) Ms = fmaxf(Ms, sm_m[w * TS + s_i]);
-            float Ss = 0.f, gsum = 0.f;
-            for (int w = 0; w < nwaves; ++w) {
-                const float f = __expf(sm_m[w * TS + s_i] - Ms);
-                Ss = fmaf(sm_s[w * TS + s_i], f, Ss);
-                gsum = fmaf(sm_acc[(w * DP + i) * TS + s_i], f, gsum);
-            }
-            outt[s_i * ldx + i] = gsum / Ss;
+            float gsum = 0.f;
+            for (int w = 0; w < nwaves; ++w) gsum += sm_acc[(w * DP + i) * TS + s_i];
+            outt[s_i * ldx + i] = gsum * sm_s[s_i];
         }
-        __syncthreads();
+        ME_LDS_BARRIER();
         for (int e = threadIdx.x; e < n_here * D; e += blockDim.x)
             grad_out[(size_t)n0 * D + e] = outt[(e / D) * ldx + (e % D)];
     }
@@ -845,7 +859,7 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_ws_kernel(float nu, int
             for (int u = 0; u < NPRE; ++u)
                 if (tid + 512 * u < BLK) Bn[tid + 512 * u] = pre[u];
         }
-        __syncthreads();
+        ME_LDS_BARRIER();              // (LDS only: __syncthreads() would drain the log-density stores of every component)
     }
     // ---- the wave's results leave from its registers: log values by the lanes of group 0, gradient rows 4 g + r of tile mt ---
     if (g == 0) {
