@@ -58,23 +58,28 @@ class GMMVI:
         from .fused import SamtronFastPath
         self._fast_path = SamtronFastPath(self)
 
+    # the plug-in modules of an iteration: (constructor argument of GMMVI, factory(config, model, sample_db=, target_distribution=));
+    # gmmvi.py:105-144 builds the same objects one statement at a time
+    _MODULES = (
+        ("ng_estimator", lambda c, m, **kw: NgEstimator.build_from_config(c, c['temperature'], m)),
+        ("ng_based_updater", lambda c, m, **kw: NgBasedComponentUpdater.build_from_config(c, m)),
+        ("num_component_adapter", lambda c, m, **kw: ComponentAdaptation.build_from_config(
+            c, m, kw["sample_db"], target_distribution=kw["target_distribution"],
+            prior_mean=c["model_initialization"]["prior_mean"], initial_cov=c["model_initialization"]["initial_cov"])),
+        ("component_stepsize_adapter", lambda c, m, **kw: ComponentStepsizeAdaptation.build_from_config(c, m)),
+        ("sample_selector", lambda c, m, **kw: SampleSelector.build_from_config(c, m, kw["sample_db"],
+                                                                               kw["target_distribution"])),
+        ("weight_updater", lambda c, m, **kw: WeightUpdater.build_from_config(c, m)),
+        ("weight_stepsize_adapter", lambda c, m, **kw: WeightStepsizeAdaptation.build_from_config(c, m)),
+    )
+
     @staticmethod
     def build_from_config(config: dict, target_distribution, model: GmmWrapper):
-        """gmmvi.py:105-144."""
+        """gmmvi.py:105-144: one module per entry of ``_MODULES``, all on the same model and sample database."""
         sample_db = SampleDB.build_from_config(config, model.num_dimensions)
-        ng_estimator = NgEstimator.build_from_config(config, config['temperature'], model)
-        ng_based_updater = NgBasedComponentUpdater.build_from_config(config, model)
-        num_component_adapter = ComponentAdaptation.build_from_config(
-            config, model, sample_db, target_distribution=target_distribution,
-            prior_mean=config["model_initialization"]["prior_mean"],
-            initial_cov=config["model_initialization"]["initial_cov"])
-        component_stepsize_adapter = ComponentStepsizeAdaptation.build_from_config(config, model)
-        sample_selector = SampleSelector.build_from_config(config, model, sample_db, target_distribution)
-        weight_updater = WeightUpdater.build_from_config(config, model)
-        weight_stepsize_adapter = WeightStepsizeAdaptation.build_from_config(config, model)
-        return GMMVI(model, sample_db, config['temperature'], sample_selector, num_component_adapter,
-                     component_stepsize_adapter, ng_estimator, ng_based_updater, weight_stepsize_adapter,
-                     weight_updater)
+        parts = {name: factory(config, model, sample_db=sample_db, target_distribution=target_distribution)
+                 for name, factory in GMMVI._MODULES}
+        return GMMVI(model, sample_db, config['temperature'], **parts)
 
     def train_iter(self):
         """gmmvi.py:146-161.  Built-in SAMTRON-style module sets take the single-call fast path (optimization/fused.py:
@@ -88,8 +93,8 @@ class GMMVI:
         self.num_component_adapter.adapt_number_of_components(self.num_updates)
 
     def _run_updates(self, samples, mapping, sample_dist_densities, target_lnpdfs, target_lnpdf_grads):
-        """gmmvi.py:163-174 -- the ordering contract of the hot path."""
-        # update components
+        """gmmvi.py:163-174 -- the ordering contract of the hot path: stepsizes, natural-gradient estimate, component
+        update, then weight stepsize and weight update."""
         new_component_stepsizes = self.component_stepsize_adapter.update_stepsize(self.model.stepsizes)
         self.model.update_stepsizes(new_component_stepsizes)
         # only_use_own_samples needs max(mapping) (ng_estimator.py:244): read it off the DB's host mirror of the mapping
@@ -103,7 +108,6 @@ class GMMVI:
         expected_hessian_neg, expected_grad_neg = self.ng_estimator.get_expected_hessian_and_grad(
             samples, mapping, sample_dist_densities, target_lnpdfs, target_lnpdf_grads)
         self.ng_based_updater.apply_NG_update(expected_hessian_neg, expected_grad_neg, self.model.stepsizes)
-        # update weights
         weight_stepsize = self.weight_stepsize_adapter.update_stepsize()
         self.weight_updater.update_weights(samples, sample_dist_densities, target_lnpdfs, weight_stepsize)
         self.num_updates.assign_add(1)

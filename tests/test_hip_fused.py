@@ -66,14 +66,16 @@ def test_fast_path_equals_modular_path(kind, d, k, s, cfg):
 def test_direct_whitening_of_the_moment_sums(kind, d, k, s, cfg):
     """Default single-call route at D = 4 / 10 / 20 / 32 / 40 / 50 with self-normalised weights: the update kernel forms
     M = -sym(L^T C L^-T) / sum e from the Stein moment sums instead of materialising H (csrc/update_kl.hip).  Same mathematics,
-    fewer roundings: the first iteration agrees with the module-by-module path to a few ulp, the trajectories stay together,
-    the accept / reject decisions are the same."""
+    fewer roundings: the first iteration (identical inputs: the only difference is how the whitened matrix M and the vector
+    w are formed) agrees with the module-by-module path to 2e-5 of the parameter scale, every later iteration to a FIXED
+    2e-4 (no growth with the iteration count: 260-iteration runs of this route stay within 3e-5 of the fp64 oracle,
+    tests/test_hip_long_horizon.py), the accept / reject decisions are the same."""
     o, fast, slow = _pair(kind, d, k, s, 23, cfg)
     assert not fast._fast_path.explicit_estimate
     for it in range(6):
         fast.train_iter()
         slow.train_iter()
-        tol = 2e-5 if it == 0 else 2e-3 * (1 + it)
+        tol = 2e-5 if it == 0 else 2e-4
         for name in ("means", "chol_cov", "log_weights"):
             a, b = getattr(fast.model, name).numpy(), getattr(slow.model, name).numpy()
             scale = max(1.0, float(np.abs(b).max()))
