@@ -65,8 +65,14 @@ static int launch_stein_finalize(gmmvi_ctx* ctx, int K, int D, int R, int N, int
 //
 // Grid (stack of NB components, sample range); 4 waves per workgroup, all on the same stack, the range split evenly over
 // them.  A wave works through its samples in chunks of 64 WITHOUT any workgroup barrier: lane = sample loads its x / g row,
-// transposed into a wave-private feature-major LDS image T[feature][sample] (row stride 72: the ds_read_b128 of a 16-lane
-// group hit disjoint banks), the importance weights e = exp(ld - bg - M) with lane = sample (M: the maximum over the wave's
+// transposed into a wave-private feature-major LDS image T[feature][sample] (row stride 72 floats = 18 sixteen-byte slots: a
+// ds_read_b128 is served in four 16-lane groups -- lanes {0-3, 12-15, 20-27}, ... -- and within a group the rows c16 in
+// {0-3, 12-15} (k-slot q) and {4-11} (k-slot q + 1) of the [g; 1] operand fall on sixteen different slots: conflict-free.
+// The STACKED [x - mu; 1] operand reads rows (16 nt + c16) mod (D + 1), which wrap around the D + 1 rows of a component:
+// rows eight apart then meet on one slot (D = 20, nt = 1: 16 / 8, 17 / 9, 18 / 10, 20 / 4) -- two-way conflicts on part of
+// its reads, 55 % of the kernel's LDS cycles by SQ_LDS_BANK_CONFLICT, with LDS ~6 % of the wave cycles.  A per-16-rows skew
+// of the image was measured and made it worse (3.7e5 -> 5.0e5 conflict cycles per launch: it breaks the other column
+// tiles); an image in stacked order would triple the x stores.  Left as it is.), the importance weights e = exp(ld - bg - M) with lane = sample (M: the maximum over the wave's
 // samples, found by a first pass over the log weights alone), then per 16 samples: MT + 2 NT ds_read_b128 (four MFMA steps each),
 // (x - mu) e on the vector unit, 4 MT NT MFMAs.  Which sample sits in which k-slot of which step is free (the contraction
 // sums over all of them): the lane with k-slot q takes samples 16 u + 4 q + {0,1,2,3} for its four steps of block u, which

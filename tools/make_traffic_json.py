@@ -7,10 +7,12 @@ import json, re, sys
 
 NAMES = [  # (substring of the kernel instance name, bench.py kernel name); first match wins
     ("stein_moment_kernel", "stein_partial"), ("stein_finalize_kernel", "stein_finalize"),
-    ("mixture_eval_kernel<20, 1, true", "target_mixture_eval_grad"), ("mixture_eval_kernel<10, 1, true", "target_mixture_eval_grad"),
-    ("mixture_eval_mfma_ws_kernel<50, 0, true", "mixture_eval_grad"), ("mixture_eval_mfma_kernel<50, 0, true", "target_mixture_eval_grad"), ("mixture_eval_mfma_kernel<50, 0, false", "mixture_eval"),
-    ("mixture_eval_kernel<20, 0, true", "mixture_eval_grad"), ("mixture_eval_kernel<20, 0, false", "mixture_eval"),
-    ("mixture_eval_kernel<10, 0, true", "mixture_eval_grad"), ("mixture_eval_kernel<10, 0, false", "mixture_eval"),
+    # density sweeps by their bench.py launch names (the single-call iteration: dual sweep = model gradient instance, post-update
+    # sweep = model log-value instance, target = the other family / the per-wave matrix-core instance at D = 50)
+    ("mixture_eval_kernel<20, 1, true", "sweep_target"), ("mixture_eval_kernel<10, 1, true", "sweep_target"),
+    ("mixture_eval_mfma_ws_kernel<50, 0, true", "sweep_dual"), ("mixture_eval_mfma_kernel<50, 0, true", "sweep_target"), ("mixture_eval_mfma_kernel<50, 0, false", "sweep_post"),
+    ("mixture_eval_kernel<20, 0, true", "sweep_dual"), ("mixture_eval_kernel<20, 0, false", "sweep_post"),
+    ("mixture_eval_kernel<10, 0, true", "sweep_dual"), ("mixture_eval_kernel<10, 0, false", "sweep_post"),
     ("update_kl_fast_kernel", "update_kl"), ("combine_partials_kernel", "mixture_combine"),
     ("sample_components_kernel", "sample_components"), ("elr_kernel", "expected_log_ratios"),
     ("update_weights_kernel", "update_weights"),
