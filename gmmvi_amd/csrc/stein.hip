@@ -81,12 +81,6 @@ static int launch_stein_finalize(gmmvi_ctx* ctx, int K, int D, int R, int N, int
 // slab that stein_finalize sums -- K x R x (D+1)^2 floats with R ~ CUs / stacks ranges instead of one per 256 samples.
 // =====================================================================================================================
 constexpr int SM_RS = 72;          // LDS row stride (floats) of the transposed images: 64 samples + 8
-// Row r of an image starts at SM_ROW(r): stride 72 plus a skew of four floats per sixteen rows.  A ds_read_b128 is served eight
-// lanes (128 bytes) at a time; with the plain stride, rows r and r + 8 k share their four banks -- harmless for the [g; 1]
-// operand (eight consecutive rows per pass) but not for the STACKED [x - mu; 1] operand, whose eight rows wrap around the
-// D + 1 rows of a component (D = 20: rows 16..20, 0, 1, 2 in one pass: 16 / 0, 17 / 1, 18 / 2 collided; 55 % of the LDS
-// cycles of the round-2 kernel were bank conflicts).  The skew moves rows 16..31 by one 16-byte slot, 32..47 by two, ...
-__host__ __device__ constexpr int SM_ROW(int r) { return r * SM_RS + 4 * (r >> 4); }
 constexpr int SM_NBMAX = 5;        // most components stacked in one tile row
 
 // Tiling of the padded dimension DP (covers D in (previous DP, DP]): MT row tiles for the D + 1 rows of [g; 1], NB components
@@ -143,7 +137,7 @@ template <int DP, bool EXACT>
 __device__ __forceinline__ void sm_store_rows(float* t, int D, const float (&v)[DP]) {
 #pragma unroll
     for (int f = 0; f < DP; ++f)
-        if (EXACT || f < SteinTile<DP>::PREV + 1 || f < D) t[SM_ROW(f)] = v[f];
+        if (EXACT || f < SteinTile<DP>::PREV + 1 || f < D) t[f * SM_RS] = v[f];
 }
 
 // VW > 1: the fast instances, D == DP (compile time) and all weights from ld - bg; VW == 1: any D in the class, scalar row
@@ -178,11 +172,11 @@ void stein_moment_kernel(int K, int D_rt, int N, int wave_range, int stacks, int
     // Te rows 0..NB-1 = importance weights, row NB = 0
     const int rows_g = D1 + 1, rows_x = D1;
     constexpr int rows_e = NB + 1;
-    const int wave_floats = SM_ROW(rows_g) + SM_ROW(rows_x) + SM_ROW(rows_e);
+    const int wave_floats = (rows_g + rows_x + rows_e) * SM_RS;
     float* Tg = sm + (size_t)wave * wave_floats;
-    float* Tx = Tg + SM_ROW(rows_g);
-    float* Te = Tx + SM_ROW(rows_x);
-    for (int e = lane; e < SM_RS; e += 64) { Tg[SM_ROW(D1) + e] = 0.f; Te[SM_ROW(NB) + e] = 0.f; Tx[SM_ROW(D) + e] = 1.f; }
+    float* Tx = Tg + rows_g * SM_RS;
+    float* Te = Tx + rows_x * SM_RS;
+    for (int e = lane; e < SM_RS; e += 64) { Tg[D1 * SM_RS + e] = 0.f; Te[NB * SM_RS + e] = 0.f; Tx[D * SM_RS + e] = 1.f; }
 
     // ---- per-lane operand addresses: A rows of the MT row tiles, (x row, e row, mu) of the NT column tiles ---------------
     const int q = lane >> 4, c16 = lane & 15;
@@ -191,7 +185,7 @@ void stein_moment_kernel(int K, int D_rt, int N, int wave_range, int stacks, int
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int row = 16 * mt + c16;
-        a_off[mt] = SM_ROW(row < D1 ? row : D1) + 4 * q;
+        a_off[mt] = (row < D1 ? row : D1) * SM_RS + 4 * q;
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -199,8 +193,8 @@ void stein_moment_kernel(int K, int D_rt, int N, int wave_range, int stacks, int
         const int comp = c / D1, j = c - comp * D1;
         const bool valid = comp < nb;
         cidx[nt] = valid ? comp : NB;
-        x_off[nt] = SM_ROW(valid ? j : 0) + 4 * q;
-        e_off[nt] = SM_ROW(valid ? comp : NB) + 4 * q;
+        x_off[nt] = (valid ? j : 0) * SM_RS + 4 * q;
+        e_off[nt] = (valid ? comp : NB) * SM_RS + 4 * q;
         mu[nt] = (valid && j < D) ? packed[(size_t)(k0 + comp) * Pack<DP>::STRIDE + j] : 0.f;
     }
     const int w_begin = min(N, (range_id * 4 + wave) * wave_range);
@@ -266,8 +260,8 @@ void stein_moment_kernel(int K, int D_rt, int N, int wave_range, int stacks, int
         for (int f = 0; f < DP; ++f) tr[f] -= qr[f];               // g = grad log p~ - grad log q (:248)
         sm_store_rows<DP, EXACT>(Tg + lane, D, tr);
 #pragma unroll
-        for (int c = 0; c < NB; ++c) Te[SM_ROW(c) + lane] = (a[c] > -1.0e38f) ? __expf(a[c] - M[c]) : 0.f;
-        Tg[SM_ROW(D) + lane] = 1.f;
+        for (int c = 0; c < NB; ++c) Te[c * SM_RS + lane] = (a[c] > -1.0e38f) ? __expf(a[c] - M[c]) : 0.f;
+        Tg[D * SM_RS + lane] = 1.f;
         WAVE_LDS_SYNC();
         fetch(n0 + 64);                                            // past the end: clamped rows, never used
 #pragma unroll
@@ -360,7 +354,7 @@ static int launch_stein_moment(gmmvi_ctx* ctx, int K, int D, const float* packed
     if (rc != GMMVI_OK) return rc;
     float* part = (float*)ctx->ws;
     float* part_m = part + part_floats;
-    size_t floats = (size_t)4 * ((2 * D1 + ST::NB + 2) * SM_RS + 3 * 16);        // (+ the row skews of the three images)
+    size_t floats = (size_t)4 * (2 * D1 + ST::NB + 2) * SM_RS;
     if (floats < (size_t)16 * ST::MT * (16 * ST::NT + 1)) floats = (size_t)16 * ST::MT * (16 * ST::NT + 1);
     const size_t shmem = floats * sizeof(float);
     static size_t attr = 64 * 1024;
