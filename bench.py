@@ -93,8 +93,9 @@ def spec(workload, n_gpus, seed=0):
     from helpers import samtron_config
     from oracle import targets as otargets
     kind, d, k_per_gpu, s1 = WORKLOADS[workload][:4]
-    estimator = (WORKLOADS[workload] + ("Stein",))[4]
-    reuse = (WORKLOADS[workload] + ("Stein", 0.0))[5]
+    extra = WORKLOADS[workload][4:]
+    estimator = extra[0] if len(extra) > 0 else "Stein"
+    reuse = float(extra[1]) if len(extra) > 1 else 0.0
     if workload in STRONG_WORKLOADS:
         if k_per_gpu % n_gpus:
             raise SystemExit(f"bench.py: workload {workload} splits K = {k_per_gpu} components evenly; --gpus {n_gpus} does not divide it")
