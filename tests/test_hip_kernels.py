@@ -77,6 +77,44 @@ def test_mixture_eval_gauss(ctx, rng, k, d, n):
     np.testing.assert_allclose(lp2.numpy(), lp.numpy(), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("k,d,n", [(6, 1, 70), (5, 7, 300), (9, 8, 257), (11, 11, 400), (6, 12, 129), (7, 13, 333),
+                                   (12, 16, 500), (5, 17, 260), (10, 23, 300), (9, 24, 300), (64, 20, 4000), (100, 10, 3000)])
+@pytest.mark.parametrize("family", ["gauss", "student_t"])
+def test_mixture_eval_every_padded_dimension(ctx, rng, k, d, n, family):
+    """The scalar-fed sweep with software-pipelined block loads (csrc/subst_phased.h) at every padded dimension it is
+    instantiated for (2, 4, 8, 10, 12, 16, 20, 24: one to nine 32-float pieces per substitution, pieces that start in the
+    middle of a 16-byte word), dimensions below their padding (7 in 8, 11 in 12, 13 in 16, 17 in 20, 23 in 24), ragged last
+    tiles, and component counts that split the sweep into chunks (K = 64 / 100: partial merge)."""
+    m = random_gmm(rng, k, d)
+    x = m.means[rng.integers(0, k, n)] + rng.normal(size=(n, d)) * 1.5
+    logw, means, chols = upload_model(ctx, m)
+    if family == "gauss":
+        packed, _ = ops().pack_components(ctx, means, chols)
+        ld, lp, grad = ops().mixture_eval(ctx, packed, logw, ctx.asarray(x), d, want_ld=True, want_lp=True, want_grad=True)
+        lq, g, cld = m.log_density_and_grad(x.astype(np.float32).astype(np.float64))
+    else:
+        from gmmvi_amd import _lib
+        t = otargets.StudentTMixtureTarget(m.weights, m.means, m.covs, 2.0)
+        packed, _ = ops().pack_components(ctx, means, chols, family=_lib.STUDENT_T, nu=2.0)
+        ld, lp, grad = ops().mixture_eval(ctx, packed, logw, ctx.asarray(x), d, family=_lib.STUDENT_T, nu=2.0, want_ld=True,
+                                          want_lp=True, want_grad=True)
+        xs = x.astype(np.float32).astype(np.float64)
+        lq, g = t.log_density_and_grad(xs)
+        cld = None
+    if cld is not None:
+        np.testing.assert_allclose(ld.numpy(), cld, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(lp.numpy(), lq, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(grad.numpy(), g, rtol=1e-3, atol=1e-3)
+    # the dual sweep (second set of weights over the same components) and the sweep without the gradient agree with it
+    if family == "gauss":
+        logw2 = ctx.asarray(np.log(rng.dirichlet(np.ones(k))).astype(np.float32))
+        ld_d, lp_d, grad_d, lp2_d = ops().mixture_eval_dual(ctx, packed, logw, logw2, ctx.asarray(x), d)
+        np.testing.assert_array_equal(lp_d.numpy(), lp.numpy())
+        np.testing.assert_array_equal(grad_d.numpy(), grad.numpy())
+        _, lp2_ref, _ = ops().mixture_eval(ctx, packed, logw2, ctx.asarray(x), d)
+        np.testing.assert_allclose(lp2_d.numpy(), lp2_ref.numpy(), rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("k,d,n", [(20, 50, 2304), (17, 40, 2100), (16, 32, 2049), (33, 45, 2600)])
 def test_mixture_eval_workgroup_shared_blocks(ctx, rng, k, d, n):
     """K >= 16 and N >= 2048 with the gradient on the matrix-core dimensions: the eight waves of a workgroup share a component
