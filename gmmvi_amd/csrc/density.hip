@@ -123,6 +123,21 @@ typedef float me_f32x4 __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_s_barrier();                          \
         asm volatile("" ::: "memory");                         \
     } while (0)
+// rows of the last 16-row tile of the padded dimension when there are at most four of them (handled on the vector unit by the
+// matrix-core kernels), else 0
+__host__ __device__ constexpr int me_rem_rows(int dp) { return (dp % 16 != 0 && dp % 16 <= 4 && dp > 16) ? dp % 16 : 0; }
+// the value of lane 16 g + R of v in every lane of lane group g (DPP row broadcast)
+template <int R>
+__device__ __forceinline__ float me_row_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + R, 0xf, 0xf, false));
+}
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void me_static_rows(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        me_static_rows<N, I + 1>(f);
+    }
+}
 #ifndef GMMVI_ME_THREADS
 #define GMMVI_ME_THREADS 1024
 #define GMMVI_ME_MINW 1
@@ -450,17 +465,49 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_kernel(float nu, int K_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z[t][mt][r] = 0.f;
         // k-step outermost: consecutive MFMAs go to different accumulators (NTS x MT independent chains), none waits for the
-        // 40-cycle dependent-issue latency of its predecessor
+        // 40-cycle dependent-issue latency of its predecessor.
+        // REM rows in the last 16-row tile (D = 50: rows 48, 49 -- two useful rows for 13 of the 37 forward fragments): those
+        // rows go to the vector unit instead: lane (g, n) multiplies its own k-slots of row R (the fragment value of lane
+        // 16 g + r, fetched by a DPP row broadcast) and the four lane groups are summed; the result lands where the matrix
+        // cores would have put it (register r of the lanes of group 0).
+        constexpr int REM = me_rem_rows(DP);
+        float zr[REM > 0 ? NTS : 1][REM > 0 ? REM : 1];
+        if constexpr (REM > 0) {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t)
+#pragma unroll
+                for (int r = 0; r < REM; ++r) zr[t][r] = 0.f;
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            float bs[NTS];
 #pragma unroll
             for (int t = 0; t < NTS; ++t) {
-                const float b = xb[t][s] - mus[s];
+                bs[t] = xb[t][s] - mus[s];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < (REM > 0 ? MT - 1 : MT); ++mt)
                     if (s < PK::nf(mt))
-                        z[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[PK::fwd_index(mt, s)], b, z[t][mt], 0, 0, 0);
+                        z[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[PK::fwd_index(mt, s)], bs[t], z[t][mt], 0, 0, 0);
             }
+            if constexpr (REM > 0) {
+                me_static_rows<REM>([&](auto R) {
+                    constexpr int r = R;
+                    const float a = me_row_bcast<r>(af[PK::fwd_index(MT - 1, s)]);      // Linv[16 (MT-1) + r][4 s + g]
+#pragma unroll
+                    for (int t = 0; t < NTS; ++t) zr[t][r] = fmaf(a, bs[t], zr[t][r]);
+                });
+            }
+        }
+        if constexpr (REM > 0) {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t)
+#pragma unroll
+                for (int r = 0; r < REM; ++r) {
+                    float v = zr[t][r];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    z[t][MT - 1][r] = g == 0 ? v : 0.f;
+                }
         }
         if constexpr (!GRAD && NTS == 4) {
             // lane = sample (16 g + n of sub-tile g): after the cross-lane completion every lane group holds |z|^2 of all four
@@ -759,19 +806,48 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_ws_kernel(float nu, int
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z[t][mt][r] = 0.f;
+        // (the REM rows of the last 16-row tile on the vector unit, as in the per-wave kernel: lane (g, n) reads the fragment value
+        // of lane 16 g + r from the LDS block)
+        constexpr int REM = me_rem_rows(DP);
+        float zr[REM > 0 ? NTS : 1][REM > 0 ? REM : 1];
+        if constexpr (REM > 0) {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t)
+#pragma unroll
+                for (int r = 0; r < REM; ++r) zr[t][r] = 0.f;
+        }
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             float bx[NTS];
 #pragma unroll
             for (int t = 0; t < NTS; ++t) bx[t] = xb[t][s] - mus[s];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < (REM > 0 ? MT - 1 : MT); ++mt) {
                 if (s < PK::nf(mt)) {
                     const float a = Fw[64 * PK::fwd_index(mt, s)];                      // one fragment read serves NTS MFMAs
 #pragma unroll
                     for (int t = 0; t < NTS; ++t) z[t][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bx[t], z[t][mt], 0, 0, 0);
                 }
             }
+            if constexpr (REM > 0) {
+#pragma unroll
+                for (int r = 0; r < REM; ++r) {
+                    const float a = B[64 * PK::fwd_index(MT - 1, s) + 16 * g + r];       // Linv[16 (MT-1) + r][4 s + g]
+#pragma unroll
+                    for (int t = 0; t < NTS; ++t) zr[t][r] = fmaf(a, bx[t], zr[t][r]);
+                }
+            }
+        }
+        if constexpr (REM > 0) {
+#pragma unroll
+            for (int t = 0; t < NTS; ++t)
+#pragma unroll
+                for (int r = 0; r < REM; ++r) {
+                    float v = zr[t][r];
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    z[t][MT - 1][r] = g == 0 ? v : 0.f;
+                }
         }
 #pragma unroll
         for (int t = 0; t < NTS; ++t) {
