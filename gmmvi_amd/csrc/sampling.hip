@@ -64,6 +64,59 @@ __global__ __launch_bounds__(256) void sample_components_kernel(int K, int D, co
         if (t + 256 * u < D * D) Ls[t + 256 * u] = lreg[u];
     if (t < D) mus[t] = mreg;
     __syncthreads();
+    if constexpr (DP >= 32) {
+        // X = mu + eps L^T as a matrix-core product (v_mfma_f32_16x16x4_f32): a wave owns 64 samples (four 16-row tiles of
+        // eps), A = eps[16 mt + i][4 s + kk], B = L^T: B[kk][j] = L[16 nt + j][4 s + kk], k-steps beyond the diagonal block of
+        // the lower-triangular L skipped.  (One lane per sample with the row of L broadcast from LDS is a chain of D^2 / 2
+        // dependent multiply-adds on 100 of the 256 threads: 16 of the 21 us of the launch at D = 50.)
+        typedef float sc_f32x4 __attribute__((ext_vector_type(4)));
+        constexpr int NT = (DP + 15) / 16, KS = (DP + 3) / 4;
+        const int wave = t >> 6, lane = t & 63, i16 = lane & 15, kk = lane >> 4;
+        const int s0 = 64 * wave;                      // first sample of this wave
+        if (s0 < n_here) {
+            sc_f32x4 acc[4][NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = sc_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s4 = 0; s4 < KS; ++s4) {
+                const int kcol = 4 * s4 + kk;
+                float a[4], b[NT];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int smp = s0 + 16 * mt + i16;
+                    a[mt] = (smp < n_here && kcol < D) ? tile[smp * ldx + kcol] : 0.f;
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int row = 16 * nt + i16;
+                    b[nt] = (row < D && kcol <= row) ? Ls[row * D + kcol] : 0.f;      // lower triangle only (and kcol < D)
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (4 * s4 > 16 * nt + 15) continue;                                // this k-step lies above the diagonal block
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+            // every eps value of the wave's rows has been read (by this wave only): the results overwrite them in place.
+            // D[i][j]: lane l, register r -> sample 16 mt + 4 (l >> 4) + r, dimension 16 nt + (l & 15)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int smp = s0 + 16 * mt + 4 * kk + r, dim = 16 * nt + i16;
+                        if (smp < n_here && dim < D) tile[smp * ldx + dim] = acc[mt][nt][r] + mus[dim];
+                    }
+        }
+        if (valid && mapping) mapping[base + t] = k + mapping_base;
+    } else {
     float eps[DP];
 #pragma unroll
     for (int i = 0; i < DP; ++i) eps[i] = (valid && i < D) ? tile[t * ldx + i] : 0.f;
@@ -79,6 +132,7 @@ __global__ __launch_bounds__(256) void sample_components_kernel(int K, int D, co
             }
         }
         if (mapping) mapping[base + t] = k + mapping_base;
+    }
     }
     __syncthreads();
     for (int e = t; e < n_here * D; e += 256) X[(size_t)base * D + e] = tile[(e / D) * ldx + (e % D)];
