@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("GMMVI_HIP_LIB", os.path.join(_HERE, "libgmmvi_hip.so"
 GAUSS, STUDENT_T = 0, 1
 SELF_NORMALIZED, OWN_SAMPLES_ONLY, EXPLICIT_ESTIMATE = 1, 2, 4
 MAX_DIM = 64
-MORE_REGISTER_MAX_DIM = 21     # gmmvi_more: register-resident ridge system up to here, the tiled route above (register-path dimensions: D <= blocked_above())
+MORE_REGISTER_MAX_DIM = 21     # gmmvi_more: register-resident ridge system up to here, the tiled route above (D <= 63)
 BLOCKED_ABOVE_DEFAULT = 50     # csrc/blocked.h: D > 50 runs the blocked (MFMA) kernels
 
 

@@ -85,6 +85,8 @@ inline int gmmvi_fail(gmmvi_ctx* ctx, int code, const std::string& msg) {
 #define GMMVI_LAUNCH_CHECK(ctx) GMMVI_HIP_CHECK(ctx, hipGetLastError())
 
 int gmmvi_ws_reserve(gmmvi_ctx* ctx, size_t nbytes);
+// density.hip: component blocks in the register-path layout (Pack<padded D>, D <= 64) regardless of the blocked threshold
+int gmmvi_pack_register_layout(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev, float* packed_dev);
 // sampling.hip: gmmvi_sample_components with a caller-known bound on the samples per component (fewer empty workgroups)
 int gmmvi_sample_components_bounded(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
                                     const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed,

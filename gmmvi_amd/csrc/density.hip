@@ -1234,6 +1234,17 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
     }
 }
 
+// C++ linkage (common.h): the register-path block layout (Pack<padded D>) whatever the blocked threshold says -- gmmvi_more
+// reads that layout and re-packs the components of a blocked-path dimension (50 < D <= 63 by default) for its call
+int gmmvi_pack_register_layout(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev, float* packed_dev) {
+    GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && D <= GMMVI_MAX_DIM && means_dev && chols_dev && packed_dev);
+    int dp = gmmvi_padded_dim(D);
+    GMMVI_DISPATCH_DP(dp, hipLaunchKernelGGL((pack_kernel<DP>), dim3(K), dim3(64), 0, ctx->stream, (int)GMMVI_GAUSS, 0.f, K, D,
+                                             means_dev, chols_dev, packed_dev, (float*)nullptr));
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
 extern "C" {
 
 int gmmvi_pack_components(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* means_dev,

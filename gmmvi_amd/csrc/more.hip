@@ -858,10 +858,30 @@ extern "C" int gmmvi_more(gmmvi_ctx* ctx, int K, int D, const float* packed_dev,
                           const float* l2_dev, float* H_neg_out_dev, float* g_neg_out_dev) {
     GMMVI_ARG_CHECK(ctx, K >= 1 && D >= 1 && N >= 1);
     GMMVI_ARG_CHECK(ctx, D < GMMVI_MAX_DIM);
-    // the kernels read the register-path block layout (Pack<DP>); dimensions on the blocked path hand over
-    // [mu | log-normaliser | dense L^-1] blocks of another stride
-    if (gmmvi_is_blocked_dim(D))
-        return gmmvi_fail(ctx, GMMVI_ERR_ARG, "gmmvi_more: no MORE route for dimensions on the blocked path (D > GMMVI_BLOCKED_ABOVE)");
+    // the kernels read the register-path block layout (Pack<DP>); a dimension on the blocked path (50 < D <= 63 by default)
+    // hands over [mu | log-normaliser | pad | dense L^-1] blocks of another stride: the components are re-packed for this call
+    // (the means are the first D floats of a blocked block); beyond D = 63 there is no MORE route (the Stein kernels need D + 1
+    // <= 64 lanes, the whitening its row in registers)
+    float* repacked = nullptr;
+    if (gmmvi_is_blocked_dim(D)) {
+        if (D >= GMMVI_MAX_DIM)
+            return gmmvi_fail(ctx, GMMVI_ERR_ARG, "gmmvi_more: no MORE route beyond D = 63");
+        const size_t rstride = gmmvi_packed_stride_dp(gmmvi_padded_dim(D));
+        float* means_tmp = nullptr;
+        GMMVI_HIP_CHECK(ctx, hipMalloc(&repacked, ((size_t)K * rstride + (size_t)K * D) * sizeof(float)));
+        means_tmp = repacked + (size_t)K * rstride;
+        hipError_t e = hipMemcpy2DAsync(means_tmp, (size_t)D * sizeof(float), packed_dev, gmmvi_blocked_stride(D) * sizeof(float),
+                                        (size_t)D * sizeof(float), (size_t)K, hipMemcpyDeviceToDevice, ctx->stream);
+        int rc = e == hipSuccess ? gmmvi_pack_register_layout(ctx, K, D, means_tmp, chols_dev, repacked)
+                                 : gmmvi_fail(ctx, GMMVI_ERR_HIP, std::string("gmmvi_more: ") + hipGetErrorString(e));
+        if (rc != GMMVI_OK) { (void)hipFree(repacked); return rc; }
+        packed_dev = repacked;
+    }
+    // (the temporary blocks live until the launches below have run: freed after a stream synchronisation)
+    struct Cleanup {
+        gmmvi_ctx* c; float* p;
+        ~Cleanup() { if (p) { (void)hipStreamSynchronize(c->stream); (void)hipFree(p); } }
+    } cleanup{ctx, repacked};
     GMMVI_ARG_CHECK(ctx, packed_dev && chols_dev && X_dev && logq_dev && tlp_dev && l2_dev && H_neg_out_dev && g_neg_out_dev);
     if (flags & GMMVI_OWN_SAMPLES_ONLY) GMMVI_ARG_CHECK(ctx, mapping_dev != nullptr);
     else GMMVI_ARG_CHECK(ctx, ld_dev && bg_dev);

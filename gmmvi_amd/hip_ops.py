@@ -148,9 +148,8 @@ def more(ctx, packed, chols, x, ld, logq, bg, tlp, l2, d, mapping=None, map_offs
     """MORE estimate (gmmvi_more) -> (h_neg [K,D,D], g_neg [K,D])."""
     k = packed.shape[0]
     n = x.shape[0]
-    if d >= _lib.MAX_DIM or d > _lib.blocked_above():
-        raise ValueError(f"MORE estimator: D = {d} is not supported by the HIP kernels (D <= "
-                         f"{min(_lib.MAX_DIM - 1, _lib.blocked_above())}: register-path dimensions only)")
+    if d >= _lib.MAX_DIM:
+        raise ValueError(f"MORE estimator: D = {d} is not supported by the HIP kernels (D <= {_lib.MAX_DIM - 1})")
     _req(packed, (k, packed_stride(d)), name="packed"); _req(chols, (k, d, d), name="chols"); _req(x, (n, d), name="x")
     _req(logq, (n,), name="logq"); _req(tlp, (n,), name="tlp"); _req(l2, (k,), name="l2")
     if own_samples_only:

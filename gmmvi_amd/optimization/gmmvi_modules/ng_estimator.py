@@ -1,3 +1,6 @@
+        from ... import _lib
+        if model.num_dimensions >= _lib.MAX_DIM:
+            raise ValueError(f"MoreNgEstimator: the HIP kernels support D <= {_lib.MAX_DIM - 1} (DESIGN.md section 7)")
 """Natural-gradient estimators (reference: src/gmmvi/optimization/gmmvi_modules/ng_estimator.py:10-376)."""
 import numpy as np
 
@@ -72,7 +75,7 @@ class SteinNgEstimator(NgEstimator):
 class MoreNgEstimator(NgEstimator):
     """ng_estimator.py:266-376 (MORE, codename letter "Z"): importance-weighted quadratic ridge regression of the
     rewards on the samples whitened by each component (least_squares.py:126-191), as one f32-MFMA Gram contraction
-    and one fp64 Cholesky solve per component (csrc/more.hip): register-resident up to D = 21, tiled above (D <= 50 by default: the register-path dimensions)."""
+    and one fp64 Cholesky solve per component (csrc/more.hip): register-resident up to D = 21, tiled above (D <= 63; components of a blocked-path dimension are re-packed for the call)."""
 
     def __init__(self, temperature, model, only_use_own_samples: bool, initial_l2_regularizer: float,
                  use_self_normalized_importance_weights: bool):

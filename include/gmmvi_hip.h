@@ -54,7 +54,7 @@ enum gmmvi_stein_flags {
 };
 
 #define GMMVI_MORE_REGISTER_MAX_DIM 21  /* gmmvi_more: up to here the F x F ridge system (F = D(D+1)/2 + D + 1) is factorised in
-                                         * one workgroup's registers; above (register-path dimensions only: D <= GMMVI_BLOCKED_ABOVE, default 50, at most 63) a tiled Gram launch and a blocked fp64
+                                         * one workgroup's registers; above (D <= 63; components of a blocked-path dimension are re-packed for the call) a tiled Gram launch and a blocked fp64
                                          * Cholesky in global memory take over */
 #define GMMVI_MAX_DIM 64       /* register-resident kernels exist for D <= 64; they are used for D <= 50 (environment
                                 * GMMVI_BLOCKED_ABOVE, 16..64, moves that threshold) */
@@ -179,8 +179,9 @@ int gmmvi_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const flo
  * Inputs: packed blocks + chols[K,D,D] of the model, X[N,D], ld[K,N] and logq[N] (gmmvi_mixture_eval on the same X),
  * bg[N], tlp[N], mapping[N] (GMMVI_OWN_SAMPLES_ONLY only), l2[K] ridge coefficients (GmmWrapper.l2_regularizers).
  * Outputs: H_neg[K,D,D], g_neg[K,D]; NaN for a component whose ridge system is not positive definite.
- * Register-path dimensions only (D <= GMMVI_BLOCKED_ABOVE = 50 by default, at most 63): GMMVI_ERR_ARG on the blocked path,
- * whose component blocks have another layout. */
+ * D <= 63.  For a dimension on the blocked path (50 < D by default) the blocks handed over have another layout: the
+ * components are re-packed in the register-path layout for the call (means from the blocks, factors from chols_dev);
+ * D >= 64: GMMVI_ERR_ARG. */
 int gmmvi_more(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* chols_dev, const float* X_dev, int N,
                const float* ld_dev, const float* logq_dev, const float* bg_dev, const float* tlp_dev,
                const int32_t* mapping_dev, int map_offset, int flags, const float* l2_dev, float* H_neg_out_dev,

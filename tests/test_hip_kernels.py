@@ -301,27 +301,46 @@ def test_more_beyond_the_register_resident_system(ctx, rng, k, d, n, snis):
     assert np.all(np.abs(g - rg) <= 1e-2 * scale_g + 1e-5), np.abs(g - rg).max() / scale_g.max()
 
 
-def test_more_refuses_blocked_path_dimensions(ctx, rng):
+@pytest.mark.parametrize("snis", [True, False])
+def test_more_on_a_blocked_path_dimension(ctx, rng, snis):
     """50 < D <= 63 under the default GMMVI_BLOCKED_ABOVE = 50: the model's component blocks come from the blocked pack
-    ([mu | log-normaliser | dense L^-1], another stride) which the MORE kernels cannot read -- a clean GMMVI_ERR_ARG through
-    the C ABI and a ValueError from the Python mirror, never a launch on a mis-sized block."""
+    ([mu | log-normaliser | dense L^-1], another stride) which the MORE kernels cannot read -- gmmvi_more re-packs the
+    components in the register-path layout for its call (D = 56: F + 1 = 1 654 features) and matches the oracle as the other
+    tiled sizes do; beyond D = 63 it refuses cleanly."""
+    from oracle import more as omore
     from gmmvi_amd import _lib
     if _lib.blocked_above() >= 56:
         pytest.skip("GMMVI_BLOCKED_ABOVE moved: D = 56 is a register-path dimension in this process")
-    k, d, n = 2, 56, 512
+    k, d, n = 1, 56, 9000
     m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
     logw, means, chols = upload_model(ctx, m)
     packed, _ = ops().pack_components(ctx, means, chols)
+    assert packed.shape[1] != 9344                                       # the blocked block, not Pack<64>
     xd = ctx.asarray(x)
     ld, lp, _ = ops().mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_lp=True)
-    l2 = ctx.asarray(np.full(k, 1e-6))
-    with pytest.raises(ValueError, match="MORE"):
-        ops().more(ctx, packed, chols, xd, ld, lp, ctx.asarray(bg), ctx.asarray(tlp), l2, d)
-    h, g = ctx.empty((k, d, d)), ctx.empty((k, d))
-    rc = ctx.lib.gmmvi_more(ctx.handle, k, d, packed.ptr, chols.ptr, xd.ptr, n, ld.ptr, lp.ptr, ctx.asarray(bg).ptr,
-                            ctx.asarray(tlp).ptr, None, 0, 1, l2.ptr, h.ptr, g.ptr)
-    assert rc == -2                                                      # GMMVI_ERR_ARG (include/gmmvi_hip.h)
-    assert b"blocked path" in ctx.lib.gmmvi_last_error(ctx.handle)
+    l2 = np.full(k, 1e-6)
+    h, g = ops().more(ctx, packed, chols, xd, ld, lp, ctx.asarray(bg), ctx.asarray(tlp), ctx.asarray(l2), d, self_normalized=snis)
+    rh, rg = omore.get_expected_hessian_and_grad(m, l2, x, mapping, bg, tlp, False, snis)
+    h, g = h.numpy(), g.numpy()
+    assert np.all(np.isfinite(h)) and np.all(np.isfinite(g))
+    scale_h = np.abs(rh).max(axis=(1, 2), keepdims=True)
+    scale_g = np.abs(rg).max(axis=1, keepdims=True)
+    assert np.all(np.abs(h - rh) <= 1e-2 * scale_h + 1e-5), np.abs(h - rh).max() / scale_h.max()
+    assert np.all(np.abs(g - rg) <= 1e-2 * scale_g + 1e-5), np.abs(g - rg).max() / scale_g.max()
+    if snis:
+        # no route beyond D = 63: a clean error from the Python mirror and GMMVI_ERR_ARG through the C ABI
+        d2, n2 = 70, 256
+        m2, x2, mp2, tlp2, tg2, bg2 = _stein_inputs(rng, 1, d2, n2)
+        lw2, mu2, ch2 = upload_model(ctx, m2)
+        pk2, _ = ops().pack_components(ctx, mu2, ch2)
+        x2d = ctx.asarray(x2)
+        ld2, lp2, _ = ops().mixture_eval(ctx, pk2, lw2, x2d, d2, want_ld=True, want_lp=True)
+        with pytest.raises(ValueError, match="MORE"):
+            ops().more(ctx, pk2, ch2, x2d, ld2, lp2, ctx.asarray(bg2), ctx.asarray(tlp2), ctx.asarray(np.full(1, 1e-6)), d2)
+        hh, gg = ctx.empty((1, d2, d2)), ctx.empty((1, d2))
+        rc = ctx.lib.gmmvi_more(ctx.handle, 1, d2, pk2.ptr, ch2.ptr, x2d.ptr, n2, ld2.ptr, lp2.ptr, ctx.asarray(bg2).ptr,
+                                ctx.asarray(tlp2).ptr, None, 0, 1, ctx.asarray(np.full(1, 1e-6)).ptr, hh.ptr, gg.ptr)
+        assert rc == -2                                                  # GMMVI_ERR_ARG (include/gmmvi_hip.h)
 
 
 @pytest.mark.parametrize("k,d,n", [(2, 10, 40), (3, 20, 150), (4, 20, 240)])
