@@ -1,6 +1,3 @@
-        from ... import _lib
-        if model.num_dimensions >= _lib.MAX_DIM:
-            raise ValueError(f"MoreNgEstimator: the HIP kernels support D <= {_lib.MAX_DIM - 1} (DESIGN.md section 7)")
 """Natural-gradient estimators (reference: src/gmmvi/optimization/gmmvi_modules/ng_estimator.py:10-376)."""
 import numpy as np
 
@@ -88,9 +85,8 @@ class MoreNgEstimator(NgEstimator):
             raise ValueError("MoreNgEstimator needs a full-covariance model (the reference's QuadFunc whitening, "
                              "least_squares.py:126-191, has no diagonal branch)")
         from ... import _lib
-        if model.num_dimensions >= _lib.MAX_DIM or model.num_dimensions > _lib.blocked_above():
-            raise ValueError(f"MoreNgEstimator: the HIP kernels support D <= {min(_lib.MAX_DIM - 1, _lib.blocked_above())} "
-                             "(the register-path dimensions; GMMVI_BLOCKED_ABOVE moves the limit up to 63: DESIGN.md section 7)")
+        if model.num_dimensions >= _lib.MAX_DIM:
+            raise ValueError(f"MoreNgEstimator: the HIP kernels support D <= {_lib.MAX_DIM - 1} (DESIGN.md section 7)")
         self.last_model_densities = None
 
     def get_expected_hessian_and_grad(self, samples, mapping, background_densities, target_lnpdfs,
