@@ -101,6 +101,11 @@ _PROTOS = {
     "gmmvi_allgather_f32": (_i, [_p, _p, _p, _sz]),
     "gmmvi_allreduce_f32": (_i, [_p, _p, _sz, _i]),
     "gmmvi_combine_partials": (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
+    "gmmvi_diag_packed_stride": (_sz, [_i]),
+    "gmmvi_diag_pack": (_i, [_p, _i, _i, _p, _p, _p]),
+    "gmmvi_diag_mixture_eval": (_i, [_p, _i, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "gmmvi_diag_sample": (_i, [_p, _i, _i, _p, _p, _p, _i, _u64, _u64, _i, _p, _p, _p]),
+    "gmmvi_diag_stein": (_i, [_p, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "gmmvi_diag_embed": (_i, [_p, _i, _i, _p, _p]),
     "gmmvi_diag_extract": (_i, [_p, _i, _i, _p, _p]),
     "gmmvi_reciprocal_f32": (_i, [_p, _p, _sz, _p]),

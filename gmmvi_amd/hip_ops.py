@@ -199,6 +199,74 @@ def update_components_plain(ctx, mode, means, chols, h_neg, g_neg, stepsizes, l2
     return success
 
 
+# ---- dedicated kernels for diagonal mixtures (csrc/diag_sweep.hip): O(D) per (sample, component) pair ----------------------
+def diag_packed_stride(d):
+    return int(_lib.load().gmmvi_diag_packed_stride(int(d)))
+
+
+def diag_pack(ctx, means, sigma):
+    """(means [K,D], standard deviations [K,D]) -> component blocks [K, diag_packed_stride(D)]."""
+    k, d = means.shape
+    _req(means, (k, d), name="means"); _req(sigma, (k, d), name="sigma")
+    packed = ctx.empty((k, diag_packed_stride(d)))
+    ctx.check(ctx.lib.gmmvi_diag_pack(ctx.handle, k, d, means.ptr, sigma.ptr, packed.ptr))
+    return packed
+
+
+def diag_mixture_eval(ctx, packed, logw, x, d, want_ld=False, want_lp=True, want_grad=False, logw2=None):
+    """-> (ld [K,N] | None, lp [N] | None, grad [N,D] | None[, lp2 [N] when logw2 is given])."""
+    k = packed.shape[0]
+    n = x.shape[0]
+    _req(packed, (k, diag_packed_stride(d)), name="packed"); _req(logw, (k,), name="logw"); _req(x, (n, d), name="x")
+    if logw2 is not None:
+        _req(logw2, (k,), name="logw2")
+        want_lp = True
+    ld = ctx.empty((k, n)) if want_ld else None
+    lp = ctx.empty((n,)) if want_lp else None
+    grad = ctx.empty((n, d)) if want_grad else None
+    lp2 = ctx.empty((n,)) if logw2 is not None else None
+    if n > 0:
+        ctx.check(ctx.lib.gmmvi_diag_mixture_eval(ctx.handle, k, d, packed.ptr, logw.ptr, None if logw2 is None else logw2.ptr,
+                                                  x.ptr, n, None if ld is None else ld.ptr, None if lp is None else lp.ptr,
+                                                  None if grad is None else grad.ptr, None if lp2 is None else lp2.ptr))
+    return (ld, lp, grad) if logw2 is None else (ld, lp, grad, lp2)
+
+
+def diag_sample(ctx, means, sigma, offsets, n, seed=0, first_index=0, stream_id=0, eps=None):
+    """x = mu_k + sigma_k * eps in component order -> (x [n,D], mapping [n] int32); arguments as sample_components."""
+    k, d = means.shape
+    _req(means, (k, d), name="means"); _req(sigma, (k, d), name="sigma"); _req(offsets, (k + 1,), I32, "offsets")
+    if eps is not None:
+        _req(eps, (n, d), name="eps")
+    x = ctx.empty((n, d))
+    mapping = ctx.empty((n,), np.int32)
+    if n > 0:
+        ctx.check(ctx.lib.gmmvi_diag_sample(ctx.handle, k, d, means.ptr, sigma.ptr, offsets.ptr, n,
+                                            int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_index), int(stream_id),
+                                            None if eps is None else eps.ptr, x.ptr, mapping.ptr))
+    return x, mapping
+
+
+def diag_stein(ctx, packed, x, ld, qgrad, bg, tgrad, d, mapping=None, map_offset=0, self_normalized=True,
+               own_samples_only=False):
+    """Stein estimate of a diagonal mixture -> (h_neg_diag [K,D], g_neg [K,D])."""
+    k = packed.shape[0]
+    n = x.shape[0]
+    _req(packed, (k, diag_packed_stride(d)), name="packed"); _req(x, (n, d), name="x")
+    _req(qgrad, (n, d), name="qgrad"); _req(tgrad, (n, d), name="tgrad")
+    if own_samples_only:
+        _req(mapping, (n,), I32, "mapping")
+    else:
+        _req(ld, (k, n), name="ld"); _req(bg, (n,), name="bg")
+    flags = (_lib.SELF_NORMALIZED if self_normalized else 0) | (_lib.OWN_SAMPLES_ONLY if own_samples_only else 0)
+    h_neg = ctx.empty((k, d))
+    g_neg = ctx.empty((k, d))
+    ctx.check(ctx.lib.gmmvi_diag_stein(ctx.handle, k, d, packed.ptr, x.ptr, n, None if ld is None else ld.ptr, qgrad.ptr,
+                                       None if bg is None else bg.ptr, tgrad.ptr, None if mapping is None else mapping.ptr,
+                                       int(map_offset), flags, h_neg.ptr, g_neg.ptr))
+    return h_neg, g_neg
+
+
 def diag_embed(ctx, chols_diag):
     """[K,D] sigma -> dense lower-triangular factors [K,D,D] = diag(sigma) for the dense density / sampling kernels."""
     k, d = chols_diag.shape

@@ -1,8 +1,9 @@
 """DiagonalGMM on the MI355X (reference: src/gmmvi/models/diagonal_gmm.py:6-59).
 
-``chol_cov`` is the reference's [K, D] array of standard deviations.  The density / gradient / sampling kernels are
-the dense ones, run on the embedded factors L_k = diag(sigma_k) (``hip_ops.diag_embed``; the zeros off the diagonal
-contribute exact zeros); the component updates have their own elementwise kernels (csrc/diag.hip).
+``chol_cov`` is the reference's [K, D] array of standard deviations.  Densities, gradients, the background density and
+sampling run on dedicated O(D)-per-pair kernels (csrc/diag_sweep.hip: component blocks [mu | 1/sigma | 1/sigma^2 | c]); the
+component updates have their own elementwise kernels (csrc/diag.hip).  ``dense_chol`` (the embedded factors diag(sigma)) is
+still available for callers of the dense entry points.
 """
 import numpy as np
 
@@ -24,6 +25,7 @@ class DiagonalGMM(GMM):
             raise ValueError("initial covariance entries must be positive")
         w = np.asarray(weights.numpy() if hasattr(weights, "numpy") else weights, dtype=np.float64)
         self._dense = None
+        self._dense_packed = None
         super().__init__(np.log(w).astype(np.float32), means, np.sqrt(covs_host), ctx)          # :21-27
         self.diagonal_covs = True                                                                # :28
 
@@ -31,6 +33,7 @@ class DiagonalGMM(GMM):
     def _invalidate(self):
         super()._invalidate()
         self._dense = None
+        self._dense_packed = None
 
     @property
     def dense_chol(self):
@@ -39,10 +42,65 @@ class DiagonalGMM(GMM):
         return self._dense
 
     @property
+    def dense_packed(self):
+        """Component blocks of the DENSE kernels on the embedded factors (the Stein estimate of the register-path dimensions)."""
+        if self._dense_packed is None:
+            self._dense_packed, _ = hip_ops.pack_components(self.ctx, self.means, self.dense_chol)
+        return self._dense_packed
+
+    @property
     def packed(self):
+        """Component blocks of the diagonal kernels [K, diag_packed_stride(D)]."""
         if self._packed is None:
-            self._packed, _ = hip_ops.pack_components(self.ctx, self.means, self.dense_chol)
+            self._packed = hip_ops.diag_pack(self.ctx, self.means, self.chol_cov)
         return self._packed
+
+    # ---- densities on the diagonal kernels (gmm.py:183-216, 274-300 with diagonal_gmm.py:47-53) ----------------------------
+    def log_densities_also_individual(self, samples):
+        ld, lp, _ = hip_ops.diag_mixture_eval(self.ctx, self.packed, self.log_weights, self._x(samples),
+                                              self.num_dimensions, want_ld=True, want_lp=True)
+        return lp, ld
+
+    def log_density(self, samples):
+        _, lp, _ = hip_ops.diag_mixture_eval(self.ctx, self.packed, self.log_weights, self._x(samples),
+                                             self.num_dimensions, want_lp=True)
+        return lp
+
+    def eval_with_background(self, samples, log_background_weights):
+        """Background density over the model's own components and the model's log_density_and_grad in one sweep (see
+        GMM.eval_with_background); the model part is cached for the next log_density_and_grad(samples)."""
+        x = self._x(samples)
+        packed = self.packed
+        ld, lp, grad, bg = hip_ops.diag_mixture_eval(self.ctx, packed, self.log_weights, x, self.num_dimensions, want_ld=True,
+                                                     want_lp=True, want_grad=True, logw2=log_background_weights)
+        self._eval_cache = (x.ptr, x.shape, packed, self.log_weights.ptr, (lp, grad, ld))
+        return bg
+
+    def log_density_and_grad(self, samples):
+        x = self._x(samples)
+        c = self._eval_cache
+        if c is not None:
+            self._eval_cache = None
+            if c[0] == x.ptr and c[1] == x.shape and c[2] is self._packed and c[3] == self.log_weights.ptr:
+                return c[4]
+        ld, lp, grad = hip_ops.diag_mixture_eval(self.ctx, self.packed, self.log_weights, x, self.num_dimensions,
+                                                 want_ld=True, want_lp=True, want_grad=True)
+        return lp, grad, ld
+
+    def sample_from_components_no_shuffle(self, samples_per_component, seed=None, first_index=0, eps=None,
+                                          stream_id=None):
+        """gmm.py:361-386 with diagonal_gmm.py:43-45: x = mu + sigma * eps (same Philox counters as the dense kernel)."""
+        from .gmm import STREAM_COMPONENT_NORMALS
+        stream_id = STREAM_COMPONENT_NORMALS if stream_id is None else stream_id
+        n_k = np.asarray(samples_per_component, dtype=np.int64).reshape(-1)
+        if n_k.shape[0] != self.num_components:
+            raise ValueError("samples_per_component must have one entry per component")
+        offsets = np.concatenate([[0], np.cumsum(n_k)]).astype(np.int32)
+        n = int(offsets[-1])
+        offsets_dev = self.ctx.cached_const(("offsets", offsets.tobytes()), lambda: self.ctx.asarray(offsets, np.int32))
+        return hip_ops.diag_sample(self.ctx, self.means, self.chol_cov, offsets_dev, n,
+                                   seed=self.seed if seed is None else seed, first_index=first_index, stream_id=stream_id,
+                                   eps=None if eps is None else self.ctx.asarray(eps))
 
     def _kernel_chol(self):
         return self.dense_chol
@@ -59,8 +117,8 @@ class DiagonalGMM(GMM):
 
     def component_log_densities(self, samples):
         """:47-53 -> [K, N]."""
-        ld, _, _ = hip_ops.mixture_eval(self.ctx, self.packed, self.log_weights, self._x(samples), self.num_dimensions,
-                                        want_ld=True, want_lp=False)
+        ld, _, _ = hip_ops.diag_mixture_eval(self.ctx, self.packed, self.log_weights, self._x(samples), self.num_dimensions,
+                                             want_ld=True, want_lp=False)
         return ld
 
     def component_log_density(self, index, samples):

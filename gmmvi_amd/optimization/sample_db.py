@@ -90,7 +90,9 @@ class SampleDB:
         self._mapping_dev = _Growable(self.ctx, (), np.int32)
         self._means = _Growable(self.ctx, (d,))
         self._chols = _Growable(self.ctx, (d,) if self.diagonal_covariances else (d, d))       # :36-41
-        self._packed = _Growable(self.ctx, (hip_ops.packed_stride(d),))
+        # component blocks of the snapshots: the diagonal kernels' blocks for a diagonal database (csrc/diag_sweep.hip)
+        self._packed = _Growable(self.ctx, (hip_ops.diag_packed_stride(d) if self.diagonal_covariances
+                                            else hip_ops.packed_stride(d),))
         self._mapping_host = _HostGrowable(np.int32)
         self._num_samples_written = 0
         # append log: (first sample, first component, per-component counts); cleared when the DB is thinned out
@@ -153,6 +155,20 @@ class SampleDB:
     def num_samples_written(self):
         return SampleDB._Counter(self)
 
+    def _pack(self, means, chols):
+        """Component blocks of (means, chols) in the layout this database's density kernels read."""
+        if self.diagonal_covariances:
+            if chols.ndim != 2:
+                raise ValueError("SampleDB(diagonal_covariances=True) got [K,D,D] Cholesky factors")
+            return hip_ops.diag_pack(self.ctx, means, chols)
+        return hip_ops.pack_components(self.ctx, means, self._dense(chols))[0]
+
+    def _mixture_lp(self, packed, logw, xs):
+        """log sum_j exp(logw_j) N(x; component j) over packed blocks of this database's layout."""
+        if self.diagonal_covariances:
+            return hip_ops.diag_mixture_eval(self.ctx, packed, logw, xs, self._dim, want_lp=True)[1]
+        return hip_ops.mixture_eval(self.ctx, packed, logw, xs, self._dim, want_lp=True)[1]
+
     def _dense(self, chols):
         """Dense lower-triangular factors for the density kernels ([K,D] standard deviations -> diag(sigma))."""
         if chols.ndim == 2:
@@ -201,7 +217,7 @@ class SampleDB:
         if mapping_host is None:
             mapping_host = np.asarray(mapping.numpy() if isinstance(mapping, DeviceArray) else mapping, np.int32)
         if packed is None:
-            packed, _ = hip_ops.pack_components(ctx, means, self._dense(chols))
+            packed = self._pack(means, chols)
         tl = ctx.asarray(target_lnpdfs); tg = ctx.asarray(target_grads)
         mapping = ctx.asarray(mapping, np.int32)
         if self.keep_samples:
@@ -243,11 +259,9 @@ class SampleDB:
         compatibility; the kernel solves with ``chols``."""
         ctx = self.ctx
         means = ctx.asarray(means); chols = ctx.asarray(chols)
-        packed, _ = hip_ops.pack_components(ctx, means, self._dense(chols))
+        packed = self._pack(means, chols)
         w = np.asarray(weights.numpy() if hasattr(weights, "numpy") else weights, np.float64)
-        _, lp, _ = hip_ops.mixture_eval(ctx, packed, ctx.asarray(np.log(w).astype(np.float32)), ctx.asarray(samples),
-                                        self._dim, want_lp=True)
-        return lp
+        return self._mixture_lp(packed, ctx.asarray(np.log(w).astype(np.float32)), ctx.asarray(samples))
 
     def _active_components(self, start):
         """unique_with_counts of mapping[start:] in first-occurrence order (sample_db.py:221)."""
@@ -293,7 +307,7 @@ class SampleDB:
                 and len(active) == fuse_with_model.num_components):
             bg = fuse_with_model.eval_with_background(xs, logw)
         else:
-            _, bg, _ = hip_ops.mixture_eval(ctx, packed, logw, xs, d, want_lp=True)            # :227
+            bg = self._mixture_lp(packed, logw, xs)                                            # :227
         return (bg, xs, self._mapping_dev.view(start), self._target_lnpdfs.view(start),
                 self._target_grads.view(start))
 

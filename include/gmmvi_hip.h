@@ -309,13 +309,35 @@ int gmmvi_combine_partials(gmmvi_ctx* ctx, int R, int N, int D, const float* lp_
 
 /* ---- diagonal-covariance GMMs (models/diagonal_gmm.py:6-59) ---------------------------------------------------- */
 /* chol[K,D] = sigma (square roots of the covariance diagonal).  Densities / gradients / sampling / background /
- * Stein use the dense entry points above on L = diag(sigma):
+ * Stein CAN use the dense entry points above on L = diag(sigma) (kept for callers that hold dense factors; the Python mirror
+ * uses the dedicated kernels below since round 3):
  * gmmvi_diag_embed writes dense[K,D,D] from diag[K,D]; gmmvi_diag_extract reads diag[K,D] = diagonal of dense[K,D,D]
  * (the diagonal Stein estimate of gmmvi_modules/ng_estimator.py:159-162,:178-181 is the diagonal of gmmvi_stein's
  * H_neg); gmmvi_reciprocal_f32 is SampleDB's inv_chols = 1 / chols (optimization/sample_db.py:119,:130). */
 int gmmvi_diag_embed(gmmvi_ctx* ctx, int K, int D, const float* diag_dev, float* dense_out_dev);
 int gmmvi_diag_extract(gmmvi_ctx* ctx, int K, int D, const float* dense_dev, float* diag_out_dev);
 int gmmvi_reciprocal_f32(gmmvi_ctx* ctx, const float* src_dev, size_t n, float* dst_dev);
+/* Dedicated O(D)-per-pair kernels for diagonal mixtures (csrc/diag_sweep.hip).  Component block of this path
+ * (gmmvi_diag_pack, gmmvi_diag_packed_stride(D) floats): [mu | 1/sigma | 1/sigma^2 | log-normaliser | padding].
+ *   gmmvi_diag_mixture_eval  DiagonalGMM.component_log_densities / log_density / log_density_and_grad (models/diagonal_gmm.py:
+ *                            40-53, models/gmm.py:183-216,274-300) and SampleDB's background density over diagonal snapshots
+ *                            (sample_db.py:164-228); logw2 / lp2_out: a second mixture over the same components (may be NULL)
+ *   gmmvi_diag_sample        GMM.sample_from_components_no_shuffle for a DiagonalGMM (x = mu + sigma * eps,
+ *                            models/diagonal_gmm.py:43-45): same offsets / Philox arguments as gmmvi_sample_components
+ *   gmmvi_diag_stein         SteinNgEstimator, diagonal branches (ng_estimator.py:159-162,:178-181): h_neg_diag[K,D], g_neg[K,D];
+ *                            arguments as gmmvi_stein */
+size_t gmmvi_diag_packed_stride(int D);
+int gmmvi_diag_pack(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* sigma_dev, float* packed_out_dev);
+int gmmvi_diag_mixture_eval(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* logw_dev, const float* logw2_dev,
+                            const float* X_dev, int N, float* ld_out_dev, float* lp_out_dev, float* grad_out_dev,
+                            float* lp2_out_dev);
+int gmmvi_diag_sample(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* sigma_dev, const int32_t* offsets_dev,
+                      int N, uint64_t seed, uint64_t first_index, int stream_id, const float* eps_dev, float* X_out_dev,
+                      int32_t* mapping_out_dev);
+int gmmvi_diag_stein(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* X_dev, int N, const float* ld_dev,
+                     const float* qgrad_dev, const float* bg_dev, const float* tgrad_dev, const int32_t* mapping_dev,
+                     int map_offset, int flags, float* h_neg_diag_out_dev, float* g_neg_out_dev);
+
 /* KLConstrainedNgBasedComponentUpdater.apply_NG_update, diagonal branches (gmmvi_modules/
  * ng_based_component_updater.py:447-453, kl() :304-318, :483-490); same contract as gmmvi_update_components_kl with
  * chols[K,D] and H_neg[K,D].  D <= GMMVI_MAX_DIM_BLOCKED. */

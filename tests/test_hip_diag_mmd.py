@@ -51,6 +51,73 @@ def test_diag_densities_grad_sampling(ctx, rng, k, d, n):
     np.testing.assert_allclose(xs.numpy(), oxs, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("k,d,n", [(40, 20, 300), (3, 300, 130), (2, 512, 70), (70, 33, 1000), (64, 5, 2000), (9, 96, 257)])
+def test_diag_sweep_kernels(ctx, rng, k, d, n):
+    """The dedicated O(D)-per-pair kernels (csrc/diag_sweep.hip) through their own entry points: component chunks with a
+    partial merge (K = 40 / 64 / 70 on few tiles), dimensions of several 32-float pieces with a ragged last piece (33, 96, 300,
+    512), the dual sweep (second set of weights over the same components), sampling from the device Philox stream."""
+    from gmmvi_amd import hip_ops
+    from oracle import philox
+    m = random_diag_gmm(rng, k, d)
+    x = (m.means[rng.integers(0, k, n)] + rng.normal(size=(n, d)) * 1.5).astype(np.float32)
+    means, sigma = ctx.asarray(m.means), ctx.asarray(m.chol_cov)
+    logw = ctx.asarray(m.log_weights)
+    packed = hip_ops.diag_pack(ctx, means, sigma)
+    assert packed.shape == (k, hip_ops.diag_packed_stride(d))
+    xd = ctx.asarray(x)
+    ld, lp, grad = hip_ops.diag_mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_lp=True, want_grad=True)
+    olp, ograd, old = m.log_density_and_grad(x.astype(np.float64))
+    np.testing.assert_allclose(ld.numpy(), old, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(lp.numpy(), olp, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(grad.numpy(), ograd, rtol=1e-3, atol=1e-3)
+    # gradient without asking for the log densities (internal scratch), log values alone
+    _, lp_b, grad_b = hip_ops.diag_mixture_eval(ctx, packed, logw, xd, d, want_ld=False, want_lp=False, want_grad=True)
+    assert lp_b is None
+    np.testing.assert_array_equal(grad_b.numpy(), grad.numpy())
+    np.testing.assert_array_equal(hip_ops.diag_mixture_eval(ctx, packed, logw, xd, d)[1].numpy(), lp.numpy())
+    # dual sweep
+    w2 = rng.dirichlet(np.ones(k))
+    logw2 = ctx.asarray(np.log(w2).astype(np.float32))
+    ld2, lp2a, grad2, lp2b = hip_ops.diag_mixture_eval(ctx, packed, logw, xd, d, want_ld=True, want_grad=True, logw2=logw2)
+    np.testing.assert_array_equal(lp2a.numpy(), lp.numpy())
+    np.testing.assert_array_equal(grad2.numpy(), grad.numpy())
+    from scipy.special import logsumexp
+    np.testing.assert_allclose(lp2b.numpy(), logsumexp(old + np.log(w2)[:, None], axis=0), rtol=1e-4, atol=1e-3)
+    # sampling: device Philox stream == oracle Philox stream, x = mu + sigma * eps
+    n_k = rng.integers(0, 9, k)
+    ns = int(n_k.sum())
+    offs = ctx.asarray(np.concatenate([[0], np.cumsum(n_k)]).astype(np.int32), np.int32)
+    xs, mp = hip_ops.diag_sample(ctx, means, sigma, offs, ns, seed=3, first_index=100)
+    eps = philox.normals(3, 100, ns, d)
+    oxs, omp = m.sample_from_components_no_shuffle(n_k, eps)
+    np.testing.assert_array_equal(mp.numpy(), omp)
+    np.testing.assert_allclose(xs.numpy(), oxs, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k,d,n", [(5, 20, 600), (3, 70, 500)])
+@pytest.mark.parametrize("snis", [True, False])
+def test_diag_stein_own_samples(ctx, rng, k, d, n, snis):
+    """only_use_own_samples on a diagonal model (ng_estimator.py:110-118 with the diagonal branches :159-162, :178-181)."""
+    from gmmvi_amd.models.gmm_wrapper import GmmWrapper
+    from gmmvi_amd.optimization.gmmvi_modules.ng_estimator import SteinNgEstimator
+    m = random_diag_gmm(rng, k, d)
+    g = GmmWrapper(device_diag(ctx, m), 0.1, 1e-12, 4)
+    mp = np.sort(rng.integers(0, k, n)).astype(np.int32)
+    mp[-1] = k - 1                                                     # the newest sample belongs to the newest component
+    x = (m.means[mp] + rng.normal(size=(n, d)) * 1.2).astype(np.float32)
+    x64 = x.astype(np.float64)
+    bg = m.log_density(x64).astype(np.float32)
+    tlp = rng.normal(size=n).astype(np.float32)
+    tg = rng.normal(size=(n, d)).astype(np.float32)
+    est = SteinNgEstimator(1.0, g, only_use_own_samples=True, use_self_normalized_importance_weights=snis)
+    h, gr = est.get_expected_hessian_and_grad(ctx.asarray(x), ctx.asarray(mp, np.int32), ctx.asarray(bg), ctx.asarray(tlp),
+                                              ctx.asarray(tg))
+    oh, og = ostein.get_expected_hessian_and_grad(m, x64, mp, bg.astype(np.float64), tlp.astype(np.float64),
+                                                  tg.astype(np.float64), True, snis)
+    np.testing.assert_allclose(h.numpy(), oh, rtol=2e-3, atol=2e-4 * max(1.0, np.abs(oh).max()))
+    np.testing.assert_allclose(gr.numpy(), og, rtol=2e-3, atol=2e-4 * max(1.0, np.abs(og).max()))
+
+
 def test_diag_embed_extract_roundtrip(ctx, rng):
     from gmmvi_amd import hip_ops
     a = rng.normal(size=(5, 37)).astype(np.float32)
