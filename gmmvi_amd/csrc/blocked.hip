@@ -67,16 +67,61 @@ __device__ __forceinline__ float4 ld4(const float* p, int nvalid, bool vec) {
 }
 __device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---- split-operand route (SPLIT = 1): the same f32 contraction on the bf16 matrix cores ------------------------------
+// Every f32 operand element is written as x = x1 + x2 + x3 with three bf16 values (round-to-nearest splits: |x2| <= 2^-9 |x|,
+// |x3| <= 2^-18 |x|, residual <= 2^-27 |x|); a product x y is the sum of the six partial products x_i y_j with i + j <= 4
+// (each EXACT in f32: 8 x 8 significant bits), accumulated in f32 by v_mfma_f32_32x32x16_bf16, smallest terms first.  The
+// dropped terms (x2 y3, x3 y2, x3 y3 and the residuals) are below 2^-25 |x y|: less than the rounding of one f32 multiply-add,
+// so the result carries the error of an f32 contraction (tests/test_hip_blocked.py measures both routes against fp64).
+// Six bf16 MFMAs (6 x 32 cycles per 32 x 32 x 16) replace eight f32 MFMAs (8 x 64 cycles): 2.7 x the matrix-core rate.
+// LDS images per operand and plane, 16 k per step: a k-contiguous operand is stored in fragment order ([k / 8][row][k % 8]:
+// lane l of a ds_read_b128 reads 16 consecutive bytes after lane l - 1); a k-major operand is stored [k][row] (row stride
+// 2 * rowsp bytes = 64 or 192 mod 256: the four k rows of a transposed read fall into disjoint banks) and read with
+// ds_read_b64_tr_b16, which hands lane i of a 16-lane group column i of a 4 x 16 block -- the MFMA operand order.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    const f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+}
+// (a, b) -> three packed bf16 pairs, a in the low half
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    p1 = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
+    p2 = cvt_pk_bf16(ra, rb);
+    p3 = cvt_pk_bf16(ra - __uint_as_float(p2 << 16), rb - __uint_as_float(p2 & 0xffff0000u));
+}
+constexpr int split_rowsp(int rows) {                  // row stride (elements) of a k-major bf16 image
+    int r = rows;
+    while (r % 128 != 32 && r % 128 != 96) r += 4;
+    return r;
+}
+__device__ __forceinline__ i32x4 lds_tr_frag(const unsigned char* base, int byte_off, int row_stride_bytes) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + byte_off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(base + byte_off + 4 * row_stride_bytes));
+    i32x4 r;
+    r[0] = __builtin_bit_cast(int2, lo).x; r[1] = __builtin_bit_cast(int2, lo).y;
+    r[2] = __builtin_bit_cast(int2, hi).x; r[3] = __builtin_bit_cast(int2, hi).y;
+    return r;
+}
+
 // NT: 32-column MFMA tiles per wave; AK / BKM: operand is k-major in memory; PRO: prologue on A (0 none, 1 subtract a
 // vector along k, 2 scale rows, 3 scale along k, 4 subtract a vector along the rows, then scale along k: k-major A only).  Every step takes one of two routes, chosen uniformly: the fast route
 // (aligned operands, a full 16-wide k step, every 16-byte piece entirely valid or entirely void -- decided once per thread)
 // issues all loads back to back without a branch; the edge route handles ragged ends element by element.
-template <int NT, int AK, int BKM, int PRO>
-__global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void bgemm_kernel(BG g) {
+template <int NT, int AK, int BKM, int PRO, int SPLIT>
+__global__ __launch_bounds__(256, (PRO == 2 || SPLIT) ? 2 : 3) void bgemm_kernel(BG g) {
     constexpr int BN = 32 * NT, LDB_S = BN + 4;
     constexpr int NVB = (BN * BK / 4 + 255) / 256;          // 16-byte pieces of the B tile per thread
-    __shared__ __align__(16) float As[2][BK * LDA_S];
-    __shared__ __align__(16) float Bs[2][BK * LDB_S];
+    // split route: bytes of one bf16 plane of a 16-k step, row strides of the k-major images
+    constexpr int RSA = split_rowsp(BM), RSB = split_rowsp(BN);
+    constexpr int APL = AK ? BK * RSA * 2 : BK * BM * 2, BPL = BKM ? BK * RSB * 2 : BK * BN * 2;
+    __shared__ __align__(16) float As[2][SPLIT ? 3 * APL / 4 : BK * LDA_S];
+    __shared__ __align__(16) float Bs[2][SPLIT ? 3 * BPL / 4 : BK * LDB_S];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
@@ -226,6 +271,31 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void bgemm_kernel(BG g) {
 #pragma unroll
             for (int u = 0; u < NVB; ++u) rb[u] = b_ok[u] ? rb[u] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if constexpr (SPLIT) {
+            // uint2 index of a piece inside a plane: k-major [k][row] (4 rows of one k) / fragment order (4 k of one row)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                uint32_t lo[3], hi[3];
+                split_pair(ra[u].x, ra[u].y, lo[0], lo[1], lo[2]);
+                split_pair(ra[u].z, ra[u].w, hi[0], hi[1], hi[2]);
+                const int at = AK ? (a_k[u] * RSA + a_r[u]) >> 2 : (((a_k[u] >> 3) * BM + a_r[u]) << 1) + ((a_k[u] >> 2) & 1);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(As[buf]) + pl * APL)[at] = make_uint2(lo[pl], hi[pl]);
+            }
+#pragma unroll
+            for (int u = 0; u < NVB; ++u) {
+                if (b_c[u] >= BN) continue;
+                uint32_t lo[3], hi[3];
+                split_pair(rb[u].x, rb[u].y, lo[0], lo[1], lo[2]);
+                split_pair(rb[u].z, rb[u].w, hi[0], hi[1], hi[2]);
+                const int at = BKM ? (b_k[u] * RSB + b_c[u]) >> 2 : (((b_k[u] >> 3) * BN + b_c[u]) << 1) + ((b_k[u] >> 2) & 1);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(Bs[buf]) + pl * BPL)[at] = make_uint2(lo[pl], hi[pl]);
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (AK) {
@@ -261,6 +331,47 @@ __global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void bgemm_kernel(BG g) {
     for (int step = 0; step < total; ++step) {
         if (step + 1 < total) gload(step + 1);
         const int k0 = kb + (step % spb) * BK;
+        if constexpr (SPLIT) {
+            const unsigned char* sa = reinterpret_cast<const unsigned char*>(As[buf]);
+            const unsigned char* sb = reinterpret_cast<const unsigned char*>(Bs[buf]);
+            // lane's place in a transposed read: group gq = lane / 16 covers operand rows 16 (gq & 1) .., k 8 (gq >> 1) ..;
+            // lane 4 q + p of the group addresses k row q, rows 4 p .. 4 p + 3
+            const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
+            const int tr_k = 8 * (tg >> 1) + tq, tr_r = 16 * (tg & 1) + 4 * tp;
+            i32x4 af[3], bf[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                if (AK) af[pl] = lds_tr_frag(sa + pl * APL, (tr_k * RSA + wave * 32 + tr_r) * 2, RSA * 2);
+                else af[pl] = reinterpret_cast<const i32x4*>(sa + pl * APL)[half * BM + wave * 32 + col];
+            }
+            auto bload = [&](int t, i32x4* dst) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    if (BKM) dst[pl] = lds_tr_frag(sb + pl * BPL, (tr_k * RSB + 32 * t + tr_r) * 2, RSB * 2);
+                    else dst[pl] = reinterpret_cast<const i32x4*>(sb + pl * BPL)[half * BN + 32 * t + col];
+                }
+            };
+            bload(0, bf[0]);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t + 1 < NT) bload(t + 1, bf[(t + 1) & 1]);
+                const int c0 = n0 + 32 * t;
+                if (c0 < g.N && !(g.tri == 1 && k0 >= c0 + 32) && !(g.tri == 2 && k0 + BK <= c0)) {
+                    const i32x4* b = bf[t & 1];
+                    // smallest partial products first
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[2]), "v"(b[0]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[0]), "v"(b[2]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[1]), "v"(b[1]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[1]), "v"(b[0]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[0]), "v"(b[1]));
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[0]), "v"(b[0]));
+                }
+            }
+            if (step + 1 < total) sstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+            continue;
+        }
         const float* a_ = As[buf] + half * LDA_S + wave * 32 + col;
         const float* b_ = Bs[buf] + half * LDB_S + col;
         float av[BK / 2];
@@ -355,8 +466,15 @@ int bgemm_col_tiles(int n) {
     return best / (32 * nt);
 }
 
-template <int AK, int BKM, int PRO>
-int bgemm_launch(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
+// GMMVI_BLOCKED_F32=1 keeps every contraction on the f32 matrix-core instruction (v_mfma_f32_32x32x2_f32); the default is
+// the split-operand route above
+bool bgemm_split_enabled() {
+    static const bool off = getenv("GMMVI_BLOCKED_F32") != nullptr && atoi(getenv("GMMVI_BLOCKED_F32")) != 0;
+    return !off;
+}
+
+template <int AK, int BKM, int PRO, int SPLIT>
+int bgemm_launch_route(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
     int nt = 4, best = 1 << 30;
     for (int c = 5; c >= 3; --c) {                       // least padded width; ties go to the wider tile
         const int w = (g.N + 32 * c - 1) / (32 * c) * 32 * c;
@@ -364,12 +482,18 @@ int bgemm_launch(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
     }
     dim3 grid(best / (32 * nt), (g.M + BM - 1) / BM, batches_outer * (g.ksplit > 1 ? g.ksplit : 1));
     switch (nt) {
-        case 3: hipLaunchKernelGGL((bgemm_kernel<3, AK, BKM, PRO>), grid, dim3(256), 0, ctx->stream, g); break;
-        case 4: hipLaunchKernelGGL((bgemm_kernel<4, AK, BKM, PRO>), grid, dim3(256), 0, ctx->stream, g); break;
-        default: hipLaunchKernelGGL((bgemm_kernel<5, AK, BKM, PRO>), grid, dim3(256), 0, ctx->stream, g); break;
+        case 3: hipLaunchKernelGGL((bgemm_kernel<3, AK, BKM, PRO, SPLIT>), grid, dim3(256), 0, ctx->stream, g); break;
+        case 4: hipLaunchKernelGGL((bgemm_kernel<4, AK, BKM, PRO, SPLIT>), grid, dim3(256), 0, ctx->stream, g); break;
+        default: hipLaunchKernelGGL((bgemm_kernel<5, AK, BKM, PRO, SPLIT>), grid, dim3(256), 0, ctx->stream, g); break;
     }
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
+}
+
+template <int AK, int BKM, int PRO>
+int bgemm_launch(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
+    if (bgemm_split_enabled()) return bgemm_launch_route<AK, BKM, PRO, 1>(ctx, g, batches_outer);
+    return bgemm_launch_route<AK, BKM, PRO, 0>(ctx, g, batches_outer);
 }
 
 // the operand layouts / prologues the callers below use
