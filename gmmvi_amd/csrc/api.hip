@@ -58,6 +58,7 @@ void gmmvi_ctx_destroy(gmmvi_ctx* ctx) {
     }
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->bimg) (void)hipFree(ctx->bimg);
     if (ctx->defer_ws) (void)hipFree(ctx->defer_ws);
     delete ctx;
 }

@@ -51,6 +51,7 @@ struct BG {
     // row] (one partial per column tile; the caller adds the tiles).  no_store: the result itself is not written.
     float* rowsq; long long rs_tile, rs_batch;
     int no_store;
+    int debug;                       // experiments (GMMVI_BG_DEBUG): 1 no MFMAs, 2 no split / LDS writes, 4 no global loads
 };
 
 constexpr int BM = 128, BK = 16, LDA_S = BM + 4;
@@ -113,15 +114,12 @@ __device__ __forceinline__ i32x4 lds_tr_frag(const unsigned char* base, int byte
 // vector along k, 2 scale rows, 3 scale along k, 4 subtract a vector along the rows, then scale along k: k-major A only).  Every step takes one of two routes, chosen uniformly: the fast route
 // (aligned operands, a full 16-wide k step, every 16-byte piece entirely valid or entirely void -- decided once per thread)
 // issues all loads back to back without a branch; the edge route handles ragged ends element by element.
-template <int NT, int AK, int BKM, int PRO, int SPLIT>
-__global__ __launch_bounds__(256, (PRO == 2 || SPLIT) ? 2 : 3) void bgemm_kernel(BG g) {
+template <int NT, int AK, int BKM, int PRO>
+__global__ __launch_bounds__(256, PRO == 2 ? 2 : 3) void bgemm_kernel(BG g) {
     constexpr int BN = 32 * NT, LDB_S = BN + 4;
     constexpr int NVB = (BN * BK / 4 + 255) / 256;          // 16-byte pieces of the B tile per thread
-    // split route: bytes of one bf16 plane of a 16-k step, row strides of the k-major images
-    constexpr int RSA = split_rowsp(BM), RSB = split_rowsp(BN);
-    constexpr int APL = AK ? BK * RSA * 2 : BK * BM * 2, BPL = BKM ? BK * RSB * 2 : BK * BN * 2;
-    __shared__ __align__(16) float As[2][SPLIT ? 3 * APL / 4 : BK * LDA_S];
-    __shared__ __align__(16) float Bs[2][SPLIT ? 3 * BPL / 4 : BK * LDB_S];
+    __shared__ __align__(16) float As[2][BK * LDA_S];
+    __shared__ __align__(16) float Bs[2][BK * LDB_S];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, half = lane >> 5;
@@ -271,31 +269,6 @@ __global__ __launch_bounds__(256, (PRO == 2 || SPLIT) ? 2 : 3) void bgemm_kernel
 #pragma unroll
             for (int u = 0; u < NVB; ++u) rb[u] = b_ok[u] ? rb[u] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if constexpr (SPLIT) {
-            // uint2 index of a piece inside a plane: k-major [k][row] (4 rows of one k) / fragment order (4 k of one row)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                uint32_t lo[3], hi[3];
-                split_pair(ra[u].x, ra[u].y, lo[0], lo[1], lo[2]);
-                split_pair(ra[u].z, ra[u].w, hi[0], hi[1], hi[2]);
-                const int at = AK ? (a_k[u] * RSA + a_r[u]) >> 2 : (((a_k[u] >> 3) * BM + a_r[u]) << 1) + ((a_k[u] >> 2) & 1);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(As[buf]) + pl * APL)[at] = make_uint2(lo[pl], hi[pl]);
-            }
-#pragma unroll
-            for (int u = 0; u < NVB; ++u) {
-                if (b_c[u] >= BN) continue;
-                uint32_t lo[3], hi[3];
-                split_pair(rb[u].x, rb[u].y, lo[0], lo[1], lo[2]);
-                split_pair(rb[u].z, rb[u].w, hi[0], hi[1], hi[2]);
-                const int at = BKM ? (b_k[u] * RSB + b_c[u]) >> 2 : (((b_k[u] >> 3) * BN + b_c[u]) << 1) + ((b_k[u] >> 2) & 1);
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
-                    reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(Bs[buf]) + pl * BPL)[at] = make_uint2(lo[pl], hi[pl]);
-            }
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (AK) {
@@ -331,47 +304,6 @@ __global__ __launch_bounds__(256, (PRO == 2 || SPLIT) ? 2 : 3) void bgemm_kernel
     for (int step = 0; step < total; ++step) {
         if (step + 1 < total) gload(step + 1);
         const int k0 = kb + (step % spb) * BK;
-        if constexpr (SPLIT) {
-            const unsigned char* sa = reinterpret_cast<const unsigned char*>(As[buf]);
-            const unsigned char* sb = reinterpret_cast<const unsigned char*>(Bs[buf]);
-            // lane's place in a transposed read: group gq = lane / 16 covers operand rows 16 (gq & 1) .., k 8 (gq >> 1) ..;
-            // lane 4 q + p of the group addresses k row q, rows 4 p .. 4 p + 3
-            const int tq = (lane >> 2) & 3, tp = lane & 3, tg = lane >> 4;
-            const int tr_k = 8 * (tg >> 1) + tq, tr_r = 16 * (tg & 1) + 4 * tp;
-            i32x4 af[3], bf[2][3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                if (AK) af[pl] = lds_tr_frag(sa + pl * APL, (tr_k * RSA + wave * 32 + tr_r) * 2, RSA * 2);
-                else af[pl] = reinterpret_cast<const i32x4*>(sa + pl * APL)[half * BM + wave * 32 + col];
-            }
-            auto bload = [&](int t, i32x4* dst) {
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    if (BKM) dst[pl] = lds_tr_frag(sb + pl * BPL, (tr_k * RSB + 32 * t + tr_r) * 2, RSB * 2);
-                    else dst[pl] = reinterpret_cast<const i32x4*>(sb + pl * BPL)[half * BN + 32 * t + col];
-                }
-            };
-            bload(0, bf[0]);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (t + 1 < NT) bload(t + 1, bf[(t + 1) & 1]);
-                const int c0 = n0 + 32 * t;
-                if (c0 < g.N && !(g.tri == 1 && k0 >= c0 + 32) && !(g.tri == 2 && k0 + BK <= c0)) {
-                    const i32x4* b = bf[t & 1];
-                    // smallest partial products first
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[2]), "v"(b[0]));
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[0]), "v"(b[2]));
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[1]), "v"(b[1]));
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[1]), "v"(b[0]));
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[0]), "v"(b[1]));
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[0]), "v"(b[0]));
-                }
-            }
-            if (step + 1 < total) sstore(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
-            continue;
-        }
         const float* a_ = As[buf] + half * LDA_S + wave * 32 + col;
         const float* b_ = Bs[buf] + half * LDB_S + col;
         float av[BK / 2];
@@ -449,21 +381,410 @@ __global__ __launch_bounds__(256, (PRO == 2 || SPLIT) ? 2 : 3) void bgemm_kernel
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// the same contraction, split-operand route: role-specialised workgroup on v_mfma_f32_32x32x16_bf16
+// ---------------------------------------------------------------------------------------------------------------------------
+// A wave issues one instruction every four cycles whatever its kind, an MFMA of this shape occupies the matrix core for 32:
+// the kernel is paced by the matrix cores only if fewer than ~7 other instructions are issued per MFMA, address arithmetic
+// and loop control included (first version of this route, every wave staging and multiplying: 8.9 vector + 7.4 scalar
+// instructions per MFMA, matrix cores 19 % busy).  Hence:
+//  * the B operand (component data / shared rows: reused by every row tile) is split ONCE per launch by bsplit_image_kernel
+//    into the exact byte order of the LDS stage (per 16-k step: [plane][k half][column][8 k] bf16, transposed, masked for
+//    triangular operands, zero-padded): staging B is a 16-byte copy;
+//  * 512 threads: waves 0..3 MULTIPLY (wave w owns rows 32 w .. of the 128 x 32 NT tile; NT up to 10, so D <= 320 is ONE
+//    column tile and (x - mu) is read and split once per component): LDS fragment reads and MFMAs only, the first fragments
+//    of the next step are read before the last MFMAs of this one are issued; waves 4..7 STAGE: global loads (three register
+//    stages: the loads of step s + 3 are issued when step s has been handed to LDS), the element-wise prologue and the
+//    3-way split of A, the LDS writes;
+//  * LDS is a ring of three stages; one LDS-only barrier per step (s_waitcnt lgkmcnt(0) + s_barrier: the stagers' global
+//    loads stay in flight across it): during step t the multipliers read stage t % 3 (and the head of stage (t + 1) % 3,
+//    complete since the previous barrier) while the stagers fill stage (t + 2) % 3.
+#define BG_LDS_BARRIER()                                       \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_s_barrier();                          \
+        asm volatile("" ::: "memory");                         \
+    } while (0)
+
+template <int N> using bg_ic = std::integral_constant<int, N>;
+
+// bytes of the B image of one (batch, 16-k step): three planes x two k halves x ncolp columns x 8 bf16
+__host__ __device__ inline size_t bimg_step_bytes(int ncolp) { return (size_t)96 * ncolp; }
+
+// B image: thread = (column n, k half h) of one (step, batch): eight k values -> three 16-byte fragments
+__global__ __launch_bounds__(256) void bsplit_image_kernel(BG g, int ncolp, int nsteps, unsigned char* img) {
+    const int step = blockIdx.x, b = blockIdx.y;
+    const float* Bb = g.B + (long long)b * g.sB;
+    unsigned char* out = img + ((size_t)b * nsteps + step) * bimg_step_bytes(ncolp);
+    for (int e = threadIdx.x; e < 2 * ncolp; e += 256) {
+        const int h = e / ncolp, n = e - h * ncolp;
+        const int k0 = step * BK + 8 * h;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            bool live = n < g.N && k < g.Kd;
+            if (g.tri == 1) live = live && k <= n;
+            if (g.tri == 2) live = live && k >= n;
+            v[j] = live ? (g.b_kmajor ? Bb[(long long)k * g.ldb + n] : Bb[(long long)n * g.ldb + k]) : 0.f;
+        }
+        uint32_t p[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_pair(v[2 * j], v[2 * j + 1], p[0][j], p[1][j], p[2][j]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<uint4*>(out + ((size_t)(pl * 2 + h) * ncolp + n) * 16) = make_uint4(p[pl][0], p[pl][1], p[pl][2], p[pl][3]);
+    }
+}
+
+template <int NT, int AK, int PRO>
+__global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned char* __restrict__ bimg, int ncolp, int nsteps) {
+    constexpr int BN = 32 * NT;
+    constexpr int RSA = split_rowsp(BM);
+    // fragment-order plane of a k-contiguous A: two k halves of [row][8 k] (+128 bytes between them: the two halves a
+    // ds_write_b64 touches fall into different banks); B stage = the image slice, k halves BHS apart
+    constexpr int AHS = BM * 16 + 128, BHS = BN * 16 + 128;
+    constexpr int APL = AK ? BK * RSA * 2 : 2 * AHS, BPL = 2 * BHS;
+    constexpr int STG = 3 * (APL + BPL);                    // bytes of one ring stage: three planes of each operand
+    constexpr int NCB = (6 * BN + 255) / 256;               // 16-byte chunks of the B stage per staging thread
+    __shared__ __align__(16) unsigned char ring[3 * STG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int nsplit = g.ksplit > 1 ? g.ksplit : 1;
+    const int bz = blockIdx.z / nsplit, kz = blockIdx.z - bz * nsplit;
+    int Mb = g.M;
+    long long rowbase = 0;
+    if (g.row_off) { rowbase = g.row_off[bz]; Mb = g.row_off[bz + 1] - (int)rowbase; }
+    if (m0 >= Mb) return;
+    int kb = 0, ke = g.Kd;                                  // kb: a multiple of 16 (the image is cut in 16-k steps from k = 0)
+    if (g.tri == 1) ke = min(g.Kd, n0 + BN);
+    else if (g.tri == 2) kb = min(g.Kd, n0) & ~15;
+    if (nsplit > 1) {
+        const int chunk = ((g.Kd + nsplit - 1) / nsplit + BK - 1) / BK * BK;
+        kb = min(g.Kd, kz * chunk);
+        ke = min(g.Kd, kb + chunk);
+    }
+    const int spb = (ke - kb + BK - 1) / BK;
+    const int nb = g.inner > 0 ? min(g.inner, g.inner_total - bz * g.inner) : 1;
+    const int total = nb * spb;
+    const int total3 = (total + 2) / 3 * 3;            // barriers after the first one, both roles
+
+    if (wave >= 4) {
+        // ------------------------------------------------ staging waves ------------------------------------------------
+        const int pt = tid - 256;
+        const float* A0 = g.A + (AK ? rowbase : rowbase * g.lda);
+        const float* pro = PRO == 1 ? g.a_sub : (PRO == 2 ? g.a_rscale : (PRO >= 3 ? g.a_kscale : nullptr));
+        const long long s_pro = PRO == 1 ? g.s_asub : (PRO == 2 ? g.s_ars : (PRO >= 3 ? g.s_aks : 0));
+        const bool vecR = PRO != 4 || (al16(g.a_rsub) && (g.s_arsub & 3) == 0);
+        const bool vecA = al16(A0) && ((g.lda | g.sA) & 3) == 0;
+        const bool vecP = PRO == 0 || (al16(pro) && (s_pro & 3) == 0);
+        // A pieces as in bgemm_kernel; a_at: where a piece goes inside a plane (units of 8 bytes)
+        int a_r[2], a_k[2], a_at[2];
+        bool a_ok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int idx = pt + 256 * u;
+            if (AK) { a_k[u] = idx >> 5; a_r[u] = 4 * (idx & 31); } else { a_r[u] = idx >> 2; a_k[u] = 4 * (idx & 3); }
+            a_ok[u] = m0 + a_r[u] < Mb;
+            a_at[u] = AK ? (a_k[u] * RSA + a_r[u]) >> 2 : ((a_k[u] >> 3) * AHS + a_r[u] * 16 + ((a_k[u] >> 2) & 1) * 8) >> 3;
+        }
+        // B chunks: chunk q = (plane-and-half ph = q / BN, column c = q % BN): image offset and LDS offset, fixed for the launch
+        unsigned b_go[NCB], b_lo[NCB];
+        bool b_has[NCB];
+#pragma unroll
+        for (int u = 0; u < NCB; ++u) {
+            const int q = pt + 256 * u;
+            const int ph = q / BN, c = q - ph * BN;
+            b_has[u] = q < 6 * BN;
+            b_go[u] = b_has[u] ? ((unsigned)ph * ncolp + n0 + c) * 16u : 0u;
+            b_lo[u] = (unsigned)(3 * APL + (ph >> 1) * BPL + (ph & 1) * BHS + c * 16);
+        }
+        const size_t img_step = bimg_step_bytes(ncolp);
+        auto split_store_a = [&](unsigned char* sa, const float4* va) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                uint32_t lo[3], hi[3];
+                split_pair(va[u].x, va[u].y, lo[0], lo[1], lo[2]);
+                split_pair(va[u].z, va[u].w, hi[0], hi[1], hi[2]);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) reinterpret_cast<uint2*>(sa + pl * APL)[a_at[u]] = make_uint2(lo[pl], hi[pl]);
+            }
+        };
+        // Fast route (decided once per workgroup): aligned A, every 16-byte piece entirely inside or entirely outside the
+        // operand (k range and row range), byte offsets that fit 32 bits.  One straight-line load routine, no merge of
+        // register values with another route: the loads of three steps stay in flight.
+        const long long extA = AK ? (long long)g.Kd * g.lda : (long long)Mb * g.lda;
+        const bool fast = vecA && vecP && vecR && (!AK || (Mb & 3) == 0 || m0 + BM <= Mb) && (AK || ((kb | ke) & 3) == 0) &&
+                          extA < (1ll << 29);
+        if (fast) {
+            // byte offsets of the pieces from the operand's place at (batch, k = kb); pieces outside the row range read piece 0
+            unsigned a_bo[2], p_bo[2], r_bo[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                a_bo[u] = a_ok[u] ? 4u * (unsigned)(AK ? a_k[u] * g.lda + m0 + a_r[u] : (m0 + a_r[u]) * g.lda + a_k[u]) : 0u;
+                // prologue vector: along k (PRO 1, 3, 4) or along the rows (PRO 2); PRO 4: second vector along the rows
+                p_bo[u] = PRO == 2 ? 4u * (unsigned)(a_ok[u] ? m0 + a_r[u] : 0) : 4u * (unsigned)a_k[u];
+                r_bo[u] = 4u * (unsigned)(a_ok[u] ? m0 + a_r[u] : 0);
+            }
+            const unsigned a_kstep = 4u * (unsigned)(AK ? g.lda : 1);
+            float4 ra[3][2], pv[3][2], pw[3][2];
+            i32x4 rb[3][NCB];
+            int klim[3] = {0, 0, 0};                 // ke - k0 of the step a register stage holds
+            int ld_bi = 0, ld_ks = 0, ld_n = 0;      // (inner batch, k step, index) of the next step to load: steps are loaded in order
+            auto gload = [&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                // (behind the last step the last step is loaded again and never handed over: every path through the loop
+                // issues the same number of loads, which lets the compiler wait with vmcnt(two stages) instead of vmcnt(0))
+                const long long b = (long long)bz * (g.inner > 0 ? g.inner : 1) + ld_bi;
+                const int k0 = kb + ld_ks * BK;
+                const unsigned kofs = (unsigned)(ld_ks * BK);
+                if (++ld_n < total && ++ld_ks == spb) { ld_ks = 0; ++ld_bi; }
+                klim[R] = ke - k0;
+                const char* Ab = reinterpret_cast<const char*>(A0 + b * g.sA + (AK ? (long long)kb * g.lda : (long long)kb));
+                const unsigned char* Bi = bimg + ((size_t)(g.sB ? b : 0) * nsteps + (k0 >> 4)) * img_step;
+                const char* pb = PRO ? reinterpret_cast<const char*>(pro + b * s_pro + (PRO == 2 ? 0 : kb)) : nullptr;
+                const char* pr = PRO == 4 ? reinterpret_cast<const char*>(g.a_rsub + b * g.s_arsub) : nullptr;
+                // a piece whose k lies behind ke reads the step-0 place of the same piece (valid memory), masked at the hand-over
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned ko = a_k[u] < klim[R] ? kofs : 0u;
+                    ra[R][u] = *reinterpret_cast<const float4*>(Ab + (a_bo[u] + ko * a_kstep));
+                }
+#pragma unroll
+                for (int u = 0; u < NCB; ++u) rb[R][u] = *reinterpret_cast<const i32x4*>(Bi + b_go[u]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (PRO == 2) {
+                        if (AK) pv[R][u] = *reinterpret_cast<const float4*>(pb + p_bo[u]);
+                        else { const float sc = *reinterpret_cast<const float*>(pb + p_bo[u]); pv[R][u] = make_float4(sc, sc, sc, sc); }
+                    } else if (PRO != 0) {
+                        const unsigned ko = a_k[u] < klim[R] ? kofs : 0u;
+                        if (AK) { const float sc = *reinterpret_cast<const float*>(pb + (p_bo[u] + 4u * ko)); pv[R][u] = make_float4(sc, sc, sc, sc); }
+                        else pv[R][u] = *reinterpret_cast<const float4*>(pb + (p_bo[u] + 4u * ko));
+                        if (PRO == 4) pw[R][u] = *reinterpret_cast<const float4*>(pr + r_bo[u]);
+                    }
+                }
+            };
+            auto sstore = [&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                unsigned char* stage = ring + R * STG;       // step s lives in register stage and ring stage s % 3
+                float4 va[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float4 v = ra[R][u];
+                    if (PRO == 1) { v.x -= pv[R][u].x; v.y -= pv[R][u].y; v.z -= pv[R][u].z; v.w -= pv[R][u].w; }
+                    if (PRO == 4) { v.x -= pw[R][u].x; v.y -= pw[R][u].y; v.z -= pw[R][u].z; v.w -= pw[R][u].w; }
+                    if (PRO >= 2) { v.x *= pv[R][u].x; v.y *= pv[R][u].y; v.z *= pv[R][u].z; v.w *= pv[R][u].w; }
+                    va[u] = (a_ok[u] && a_k[u] < klim[R]) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                split_store_a(stage, va);
+#pragma unroll
+                for (int u = 0; u < NCB; ++u)
+                    if (b_has[u]) *reinterpret_cast<i32x4*>(stage + b_lo[u]) = rb[R][u];
+            };
+            if (total > 0) {
+                // (scheduling barriers: the loads must be ISSUED in step order -- the waits count loads issued later)
+                gload(bg_ic<0>());
+                __builtin_amdgcn_sched_barrier(0);
+                gload(bg_ic<1>());
+                __builtin_amdgcn_sched_barrier(0);
+                gload(bg_ic<2>());
+                __builtin_amdgcn_sched_barrier(0);
+                sstore(bg_ic<0>());
+                gload(bg_ic<0>());
+                __builtin_amdgcn_sched_barrier(0);
+                if (1 < total) sstore(bg_ic<1>());
+                gload(bg_ic<1>());
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            BG_LDS_BARRIER();
+            // during step t: fill ring stage (t + 2) % 3 with step t + 2, then load step t + 5 into the freed registers.  The loop
+            // runs over total3 steps (total rounded up to a multiple of 3; the extra steps only meet the barrier) and has no
+            // early exit: every path to a hand-over has issued the same loads in the same order
+            for (int t = 0; t < total3; t += 3) {
+                if (t + 2 < total) sstore(bg_ic<2>());
+                gload(bg_ic<2>());
+                BG_LDS_BARRIER();
+                if (t + 3 < total) sstore(bg_ic<0>());
+                gload(bg_ic<0>());
+                BG_LDS_BARRIER();
+                if (t + 4 < total) sstore(bg_ic<1>());
+                gload(bg_ic<1>());
+                BG_LDS_BARRIER();
+            }
+            return;
+        }
+        // General route (misaligned or ragged A): element-wise loads, one step at a time, same ring protocol
+        auto stage_step = [&](int step) {
+            const int bi = step / spb;
+            const long long b = (long long)bz * (g.inner > 0 ? g.inner : 1) + bi;
+            const int k0 = kb + (step - bi * spb) * BK;
+            const float* Ab = A0 + b * g.sA;
+            const unsigned char* Bi = bimg + ((size_t)(g.sB ? b : 0) * nsteps + (k0 >> 4)) * img_step;
+            const float* pb = PRO ? pro + b * s_pro : nullptr;
+            const float* pr = PRO == 4 ? g.a_rsub + b * g.s_arsub : nullptr;
+            unsigned char* stage = ring + (step % 3) * STG;
+            float4 va[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int gm = m0 + a_r[u], gk = k0 + a_k[u];
+                float4 v;
+                if (AK) {                                           // 4 consecutive rows of one k
+                    const int nv = (gk < ke) ? Mb - gm : 0;
+                    v = ld4(Ab + (long long)gk * g.lda + gm, nv, vecA);
+                    if (nv > 0) {
+                        if (PRO == 1) { const float sc = pb[gk]; v.x -= sc; v.y -= sc; v.z -= sc; v.w -= sc; }
+                        if (PRO == 3) { const float sc = pb[gk]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+                        if (PRO == 2) { const float4 sc = ld4(pb + gm, nv, vecP); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+                        if (PRO == 4) {
+                            const float4 r4 = ld4(pr + gm, nv, vecR);
+                            const float sc = pb[gk];
+                            v.x = (v.x - r4.x) * sc; v.y = (v.y - r4.y) * sc; v.z = (v.z - r4.z) * sc; v.w = (v.w - r4.w) * sc;
+                        }
+                        if (nv < 4) { if (nv < 2) v.y = 0.f; if (nv < 3) v.z = 0.f; v.w = 0.f; }
+                    }
+                } else {                                            // 4 consecutive k of one row
+                    const int nv = (gm < Mb) ? ke - gk : 0;
+                    v = ld4(Ab + (long long)gm * g.lda + gk, nv, vecA);
+                    if (nv > 0) {
+                        if (PRO == 1) { const float4 sc = ld4(pb + gk, nv, vecP); v.x -= sc.x; v.y -= sc.y; v.z -= sc.z; v.w -= sc.w; }
+                        if (PRO == 3) { const float4 sc = ld4(pb + gk, nv, vecP); v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+                        if (PRO == 2) { const float sc = pb[gm]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+                        if (nv < 4) { if (nv < 2) v.y = 0.f; if (nv < 3) v.z = 0.f; v.w = 0.f; }
+                    }
+                }
+                va[u] = v;
+            }
+            split_store_a(stage, va);
+#pragma unroll
+            for (int u = 0; u < NCB; ++u)
+                if (b_has[u]) *reinterpret_cast<i32x4*>(stage + b_lo[u]) = *reinterpret_cast<const i32x4*>(Bi + b_go[u]);
+        };
+        if (0 < total) stage_step(0);
+        if (1 < total) stage_step(1);
+        BG_LDS_BARRIER();
+        for (int t = 0; t < total3; ++t) {
+            if (t + 2 < total) stage_step(t + 2);
+            BG_LDS_BARRIER();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------- multiplying waves ----------------------------------------------------
+    const int col = lane & 31, half = lane >> 5;
+    // lane's place in a transposed read (k-major A): group lane / 16 covers operand rows 16 (group & 1) .., k 8 (group >> 1) ..;
+    // lane 4 q + p of the group addresses k row q, rows 4 p .. 4 p + 3
+    const int tr_k = 8 * (lane >> 5) + ((lane >> 2) & 3), tr_r = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int a_rd = AK ? (tr_k * RSA + wave * 32 + tr_r) * 2 : half * AHS + (wave * 32 + col) * 16;
+    const int b_rd = 3 * APL + half * BHS + col * 16;
+    auto aload = [&](const unsigned char* stage, i32x4* dst) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            if (AK) dst[pl] = lds_tr_frag(stage + pl * APL, a_rd, RSA * 2);
+            else dst[pl] = *reinterpret_cast<const i32x4*>(stage + pl * APL + a_rd);
+        }
+    };
+    auto bload = [&](const unsigned char* stage, int t, i32x4* dst) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const i32x4*>(stage + pl * BPL + b_rd + 512 * t);
+    };
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // sub-tile t (columns n0 + 32 t ..) takes part in a step unless opB vanishes there (triangular operands) or the columns do
+    // not exist: t_lo <= t < t_hi, from the step's k0
+    const int t_end = min(NT, (g.N - n0 + 31) >> 5);
+    BG_LDS_BARRIER();
+    i32x4 af[3], bf[2][3], afn[3], bfn[3];
+    if (total > 0) { aload(ring, af); bload(ring, 0, bf[0]); }
+    int slot = 0, ks = 0;
+    for (int step = 0; step < total; ++step) {
+        const int k0 = kb + ks * BK;
+        if (++ks == spb) ks = 0;
+        const int t_lo = g.tri == 1 ? max(0, (k0 - n0) >> 5) : 0;                       // live iff k0 < n0 + 32 t + 32
+        const int t_hi = g.tri == 2 ? min(t_end, (k0 + BK - n0 + 31) >> 5) : t_end;     // live iff k0 + 16 > n0 + 32 t
+        const unsigned char* stage = ring + slot * STG;
+        slot = slot == 2 ? 0 : slot + 1;
+        const unsigned char* next = ring + slot * STG;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) bload(stage, t + 1, bf[(t + 1) & 1]);
+            else if (step + 1 < total) { aload(next, afn); bload(next, 0, bfn); }
+            if (t >= t_lo && t < t_hi) {
+                const i32x4* b = bf[t & 1];
+                // smallest partial products first
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[2]), "v"(b[0]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[0]), "v"(b[2]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[1]), "v"(b[1]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[1]), "v"(b[0]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[0]), "v"(b[1]));
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[0]), "v"(b[0]));
+            }
+        }
+        BG_LDS_BARRIER();
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { af[pl] = afn[pl]; bf[0][pl] = bfn[pl]; }
+    }
+    for (int step = total; step < total3; ++step) BG_LDS_BARRIER();
+    // the last MFMA must have retired before its accumulators are read (inline asm: no automatic hazard nops)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (g.rowsq != nullptr) {
+        // lane (col, half) holds rows (r & 3) + 8 (r >> 2) + 4 half of its column in every sub-tile: square-sum over the
+        // sub-tiles, then over the 32 lanes of the half on the DPP network (four steps inside a row of 16, two v_readlane
+        // per half); lane i of the wave collects the sum of row i: one 128-byte store
+        float mine = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float z = g.alpha * acc[t][r];
+                if (n0 + 32 * t + col < g.N) v = fmaf(z, z, v);
+            }
+            v += gmmvi_dpp<0xB1>(v);
+            v += gmmvi_dpp<0x4E>(v);
+            v += gmmvi_dpp<0x141>(v);
+            v += gmmvi_dpp<0x140>(v);
+            const float s0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
+                             __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+            const float s1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
+                             __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+            const int i0 = (r & 3) + 8 * (r >> 2);
+            mine = lane == i0 ? s0 : (lane == i0 + 4 ? s1 : mine);
+        }
+        float* rq = g.rowsq + (long long)blockIdx.x * g.rs_tile + (long long)blockIdx.z * g.rs_batch + rowbase;
+        const int i = m0 + wave * 32 + lane;
+        if (lane < 32 && i < Mb) rq[i] = mine;
+    }
+    if (g.no_store) return;
+    float* Cb = g.C + (long long)blockIdx.z * g.sC + rowbase * g.ldc;
+    const float* bias = g.c_bias ? g.c_bias + (long long)bz * g.s_cb : nullptr;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int j = n0 + 32 * t + col;
+        if (j >= g.N) continue;
+        const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (i < Mb) {
+                float* p = Cb + (long long)i * g.ldc + j;
+                float v = fmaf(g.alpha, acc[t][r], bj);
+                if (g.accumulate) v += *p;
+                *p = v;
+            }
+        }
+    }
+}
+
 BG bg_zero() {
     BG g;
     memset(&g, 0, sizeof(g));
     g.alpha = 1.f;
     return g;
-}
-
-// number of column tiles bgemm_launch will use for a result of n columns (same rule as below)
-int bgemm_col_tiles(int n) {
-    int nt = 4, best = 1 << 30;
-    for (int c = 5; c >= 3; --c) {
-        const int w = (n + 32 * c - 1) / (32 * c) * 32 * c;
-        if (w < best) { best = w; nt = c; }
-    }
-    return best / (32 * nt);
 }
 
 // GMMVI_BLOCKED_F32=1 keeps every contraction on the f32 matrix-core instruction (v_mfma_f32_32x32x2_f32); the default is
@@ -473,27 +794,77 @@ bool bgemm_split_enabled() {
     return !off;
 }
 
-template <int AK, int BKM, int PRO, int SPLIT>
-int bgemm_launch_route(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
-    int nt = 4, best = 1 << 30;
-    for (int c = 5; c >= 3; --c) {                       // least padded width; ties go to the wider tile
-        const int w = (g.N + 32 * c - 1) / (32 * c) * 32 * c;
-        if (w < best) { best = w; nt = c; }
+// tile widths of the two routes: f32 route 32 x {3, 4, 5}, split route 32 x {3, 4, 5, 6, 8, 10}: the least padded total width,
+// ties go to the wider tile.  -> NT, *tiles = number of column tiles
+int bgemm_tile_width(int n, bool split, int* tiles) {
+    static const int f32_nt[] = {5, 4, 3}, split_nt[] = {10, 8, 6, 5, 4, 3};
+    const int* cand = split ? split_nt : f32_nt;
+    const int nc = split ? 6 : 3;
+    int nt = cand[0], best = 1 << 30;
+    for (int i = 0; i < nc; ++i) {
+        const int w = (n + 32 * cand[i] - 1) / (32 * cand[i]) * 32 * cand[i];
+        if (w < best) { best = w; nt = cand[i]; }
     }
-    dim3 grid(best / (32 * nt), (g.M + BM - 1) / BM, batches_outer * (g.ksplit > 1 ? g.ksplit : 1));
-    switch (nt) {
-        case 3: hipLaunchKernelGGL((bgemm_kernel<3, AK, BKM, PRO, SPLIT>), grid, dim3(256), 0, ctx->stream, g); break;
-        case 4: hipLaunchKernelGGL((bgemm_kernel<4, AK, BKM, PRO, SPLIT>), grid, dim3(256), 0, ctx->stream, g); break;
-        default: hipLaunchKernelGGL((bgemm_kernel<5, AK, BKM, PRO, SPLIT>), grid, dim3(256), 0, ctx->stream, g); break;
-    }
-    GMMVI_LAUNCH_CHECK(ctx);
+    *tiles = best / (32 * nt);
+    return nt;
+}
+
+// number of column tiles bgemm_launch will use for a result of n columns
+int bgemm_col_tiles(int n) {
+    int tiles = 1;
+    (void)bgemm_tile_width(n, bgemm_split_enabled(), &tiles);
+    return tiles;
+}
+
+int bimg_reserve(gmmvi_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->bimg_bytes) return GMMVI_OK;
+    GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->bimg) GMMVI_HIP_CHECK(ctx, hipFree(ctx->bimg));
+    ctx->bimg = nullptr;
+    ctx->bimg_bytes = 0;
+    const size_t want = bytes + bytes / 4;
+    GMMVI_HIP_CHECK(ctx, hipMalloc(&ctx->bimg, want));
+    ctx->bimg_bytes = want;
     return GMMVI_OK;
 }
 
 template <int AK, int BKM, int PRO>
-int bgemm_launch(gmmvi_ctx* ctx, const BG& g, int batches_outer) {
-    if (bgemm_split_enabled()) return bgemm_launch_route<AK, BKM, PRO, 1>(ctx, g, batches_outer);
-    return bgemm_launch_route<AK, BKM, PRO, 0>(ctx, g, batches_outer);
+int bgemm_launch(gmmvi_ctx* ctx, const BG& g0, int batches_outer) {
+    const bool split = bgemm_split_enabled();
+    int tiles = 1;
+    const int nt = bgemm_tile_width(g0.N, split, &tiles);
+    dim3 grid(tiles, (g0.M + BM - 1) / BM, batches_outer * (g0.ksplit > 1 ? g0.ksplit : 1));
+    if (!split) {
+        switch (nt) {
+            case 3: hipLaunchKernelGGL((bgemm_kernel<3, AK, BKM, PRO>), grid, dim3(256), 0, ctx->stream, g0); break;
+            case 4: hipLaunchKernelGGL((bgemm_kernel<4, AK, BKM, PRO>), grid, dim3(256), 0, ctx->stream, g0); break;
+            default: hipLaunchKernelGGL((bgemm_kernel<5, AK, BKM, PRO>), grid, dim3(256), 0, ctx->stream, g0); break;
+        }
+        GMMVI_LAUNCH_CHECK(ctx);
+        return GMMVI_OK;
+    }
+    static const int dbg = getenv("GMMVI_BG_DEBUG") ? atoi(getenv("GMMVI_BG_DEBUG")) : 0;
+    BG g = g0;
+    g.debug = dbg;
+    // the B image: every batch of B (one if B is shared: sB == 0), every 16-k step of [0, Kd)
+    const int ncolp = tiles * nt * 32, nsteps = (g.Kd + BK - 1) / BK;
+    const long long nbatch = g.sB ? (g.inner > 0 ? (long long)g.inner_total : (long long)batches_outer) : 1;
+    const size_t bytes = (size_t)nbatch * nsteps * bimg_step_bytes(ncolp);
+    int rc = bimg_reserve(ctx, bytes);
+    if (rc != GMMVI_OK) return rc;
+    unsigned char* img = static_cast<unsigned char*>(ctx->bimg);
+    hipLaunchKernelGGL(bsplit_image_kernel, dim3(nsteps, (unsigned)nbatch), dim3(256), 0, ctx->stream, g, ncolp, nsteps, img);
+    GMMVI_LAUNCH_CHECK(ctx);
+    switch (nt) {
+        case 3: hipLaunchKernelGGL((bgemm_ws_kernel<3, AK, PRO>), grid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps); break;
+        case 4: hipLaunchKernelGGL((bgemm_ws_kernel<4, AK, PRO>), grid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps); break;
+        case 5: hipLaunchKernelGGL((bgemm_ws_kernel<5, AK, PRO>), grid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps); break;
+        case 6: hipLaunchKernelGGL((bgemm_ws_kernel<6, AK, PRO>), grid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps); break;
+        case 8: hipLaunchKernelGGL((bgemm_ws_kernel<8, AK, PRO>), grid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps); break;
+        default: hipLaunchKernelGGL((bgemm_ws_kernel<10, AK, PRO>), grid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps); break;
+    }
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
 }
 
 // the operand layouts / prologues the callers below use

@@ -31,6 +31,8 @@ struct gmmvi_ctx {
     uint64_t ws_epoch = 0;       // bumped by every gmmvi_ws_reserve: the scratch contents belong to the call that reserved them
     void* arena = nullptr;       // persistent scratch of the single-call iteration (fused.hip)
     size_t arena_bytes = 0;
+    void* bimg = nullptr;        // split bf16 images of the B operands of the blocked contractions (blocked.hip), grown on demand
+    size_t bimg_bytes = 0;
     bool defer_combine = false;  // set by fused.hip around a sweep whose merge the next launch carries
     CombineJob pending;          // R > 0: partials in defer_ws wait for their merge
     void* defer_ws = nullptr;    // partials of a deferred merge (ctx->ws is reused by the launches in between)
