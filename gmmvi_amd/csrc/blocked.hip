@@ -437,22 +437,57 @@ __global__ __launch_bounds__(256) void bsplit_image_kernel(BG g, int ncolp, int 
     }
 }
 
-template <int NT, int AK, int PRO>
-__global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned char* __restrict__ bimg, int ncolp, int nsteps) {
+// experiment switches (GMMVI_BG_DEBUG) exist only in -DBG_STAMPS builds: a runtime branch around a load or a hand-over changes
+// what the compiler can prove about the loads in flight
+#ifdef BG_STAMPS
+#define BG_DBG(bit) (g.debug & (bit))
+#else
+#define BG_DBG(bit) 0
+#endif
+#ifdef BG_STAMPS
+#define BG_CLK() __builtin_readcyclecounter()
+#define BG_BARRIER_TIMED(acc_)                                 \
+    do {                                                       \
+        const unsigned long long b0__ = BG_CLK();              \
+        BG_LDS_BARRIER();                                      \
+        acc_ += BG_CLK() - b0__;                               \
+    } while (0)
+#else
+#define BG_BARRIER_TIMED(acc_) BG_LDS_BARRIER()
+#endif
+
+// bytes of the LDS ring of bgemm_ws_kernel<NT, AK, .>
+template <int NT, int AK>
+constexpr int bg_ws_ring_bytes() {
     constexpr int BN = 32 * NT;
+    constexpr int APL = AK ? BK * split_rowsp(BM) * 2 : 2 * (BM * 16 + 128), BPL = 2 * (BN * 16 + 128);
+    return 3 * (3 * (APL + BPL) + 4096);
+}
+
+// one tile (bx, by, bzz) of the launch: both roles leave this function after 1 + total3 barriers
+template <int NT, int AK, int PRO>
+__device__ __forceinline__ void bgemm_ws_tile(const BG& g, const unsigned char* __restrict__ bimg, int ncolp, int nsteps,
+                                              unsigned char* ring, const int bx, const int by, const int bzz) {
+    constexpr int BN = 32 * NT;
+#ifdef BG_STAMPS
+    const unsigned long long st0 = BG_CLK();
+    unsigned long long bwait = 0;
+#endif
     constexpr int RSA = split_rowsp(BM);
     // fragment-order plane of a k-contiguous A: two k halves of [row][8 k] (+128 bytes between them: the two halves a
     // ds_write_b64 touches fall into different banks); B stage = the image slice, k halves BHS apart
     constexpr int AHS = BM * 16 + 128, BHS = BN * 16 + 128;
     constexpr int APL = AK ? BK * RSA * 2 : 2 * AHS, BPL = 2 * BHS;
-    constexpr int STG = 3 * (APL + BPL);                    // bytes of one ring stage: three planes of each operand
+    // bytes of one ring stage: three planes of each operand (+4 KB: where the staging threads put the chunks that do not
+    // exist, so that their stores need no branch)
+    constexpr int STG = 3 * (APL + BPL) + 4096;
     constexpr int NCB = (6 * BN + 255) / 256;               // 16-byte chunks of the B stage per staging thread
-    __shared__ __align__(16) unsigned char ring[3 * STG];
+    static_assert(3 * STG == bg_ws_ring_bytes<NT, AK>(), "ring size");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
     const int nsplit = g.ksplit > 1 ? g.ksplit : 1;
-    const int bz = blockIdx.z / nsplit, kz = blockIdx.z - bz * nsplit;
+    const int bz = bzz / nsplit, kz = bzz - bz * nsplit;
     int Mb = g.M;
     long long rowbase = 0;
     if (g.row_off) { rowbase = g.row_off[bz]; Mb = g.row_off[bz + 1] - (int)rowbase; }
@@ -472,6 +507,8 @@ __global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned c
 
     if (wave >= 4) {
         // ------------------------------------------------ staging waves ------------------------------------------------
+        // (priority: the multiplying waves are the older ones and win the arbitration for the vector issue port otherwise)
+        if (!BG_DBG(256)) __builtin_amdgcn_s_setprio(3);
         const int pt = tid - 256;
         const float* A0 = g.A + (AK ? rowbase : rowbase * g.lda);
         const float* pro = PRO == 1 ? g.a_sub : (PRO == 2 ? g.a_rscale : (PRO >= 3 ? g.a_kscale : nullptr));
@@ -498,7 +535,7 @@ __global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned c
             const int ph = q / BN, c = q - ph * BN;
             b_has[u] = q < 6 * BN;
             b_go[u] = b_has[u] ? ((unsigned)ph * ncolp + n0 + c) * 16u : 0u;
-            b_lo[u] = (unsigned)(3 * APL + (ph >> 1) * BPL + (ph & 1) * BHS + c * 16);
+            b_lo[u] = b_has[u] ? (unsigned)(3 * APL + (ph >> 1) * BPL + (ph & 1) * BHS + c * 16) : (unsigned)(STG - 4096 + pt * 16);
         }
         const size_t img_step = bimg_step_bytes(ncolp);
         auto split_store_a = [&](unsigned char* sa, const float4* va) {
@@ -536,13 +573,14 @@ __global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned c
                 constexpr int R = decltype(rc)::value;
                 // (behind the last step the last step is loaded again and never handed over: every path through the loop
                 // issues the same number of loads, which lets the compiler wait with vmcnt(two stages) instead of vmcnt(0))
+                if (BG_DBG(4)) return;
                 const long long b = (long long)bz * (g.inner > 0 ? g.inner : 1) + ld_bi;
                 const int k0 = kb + ld_ks * BK;
-                const unsigned kofs = (unsigned)(ld_ks * BK);
+                const unsigned kofs = BG_DBG(128) ? 0u : (unsigned)(ld_ks * BK);
                 if (++ld_n < total && ++ld_ks == spb) { ld_ks = 0; ++ld_bi; }
                 klim[R] = ke - k0;
                 const char* Ab = reinterpret_cast<const char*>(A0 + b * g.sA + (AK ? (long long)kb * g.lda : (long long)kb));
-                const unsigned char* Bi = bimg + ((size_t)(g.sB ? b : 0) * nsteps + (k0 >> 4)) * img_step;
+                const unsigned char* Bi = bimg + ((size_t)(g.sB ? b : 0) * nsteps + (BG_DBG(64) ? 0 : (k0 >> 4))) * img_step;
                 const char* pb = PRO ? reinterpret_cast<const char*>(pro + b * s_pro + (PRO == 2 ? 0 : kb)) : nullptr;
                 const char* pr = PRO == 4 ? reinterpret_cast<const char*>(g.a_rsub + b * g.s_arsub) : nullptr;
                 // a piece whose k lies behind ke reads the step-0 place of the same piece (valid memory), masked at the hand-over
@@ -578,10 +616,10 @@ __global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned c
                     if (PRO >= 2) { v.x *= pv[R][u].x; v.y *= pv[R][u].y; v.z *= pv[R][u].z; v.w *= pv[R][u].w; }
                     va[u] = (a_ok[u] && a_k[u] < klim[R]) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                split_store_a(stage, va);
+                if (!BG_DBG(2)) split_store_a(stage, va);
 #pragma unroll
                 for (int u = 0; u < NCB; ++u)
-                    if (b_has[u]) *reinterpret_cast<i32x4*>(stage + b_lo[u]) = rb[R][u];
+                    if (!BG_DBG(8)) *reinterpret_cast<i32x4*>(ring + R * STG + b_lo[u]) = rb[R][u];
             };
             if (total > 0) {
                 // (scheduling barriers: the loads must be ISSUED in step order -- the waits count loads issued later)
@@ -602,17 +640,34 @@ __global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned c
             // during step t: fill ring stage (t + 2) % 3 with step t + 2, then load step t + 5 into the freed registers.  The loop
             // runs over total3 steps (total rounded up to a multiple of 3; the extra steps only meet the barrier) and has no
             // early exit: every path to a hand-over has issued the same loads in the same order
+#ifdef BG_STAMPS
+            const unsigned long long pst1 = BG_CLK();
+#endif
+#ifdef BG_STAMPS
+            unsigned long long tss = 0, tgl = 0, c0_, c1_;
+#define BG_T(acc_, stmt)  do { c0_ = BG_CLK(); stmt; c1_ = BG_CLK(); acc_ += c1_ - c0_; } while (0)
+#else
+#define BG_T(acc_, stmt)  do { stmt; } while (0)
+#endif
             for (int t = 0; t < total3; t += 3) {
-                if (t + 2 < total) sstore(bg_ic<2>());
-                gload(bg_ic<2>());
-                BG_LDS_BARRIER();
-                if (t + 3 < total) sstore(bg_ic<0>());
-                gload(bg_ic<0>());
-                BG_LDS_BARRIER();
-                if (t + 4 < total) sstore(bg_ic<1>());
-                gload(bg_ic<1>());
-                BG_LDS_BARRIER();
+                BG_T(tss, if (t + 2 < total) sstore(bg_ic<2>()));
+                BG_T(tgl, gload(bg_ic<2>()));
+                BG_BARRIER_TIMED(bwait);
+                BG_T(tss, if (t + 3 < total) sstore(bg_ic<0>()));
+                BG_T(tgl, gload(bg_ic<0>()));
+                BG_BARRIER_TIMED(bwait);
+                BG_T(tss, if (t + 4 < total) sstore(bg_ic<1>()));
+                BG_T(tgl, gload(bg_ic<1>()));
+                BG_BARRIER_TIMED(bwait);
             }
+#ifdef BG_STAMPS
+            if ((g.debug & 32) && pt == 0 && blockIdx.x == 7 && bzz == 1) {
+                const unsigned long long pst2 = BG_CLK();
+                printf("stager  by=%d total=%d: start %llu prime %llu  loop %llu  per step: all %llu  hand-over %llu  loads %llu  barrier %llu\n", by, total,
+                       st0 % 100000000ull, pst1 - st0, pst2 - pst1, (pst2 - pst1) / (unsigned long long)total3, tss / (unsigned long long)total3,
+                       tgl / (unsigned long long)total3, bwait / (unsigned long long)total3);
+            }
+#endif
             return;
         }
         // General route (misaligned or ragged A): element-wise loads, one step at a time, same ring protocol
@@ -698,6 +753,9 @@ __global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned c
     // not exist: t_lo <= t < t_hi, from the step's k0
     const int t_end = min(NT, (g.N - n0 + 31) >> 5);
     BG_LDS_BARRIER();
+#ifdef BG_STAMPS
+    const unsigned long long st1 = BG_CLK();
+#endif
     i32x4 af[3], bf[2][3], afn[3], bfn[3];
     if (total > 0) { aload(ring, af); bload(ring, 0, bf[0]); }
     int slot = 0, ks = 0;
@@ -713,7 +771,7 @@ __global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned c
         for (int t = 0; t < NT; ++t) {
             if (t + 1 < NT) bload(stage, t + 1, bf[(t + 1) & 1]);
             else if (step + 1 < total) { aload(next, afn); bload(next, 0, bfn); }
-            if (t >= t_lo && t < t_hi) {
+            if (t >= t_lo && t < t_hi && !BG_DBG(1)) {
                 const i32x4* b = bf[t & 1];
                 // smallest partial products first
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[2]), "v"(b[0]));
@@ -724,11 +782,14 @@ __global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned c
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(af[0]), "v"(b[0]));
             }
         }
-        BG_LDS_BARRIER();
+        BG_BARRIER_TIMED(bwait);
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) { af[pl] = afn[pl]; bf[0][pl] = bfn[pl]; }
     }
     for (int step = total; step < total3; ++step) BG_LDS_BARRIER();
+#ifdef BG_STAMPS
+    const unsigned long long st2 = BG_CLK();
+#endif
     // the last MFMA must have retired before its accumulators are read (inline asm: no automatic hazard nops)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     if (g.rowsq != nullptr) {
@@ -755,12 +816,12 @@ __global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned c
             const int i0 = (r & 3) + 8 * (r >> 2);
             mine = lane == i0 ? s0 : (lane == i0 + 4 ? s1 : mine);
         }
-        float* rq = g.rowsq + (long long)blockIdx.x * g.rs_tile + (long long)blockIdx.z * g.rs_batch + rowbase;
+        float* rq = g.rowsq + (long long)bx * g.rs_tile + (long long)bzz * g.rs_batch + rowbase;
         const int i = m0 + wave * 32 + lane;
         if (lane < 32 && i < Mb) rq[i] = mine;
     }
     if (g.no_store) return;
-    float* Cb = g.C + (long long)blockIdx.z * g.sC + rowbase * g.ldc;
+    float* Cb = g.C + (long long)bzz * g.sC + rowbase * g.ldc;
     const float* bias = g.c_bias ? g.c_bias + (long long)bz * g.s_cb : nullptr;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -777,6 +838,30 @@ __global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned c
                 *p = v;
             }
         }
+    }
+#ifdef BG_STAMPS
+    if ((g.debug & 32) && tid == 0 && blockIdx.x == 7 && bzz == 1) {
+        const unsigned long long st3 = BG_CLK();
+        printf("multipl by=%d total=%d: start %llu  +prime %llu  +loop %llu (barrier %llu)  +epilogue %llu\n", by, total, st0 % 100000000ull, st1 - st0,
+               st2 - st1, bwait, st3 - st2);
+    }
+#endif
+}
+
+// Persistent launch: one workgroup per CU walks over the tiles (row tile fastest, then column tile, then batch / k-split slab).
+// The stagers leave a tile before the multipliers (which still write their results) and start loading the next one: the
+// dispatch gap between two workgroups of a 150 KB-LDS kernel and the first loads of a tile are no longer exposed
+// (measured per tile of the whitening launch before: 49 k cycles in the step loop, 36 k around it).
+template <int NT, int AK, int PRO>
+__global__ __launch_bounds__(512, 1) void bgemm_ws_kernel(BG g, const unsigned char* __restrict__ bimg, int ncolp, int nsteps,
+                                                          int ntx, int nty, int ntz) {
+    __shared__ __align__(16) unsigned char ring[bg_ws_ring_bytes<NT, AK>()];
+    const int G = gridDim.x;
+    const int ntiles = ntx * nty * ntz;
+    for (int tile = blockIdx.x; tile < ntiles; tile += G) {
+        const int by = tile % nty, rest = tile / nty;
+        const int bx = rest % ntx, bzz = rest / ntx;
+        bgemm_ws_tile<NT, AK, PRO>(g, bimg, ncolp, nsteps, ring, bx, by, bzz);
     }
 }
 
@@ -855,14 +940,19 @@ int bgemm_launch(gmmvi_ctx* ctx, const BG& g0, int batches_outer) {
     unsigned char* img = static_cast<unsigned char*>(ctx->bimg);
     hipLaunchKernelGGL(bsplit_image_kernel, dim3(nsteps, (unsigned)nbatch), dim3(256), 0, ctx->stream, g, ncolp, nsteps, img);
     GMMVI_LAUNCH_CHECK(ctx);
+    const int ntiles = (int)(grid.x * grid.y * grid.z);
+    const dim3 pgrid(ntiles < ctx->num_cus ? ntiles : ctx->num_cus);
+#define BG_WS_LAUNCH(NT_) hipLaunchKernelGGL((bgemm_ws_kernel<NT_, AK, PRO>), pgrid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps, \
+                                             (int)grid.x, (int)grid.y, (int)grid.z)
     switch (nt) {
-        case 3: hipLaunchKernelGGL((bgemm_ws_kernel<3, AK, PRO>), grid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps); break;
-        case 4: hipLaunchKernelGGL((bgemm_ws_kernel<4, AK, PRO>), grid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps); break;
-        case 5: hipLaunchKernelGGL((bgemm_ws_kernel<5, AK, PRO>), grid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps); break;
-        case 6: hipLaunchKernelGGL((bgemm_ws_kernel<6, AK, PRO>), grid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps); break;
-        case 8: hipLaunchKernelGGL((bgemm_ws_kernel<8, AK, PRO>), grid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps); break;
-        default: hipLaunchKernelGGL((bgemm_ws_kernel<10, AK, PRO>), grid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps); break;
+        case 3: BG_WS_LAUNCH(3); break;
+        case 4: BG_WS_LAUNCH(4); break;
+        case 5: BG_WS_LAUNCH(5); break;
+        case 6: BG_WS_LAUNCH(6); break;
+        case 8: BG_WS_LAUNCH(8); break;
+        default: BG_WS_LAUNCH(10); break;
     }
+#undef BG_WS_LAUNCH
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }

@@ -325,3 +325,55 @@ def test_blocked_update_components_plain(ctx, rng, mode, k, d):
         np.testing.assert_allclose(chols.numpy(), m.chol_cov, rtol=2e-3, atol=2e-4)
         np.testing.assert_allclose(l2.numpy(), w.l2_regularizers, rtol=1e-6)
         np.testing.assert_allclose(nupd.numpy(), w.num_received_updates)
+
+
+_ROUTE_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+from gmmvi_amd.device import get_context
+from gmmvi_amd import hip_ops
+d = np.load(sys.argv[2])
+ctx = get_context()
+packed, _ = hip_ops.pack_components(ctx, ctx.asarray(d["means"]), ctx.asarray(d["chols"]))
+ld, lp, grad = hip_ops.mixture_eval(ctx, packed, ctx.asarray(d["logw"]), ctx.asarray(d["x"]), int(d["x"].shape[1]),
+                                    want_ld=True, want_lp=True, want_grad=True)
+np.savez(sys.argv[3], ld=ld.numpy(), lp=lp.numpy(), grad=grad.numpy())
+"""
+
+
+def test_split_operand_route_is_as_accurate_as_the_f32_route(ctx, rng, tmp_path):
+    """The default route of the blocked contractions (three bf16 planes per f32 operand, six partial products on the bf16 matrix
+    cores, f32 accumulation: csrc/blocked.hip) against the f32 matrix-core route (GMMVI_BLOCKED_F32=1, run in a child process:
+    the switch is read once per process), both measured against the fp64 oracle on the same inputs: the split route's errors
+    must be of the size of the f32 route's (it drops terms below 2^-25 of a product, less than the rounding of one f32
+    multiply-add).  D = 300, means far from the origin (|mu| ~ 30 sigma): x - mu is formed in f32 BEFORE the split."""
+    import subprocess, sys
+    k, d, n = 4, 300, 1024
+    m = random_gmm(rng, k, d)
+    m.means[:] = m.means + 30.0
+    x = m.means[rng.integers(0, k, n)] + rng.normal(size=(n, d)) * 1.5
+    x = x.astype(np.float32).astype(np.float64)
+    inp = tmp_path / "in.npz"
+    np.savez(inp, means=m.means.astype(np.float32), chols=m.chol_cov.astype(np.float32), logw=m.log_weights.astype(np.float32),
+             x=x.astype(np.float32))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, flag in (("split", "0"), ("f32", "1")):
+        out = tmp_path / f"{name}.npz"
+        env = dict(os.environ, GMMVI_BLOCKED_F32=flag)
+        subprocess.run([sys.executable, "-c", _ROUTE_SCRIPT, root, str(inp), str(out)], check=True, env=env, timeout=300)
+        outs[name] = np.load(out)
+    # fp64 reference on the f32-rounded model (what both routes were given)
+    m.means = m.means.astype(np.float32).astype(np.float64)
+    m.chol_cov = m.chol_cov.astype(np.float32).astype(np.float64)
+    m.log_weights = m.log_weights.astype(np.float32).astype(np.float64)
+    lq, g, cld = m.log_density_and_grad(x)
+    err = {name: (np.abs(o["ld"] - cld).max(), np.abs(o["grad"] - g).max() / np.abs(g).max()) for name, o in outs.items()}
+    # same tolerance as test_blocked_mixture_eval for both, and the split route within 2x of the f32 route (+ a floor)
+    atol = 2e-6 * np.abs(cld).max() + 2e-4
+    for name in err:
+        assert err[name][0] <= atol, (name, err)
+        assert err[name][1] <= 1e-3, (name, err)
+    assert err["split"][0] <= 2.0 * err["f32"][0] + 1e-4, err
+    assert err["split"][1] <= 2.0 * err["f32"][1] + 1e-6, err
+    print("max |ld - fp64| / relative gradient error:", err)
