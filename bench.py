@@ -26,6 +26,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 PEAK_FP32_TFLOPS = 157.3      # MI355X fp32 vector == f32-input MFMA rate (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_FP64_MFMA_TFLOPS = 78.6  # MI355X fp64 matrix rate (half the f32 MFMA rate)
+# Blocked path (D > 50), default route: every f32 contraction runs as SIX bf16 x bf16 partial products of 3-way split operands
+# on the bf16 matrix cores (2516.6 TFLOP/s dense = 256 CUs x 4 x 1024 FLOP/clk x 2.4 GHz) with f32 accumulation; results carry
+# f32-contraction accuracy (tests/test_hip_blocked.py::test_split_operand_route_is_as_accurate_as_the_f32_route).  Its kernels
+# are priced against the route's own ceiling in f32-equivalent FLOPs; GMMVI_BLOCKED_F32=1 selects the f32 MFMA route (157.3).
+PEAK_SPLIT_BF16_TFLOPS = 2516.6 / 6.0
+
+
+def kernel_peak(name):
+    if name == "more_gram":
+        return PEAK_FP64_MFMA_TFLOPS
+    if name.startswith("blocked_") and os.environ.get("GMMVI_BLOCKED_F32", "0") in ("", "0"):
+        return PEAK_SPLIT_BF16_TFLOPS
+    return PEAK_FP32_TFLOPS
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -391,13 +404,13 @@ def main():
     achieved = fl / (kernels[roof_name]["avg_us"] * 1e-6) / 1e12
     kernel_roofline = {}
     for nme in priced:
-        pk = PEAK_FP64_MFMA_TFLOPS if nme == "more_gram" else PEAK_FP32_TFLOPS
+        pk = kernel_peak(nme)
         t = kernels[nme]["avg_us"] * 1e-6
         kernel_roofline[nme] = {"avg_us": kernels[nme]["avg_us"], "launches_per_step": kernels[nme]["launches_per_step"],
                                 "share_of_step": kernels[nme]["share_of_step"],
                                 "flops_alg_per_launch": launch_flops(nme), "frac": launch_flops(nme) / t / 1e12 / pk,
                                 "frac_executed": launch_flops(nme, kernel_flops_executed) / t / 1e12 / pk}
-    roof_peak = PEAK_FP64_MFMA_TFLOPS if roof_name == "more_gram" else PEAK_FP32_TFLOPS
+    roof_peak = kernel_peak(roof_name)
     d, n_tot, k_tot = w["d"], w["n_total"], w["k_total"]
     f_alg_iter = float(n_tot) * k_tot * (8 * d * d + 12 * d)                   # SURVEY.md 8d (probes reported apart)
     b_alg_iter = 4.0 * (3 * n_tot * d + 3 * n_tot + 2 * k_tot * (d * d + d + 1))
@@ -434,7 +447,8 @@ def main():
                                      "per-pair FLOP figure)") + "; kernel_roofline prices every FLOP-carrying kernel the same way",
                      "share_of_step": kernels[roof_name]["share_of_step"],
                      "note": "achieved = algorithmic FLOPs of the launch (pairs x per-pair figure of bench.kernel_flops, SURVEY.md "
-                             "8(d)) / its mean HIP-event duration; peak = fp32 vector == f32 MFMA rate. The Stein kernel "
+                             "8(d)) / its mean HIP-event duration; peak = fp32 vector == f32 MFMA rate (blocked_* kernels on the split-operand "
+                             "route: bf16 dense MFMA peak / 6 partial products, in f32-equivalent FLOPs). The Stein kernel "
                              "(moment form) executes fewer FLOPs than its algorithmic figure (kernel_roofline.stein_partial."
                              "frac_executed). Algorithmic HBM "
                              "bytes per iteration are tiny (see iter_roofline): the north star's >=50% HBM roofline is "
@@ -446,6 +460,11 @@ def main():
         "kernels": kernels, "dominant_kernel": dominant,
     }
 
+    if any(nme.startswith("blocked_") for nme in kernels):
+        result["arithmetic"] = ("f32 values throughout; blocked contractions (D > 50) " +
+                                ("on v_mfma_f32_32x32x2_f32 (GMMVI_BLOCKED_F32=1)" if kernel_peak("blocked_forward") == PEAK_FP32_TFLOPS else
+                                 "as 6 bf16 x bf16 partial products of 3-way split f32 operands with f32 accumulation (error of an f32 "
+                                 "contraction: tests/test_hip_blocked.py); GMMVI_BLOCKED_F32=1 selects the f32 MFMA route"))
     # ---- CPU baseline + matched-ELBO check (rank 0, 1 GPU only) -------------------------------------------------
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and w["d"] > 64:
         result["cpu_baseline"] = None

@@ -769,7 +769,8 @@ __device__ __forceinline__ void bgemm_ws_tile(const BG& g, const unsigned char* 
         const unsigned char* next = ring + slot * STG;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if (t + 1 < NT) bload(stage, t + 1, bf[(t + 1) & 1]);
+            // (fragments of a sub-tile that does not take part are not read: LDS bandwidth is what paces this role)
+            if (t + 1 < NT) { if (t + 1 >= t_lo && t + 1 < t_hi) bload(stage, t + 1, bf[(t + 1) & 1]); }
             else if (step + 1 < total) { aload(next, afn); bload(next, 0, bfn); }
             if (t >= t_lo && t < t_hi && !BG_DBG(1)) {
                 const i32x4* b = bf[t & 1];
@@ -941,7 +942,9 @@ int bgemm_launch(gmmvi_ctx* ctx, const BG& g0, int batches_outer) {
     hipLaunchKernelGGL(bsplit_image_kernel, dim3(nsteps, (unsigned)nbatch), dim3(256), 0, ctx->stream, g, ncolp, nsteps, img);
     GMMVI_LAUNCH_CHECK(ctx);
     const int ntiles = (int)(grid.x * grid.y * grid.z);
-    const dim3 pgrid(ntiles < ctx->num_cus ? ntiles : ctx->num_cus);
+    static const int env_grid = getenv("GMMVI_BG_GRID") ? atoi(getenv("GMMVI_BG_GRID")) : 0;      // experiments: fewer workgroups than CUs
+    const int cap = env_grid > 0 ? env_grid : ctx->num_cus;
+    const dim3 pgrid(ntiles < cap ? ntiles : cap);
 #define BG_WS_LAUNCH(NT_) hipLaunchKernelGGL((bgemm_ws_kernel<NT_, AK, PRO>), pgrid, dim3(512), 0, ctx->stream, g, img, ncolp, nsteps, \
                                              (int)grid.x, (int)grid.y, (int)grid.z)
     switch (nt) {
