@@ -880,6 +880,12 @@ bool bgemm_split_enabled() {
     return !off;
 }
 
+// Route of one launch.  The split route pays a pre-pass over B and runs one 512-thread workgroup per CU: measured at K = 64,
+// N = 19 968 (tools/time_blocked.py, whitening / whitening + gradient / Stein, us): D = 64: 269 / 609 / 348 against the f32
+// route's 188 / 446 / 442; D = 128: 415 / 1132 / 842 against 387 / 987 / 1266; D = 192: 644 / 1649 / 1057 against 950 / 2114 /
+// 1731 -- it wins from 160 result columns on, and for long contractions (the Stein sums over the samples) at every width.
+bool bgemm_use_split(int n, int kd) { return bgemm_split_enabled() && (n >= 160 || kd >= 512); }
+
 // tile widths of the two routes: f32 route 32 x {3, 4, 5}, split route 32 x {3, 4, 5, 6, 8, 10}: the least padded total width,
 // ties go to the wider tile.  -> NT, *tiles = number of column tiles
 int bgemm_tile_width(int n, bool split, int* tiles) {
@@ -896,9 +902,9 @@ int bgemm_tile_width(int n, bool split, int* tiles) {
 }
 
 // number of column tiles bgemm_launch will use for a result of n columns
-int bgemm_col_tiles(int n) {
+int bgemm_col_tiles(int n, int kd) {
     int tiles = 1;
-    (void)bgemm_tile_width(n, bgemm_split_enabled(), &tiles);
+    (void)bgemm_tile_width(n, bgemm_use_split(n, kd), &tiles);
     return tiles;
 }
 
@@ -916,7 +922,7 @@ int bimg_reserve(gmmvi_ctx* ctx, size_t bytes) {
 
 template <int AK, int BKM, int PRO>
 int bgemm_launch(gmmvi_ctx* ctx, const BG& g0, int batches_outer) {
-    const bool split = bgemm_split_enabled();
+    const bool split = bgemm_use_split(g0.N, g0.Kd);
     int tiles = 1;
     const int nt = bgemm_tile_width(g0.N, split, &tiles);
     dim3 grid(tiles, (g0.M + BM - 1) / BM, batches_outer * (g0.ksplit > 1 ? g0.ksplit : 1));
@@ -1381,7 +1387,7 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         if (S < 1) S = 1;
     }
     const size_t f_gp = S > 1 ? (size_t)S * gslab : 0;
-    const int ctiles = bgemm_col_tiles(D);
+    const int ctiles = bgemm_col_tiles(D, D);              // the whitening launch: D columns, contraction over D
     const size_t f_qp = (size_t)ctiles * Kc * N;              // |z|^2 partials of the whitening launch, one per column tile
     // Z is needed after the whitening launch only by the gradient pass and by the Stein hand-over (which requires the gradient)
     const bool store_z = grad != nullptr;
