@@ -16,6 +16,8 @@ NAMES = [  # (substring of the kernel instance name, bench.py kernel name); firs
     ("update_kl_fast_kernel", "update_kl"), ("combine_partials_kernel", "mixture_combine"),
     ("sample_components_kernel", "sample_components"), ("elr_kernel", "expected_log_ratios"),
     ("update_weights_kernel", "update_weights"),
+    ("bgemm_ws_kernel<10, 1, 4>", "blocked_stein_accumulate"), ("bgemm_ws_kernel<10, 0, 1>", "blocked_forward"),
+    ("bgemm_ws_kernel<10, 0, 2>", "blocked_grad"),
     ("bgemm_kernel<5, 1, 1, 4>", "blocked_stein_accumulate"), ("bgemm_kernel<5, 0, 0, 1>", "blocked_forward"),
     ("bgemm_kernel<5, 0, 1, 2>", "blocked_grad"), ("blk_tridiag", "blocked_tridiag"),
 ]
