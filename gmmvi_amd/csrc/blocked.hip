@@ -1572,6 +1572,17 @@ int gmmvi_blocked_stein(gmmvi_ctx* ctx, int K, int D, const float* packed, const
     if (S > N / 256) S = N / 256;
     if (S > 16) S = 16;
     if (S < 1) S = 1;
+    if (bgemm_use_split(LP, N)) {
+        // split route: one persistent workgroup per CU walks over the tiles -- the S that needs the fewest k steps per CU
+        // (whole rounds of tiles x steps of a tile; C5 shard: 3 row tiles x 64 components x S = 4 -> exactly 3 tiles per CU)
+        const int tc = ((LP + 127) / 128) * bgemm_col_tiles(LP, N) * Kc;
+        long long best = -1;
+        for (int c = 1; c <= 16 && c <= (N / 256 > 1 ? N / 256 : 1); ++c) {
+            const long long rounds = ((long long)tc * c + ctx->num_cus - 1) / ctx->num_cus;
+            const long long steps = ((N + c - 1) / c + BK - 1) / BK + 12;            // + the fixed cost of a tile, in steps
+            if (best < 0 || rounds * steps < best) { best = rounds * steps; S = c; }
+        }
+    }
     const size_t f_x = rows, f_g = rows, f_e = (size_t)Kc * N, f_m = ((size_t)Kc + 3) / 4 * 4, f_mu = (size_t)Kc * LP;
     const size_t f_c = (size_t)Kc * LP * LP, f_w = (size_t)Kc * D * D, f_t = (size_t)Kc * D * D;
     const size_t f_p = S > 1 ? (size_t)Kc * S * LP * LP : 0;
