@@ -1385,6 +1385,20 @@ int gmmvi_blocked_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         if (S > Kc / 4) S = Kc / 4;
         if (S > 16) S = 16;
         if (S < 1) S = 1;
+        if (bgemm_use_split(D, D)) {
+            // split route: one persistent workgroup per CU walks over the tiles -- the S with the fewest k steps per CU (whole
+            // rounds of tiles x components of a range; C5 shard: 156 row tiles x S = 8 ranges of 8 components = 5 rounds, 40
+            // components per CU against 39 ideal; the rule above gave 7 ranges of 10: 50)
+            const int tc = ((N + 127) / 128) * bgemm_col_tiles(D, D);
+            const int spb = (D + BK - 1) / BK;
+            long long best = -1;
+            for (int c = 1; c <= 16 && c <= (Kc / 4 > 1 ? Kc / 4 : 1); ++c) {
+                const int inner = (Kc + c - 1) / c;
+                const long long rounds = ((long long)tc * ((Kc + inner - 1) / inner) + ctx->num_cus - 1) / ctx->num_cus;
+                const long long cost = rounds * ((long long)inner * spb + 12);          // + the fixed cost of a tile, in steps
+                if (best < 0 || cost < best) { best = cost; S = c; }
+            }
+        }
     }
     const size_t f_gp = S > 1 ? (size_t)S * gslab : 0;
     const int ctiles = bgemm_col_tiles(D, D);              // the whitening launch: D columns, contraction over D
