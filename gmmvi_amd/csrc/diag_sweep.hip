@@ -145,7 +145,6 @@ __global__ __launch_bounds__(512) void diag_grad_kernel(int K, int D, const floa
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = blockDim.x >> 6;
     const int n0 = blockIdx.x * 64, n = n0 + lane;
-    const bool valid = n < N;
     const int nr = min(n, N - 1);
     const int d0 = blockIdx.y * DS_CH;
     const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
