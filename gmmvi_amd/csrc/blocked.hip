@@ -569,20 +569,38 @@ __device__ __forceinline__ void bgemm_ws_tile(const BG& g, const unsigned char* 
             i32x4 rb[3][NCB];
             int klim[3] = {0, 0, 0};                 // ke - k0 of the step a register stage holds
             int ld_bi = 0, ld_ks = 0, ld_n = 0;      // (inner batch, k step, index) of the next step to load: steps are loaded in order
+            const char* run_A = nullptr; const unsigned char* run_B = nullptr; const unsigned char* run_B0 = nullptr;
+            const char* run_pb = nullptr; const char* run_pr = nullptr;
+            auto set_batch = [&](long long b) {
+                run_A = reinterpret_cast<const char*>(A0 + b * g.sA + (AK ? (long long)kb * g.lda : (long long)kb));
+                run_B0 = bimg + ((size_t)(g.sB ? b : 0) * nsteps + (kb >> 4)) * img_step;
+                run_B = run_B0;
+                run_pb = PRO ? reinterpret_cast<const char*>(pro + b * s_pro + (PRO == 2 ? 0 : kb)) : nullptr;
+                run_pr = PRO == 4 ? reinterpret_cast<const char*>(g.a_rsub + b * g.s_arsub) : nullptr;
+            };
+            set_batch((long long)bz * (g.inner > 0 ? g.inner : 1));
             auto gload = [&](auto rc) {
                 constexpr int R = decltype(rc)::value;
                 // (behind the last step the last step is loaded again and never handed over: every path through the loop
                 // issues the same number of loads, which lets the compiler wait with vmcnt(two stages) instead of vmcnt(0))
                 if (BG_DBG(4)) return;
-                const long long b = (long long)bz * (g.inner > 0 ? g.inner : 1) + ld_bi;
+                // running pointers: the places of this step's operands are those of the previous step + one k step; only a new
+                // inner batch computes them from scratch (scalar work only, the same loads follow on both paths)
                 const int k0 = kb + ld_ks * BK;
                 const unsigned kofs = BG_DBG(128) ? 0u : (unsigned)(ld_ks * BK);
-                if (++ld_n < total && ++ld_ks == spb) { ld_ks = 0; ++ld_bi; }
                 klim[R] = ke - k0;
-                const char* Ab = reinterpret_cast<const char*>(A0 + b * g.sA + (AK ? (long long)kb * g.lda : (long long)kb));
-                const unsigned char* Bi = bimg + ((size_t)(g.sB ? b : 0) * nsteps + (BG_DBG(64) ? 0 : (k0 >> 4))) * img_step;
-                const char* pb = PRO ? reinterpret_cast<const char*>(pro + b * s_pro + (PRO == 2 ? 0 : kb)) : nullptr;
-                const char* pr = PRO == 4 ? reinterpret_cast<const char*>(g.a_rsub + b * g.s_arsub) : nullptr;
+                const char* Ab = run_A;
+                const unsigned char* Bi = BG_DBG(64) ? run_B0 : run_B;
+                const char* pb = run_pb;
+                const char* pr = run_pr;
+                if (++ld_n < total) {
+                    run_B += img_step;
+                    if (++ld_ks == spb) {
+                        ld_ks = 0;
+                        ++ld_bi;
+                        set_batch((long long)bz * (g.inner > 0 ? g.inner : 1) + ld_bi);
+                    }
+                }
                 // a piece whose k lies behind ke reads the step-0 place of the same piece (valid memory), masked at the hand-over
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
