@@ -1,6 +1,7 @@
-// Blocked path for 64 < D <= 512 (blocked.h): densities, sampling, Stein estimate and the KL-constrained update with the
-// O(D^2)-per-pair work expressed as batched fp32 contractions on the matrix cores and the O(D^3)-per-component
-// factorisations as one-workgroup-per-component kernels on L2-resident matrices.
+// Blocked path for 50 < D <= 512 (blocked.h): densities, sampling, Stein estimate and the KL-constrained update with the
+// O(D^2)-per-pair work expressed as batched f32 contractions on the matrix cores (bgemm: on the f32 instruction, or -- wide and
+// long launches, the default -- on the bf16 instruction through 3-way split operands at f32 accuracy) and the
+// O(D^3)-per-component factorisations as one-workgroup-per-component kernels on L2-resident matrices.
 //
 // Reference arithmetic: models/full_cov_gmm.py:56-62 (z = L^-1 (x - mu) -- here Z = (X - mu) L^-T with the explicit
 // inverse the reference also keeps for its sample database, optimization/sample_db.py:121), models/gmm.py:183-216,274-300,
