@@ -14,7 +14,10 @@ from helpers import samtron_config
 
 pytestmark = pytest.mark.gpu
 
-DIMS = [(3, 72, 300), (2, 130, 257), (4, 300, 200), (1, 65, 10), (2, 512, 140)]
+# (3, 201, 150) and (2, 161, 600): wide enough for the split-operand route of the contractions (>= 160 columns) with rows that are
+# NOT multiples of 16 bytes -- its element-wise staging route; (4, 300, 200) / (2, 512, 140): its aligned route; the others run
+# the f32 matrix-core route for the triangular launches (csrc/blocked.hip: bgemm_use_split)
+DIMS = [(3, 72, 300), (2, 130, 257), (4, 300, 200), (1, 65, 10), (2, 512, 140), (3, 201, 150), (2, 161, 600)]
 
 
 @pytest.fixture(scope="module")
@@ -103,7 +106,7 @@ def test_blocked_student_t_target(ctx, rng):
     np.testing.assert_allclose(grad.numpy(), rg, rtol=2e-3, atol=2e-3 * np.abs(rg).max())
 
 
-@pytest.mark.parametrize("k,d,n", DIMS[:4])
+@pytest.mark.parametrize("k,d,n", DIMS[:4] + DIMS[5:6])
 def test_blocked_sample_components(ctx, rng, k, d, n):
     m = random_gmm(rng, k, d)
     n_k = rng.multinomial(n, np.ones(k) / k)
@@ -118,7 +121,7 @@ def test_blocked_sample_components(ctx, rng, k, d, n):
     np.testing.assert_allclose(x2.numpy(), rx, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("k,d,n", [(3, 72, 600), (2, 300, 900), (4, 130, 257)])
+@pytest.mark.parametrize("k,d,n", [(3, 72, 600), (2, 300, 900), (4, 130, 257), (2, 201, 700)])
 @pytest.mark.parametrize("snis", [True, False])
 def test_blocked_stein(ctx, rng, k, d, n, snis):
     m, x, mapping, tlp, tg, bg = _stein_inputs(rng, k, d, n)
@@ -174,7 +177,7 @@ def test_blocked_stein_after_workspace_grow(rng):
         assert np.all(np.abs(g.numpy() - rg) <= 1e-2 * scale_g + 1e-6)
 
 
-@pytest.mark.parametrize("k,d", [(3, 72), (2, 300), (3, 129)])
+@pytest.mark.parametrize("k,d", [(3, 72), (2, 300), (3, 129), (2, 201)])
 def test_blocked_update_components_kl(ctx, rng, k, d):
     m, hs, gs = _update_inputs(rng, k, d)
     m32 = ogmm.FullCovGMM(m.weights, m.means.astype(np.float32), m.covs.astype(np.float32))
