@@ -1065,12 +1065,19 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // its 32 partial sums in registers: every solved x is read back from memory once per block (not once per row), the
 // multiplies run on broadcast 16-byte LDS reads.  TCM: T is given column-major (T[i][c] at Tm[c * D + i]).
 constexpr int TRB = 32;
-inline size_t blk_trsm_lds_floats(int D) { return (size_t)TRB * (((D + 3) / 4) * 4 + 4); }
+// row stride of the staged rows: a multiple of 4 (16-byte reads) whose quarter is odd (the matrix-core operand reads walk the
+// rows: stride 4 * odd spreads 32 rows over 16 banks)
+__host__ __device__ inline int blk_trsm_ld(int D) {
+    const int ld = ((D + 3) / 4) * 4 + 4;
+    return (ld / 4) % 2 == 0 ? ld + 4 : ld;
+}
+inline size_t blk_trsm_lds_floats(int D) { return (size_t)TRB * blk_trsm_ld(D); }
 
 template <bool TCM, class RhsF>
 __device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs, int i0, float* X, int ldx, float* Ts) {
     const int t = threadIdx.x;
-    const int ld = ((D + 3) / 4) * 4 + 4;
+    const int lane = t & 63, wave = t >> 6, nwave = blockDim.x >> 6, col = lane & 31, half = lane >> 5;
+    const int ld = blk_trsm_ld(D);
     for (int I = 0; I < D; I += TRB) {
         const int nbk = min(TRB, D - I), w = I + nbk;
         __syncthreads();
@@ -1086,6 +1093,39 @@ __device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs
             }
         }
         __syncthreads();
+        // what the solved rows contribute to this block, S[r][t] = sum_{c < I} T[I + r][c] x_c(t), as matrix-core tiles (wave w
+        // takes the 32-rhs tiles w, w + waves, ..: A operand from the staged rows, B operand = dword loads of X from the L2),
+        // parked in the block's own rows of X until their owners pick them up (this sum as per-thread multiply-adds over
+        // broadcast LDS reads was the bulk of the 0.96 M cycles of the solve at D = 300)
+        if (I > 0) {
+            const int ntile = (nrhs + TRB - 1) / TRB;
+            for (int tile = wave; tile < ntile; tile += nwave) {
+                const int t0 = TRB * tile;
+                const float* pa = Ts + col * ld;                               // rows past nbk: unused results
+                const float* pb = X + min(t0 + col, nrhs - 1);
+                f32x16 sacc;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) sacc[j] = 0.f;
+                for (int c = 0; c < I; c += 16) {                              // I is a multiple of 32
+                    float av[8], bv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        av[u] = pa[c + 2 * u + half];
+                        bv[u] = pb[(size_t)(c + 2 * u + half) * ldx];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], sacc, 0, 0, 0);
+                }
+                if (t0 + col < nrhs) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int r = (j & 3) + 8 * (j >> 2) + 4 * half;
+                        if (r < nbk) X[(size_t)(I + r) * ldx + t0 + col] = sacc[j];
+                    }
+                }
+            }
+            __syncthreads();
+        }
         if (t >= nrhs) continue;
         float acc[TRB];
         if (I + TRB <= i0) {                                   // structurally zero rows
@@ -1095,19 +1135,7 @@ __device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs
             continue;
         }
 #pragma unroll
-        for (int r = 0; r < TRB; ++r) acc[r] = (r < nbk) ? rhs(I + r, t) : 0.f;
-        for (int c = i0 & ~7; c < I; c += 8) {                 // x_c = 0 below i0 (stored as such); I is a multiple of 32
-            float xv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = X[(size_t)(c + u) * ldx + t];
-#pragma unroll
-            for (int r = 0; r < TRB; ++r) {
-                const float4 ta = *reinterpret_cast<const float4*>(Ts + r * ld + c);
-                const float4 tb = *reinterpret_cast<const float4*>(Ts + r * ld + c + 4);
-                float sv = fmaf(-ta.x, xv[0], fmaf(-ta.y, xv[1], fmaf(-ta.z, xv[2], fmaf(-ta.w, xv[3], acc[r]))));
-                acc[r] = fmaf(-tb.x, xv[4], fmaf(-tb.y, xv[5], fmaf(-tb.z, xv[6], fmaf(-tb.w, xv[7], sv))));
-            }
-        }
+        for (int r = 0; r < TRB; ++r) acc[r] = (r < nbk) ? rhs(I + r, t) - (I > 0 ? X[(size_t)(I + r) * ldx + t] : 0.f) : 0.f;
 #pragma unroll
         for (int r = 0; r < TRB; ++r) {
             if (r < nbk) {
@@ -1124,47 +1152,58 @@ __device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs
 
 // Cholesky factorisation A = C C^T of the symmetric matrix a(i, j) (i >= j read), left-looking over blocks of 32 columns,
 // one thread per row; the factor is built column-major (W[c * D + i] = C[i][c]: thread i walks coalesced rows of W).
-// Per column block the finished columns' entries of the block rows are staged in LDS (Wb: J x 32), every thread forms its
-// 32 partial sums in registers, one wave factorises the 32 x 32 diagonal block in LDS (Dg), the other rows solve
-// against it.  LDS: blk_chol_lds_floats(D).  Returns false (block-uniform) on a non-positive or non-finite pivot.
-inline size_t blk_chol_lds_floats(int D) { return (size_t)D * TRB + TRB * (TRB + 1) + 4; }
+// Per column block J the sums over the finished columns, S[i][r] = sum_{c < J} C[i][c] C[J + r][c] for the rows i >= J, are
+// matrix-core tiles (v_mfma_f32_32x32x2_f32: wave w takes the 32-row tiles w, w + waves, ..; both operands are dword loads of
+// W straight from the L2, sixteen k in flight) handed to the row threads through LDS (Sm: D x 33; this accumulation as
+// per-thread multiply-adds over broadcast LDS reads was 0.6 M of the factorisation's 1.4 M cycles at D = 300); then every
+// thread finishes its 32 entries, one wave factorises the 32 x 32 diagonal block in LDS (Dg), the other rows solve against
+// it.  LDS: blk_chol_lds_floats(D).  Returns false (block-uniform) on a non-positive or non-finite pivot.
+inline size_t blk_chol_lds_floats(int D) { return (size_t)D * (TRB + 1) + TRB * (TRB + 1) + 4; }
 
 template <class ElemF>
 __device__ bool blk_cholesky(int D, ElemF a, float* W, float* lds) {
-    float* Wb = lds;                                   // [c][32], c < J
-    float* Dg = lds + (size_t)D * TRB;                 // [32][33]
+    float* Sm = lds;                                   // [i][33], rows J <= i < D
+    float* Dg = lds + (size_t)D * (TRB + 1);           // [32][33]
     int* fail = reinterpret_cast<int*>(Dg + TRB * (TRB + 1));
     const int i = threadIdx.x;
+    const int lane = i & 63, wave = i >> 6, nwave = blockDim.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
     if (i == 0) *fail = 0;
     for (int J = 0; J < D; J += TRB) {
         const int nbk = min(TRB, D - J);
         __syncthreads();
-        for (int e = i; e < J * TRB; e += blockDim.x) {
-            const int c = e / TRB, r = e % TRB;
-            Wb[e] = (r < nbk) ? W[(size_t)c * D + J + r] : 0.f;
+        // S tiles: result row m = r (A operand: C[J + r][c]), result column n = matrix row i (B operand: C[i][c]); the lane
+        // holds column n = col and the rows m = (j & 3) + 8 (j >> 2) + 4 half of its 16 registers
+        const int ntile = (D - J + TRB - 1) / TRB;
+        for (int tile = wave; J > 0 && tile < ntile; tile += nwave) {
+            const int i0 = J + TRB * tile;
+            const float* pa = W + min(J + col, D - 1);             // rows past the matrix read its last row (never used)
+            const float* pb = W + min(i0 + col, D - 1);
+            f32x16 sacc;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sacc[j] = 0.f;
+            for (int c = 0; c < J; c += 16) {                      // J is a multiple of 32
+                float av[8], bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    av[u] = pa[(size_t)(c + 2 * u + half) * D];
+                    bv[u] = pb[(size_t)(c + 2 * u + half) * D];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], sacc, 0, 0, 0);
+            }
+            if (i0 + col < D) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) Sm[(size_t)(i0 + col) * (TRB + 1) + (j & 3) + 8 * (j >> 2) + 4 * half] = sacc[j];
+            }
         }
         __syncthreads();
         float acc[TRB];
         const bool mine = i >= J && i < D;
         if (mine) {
 #pragma unroll
-            for (int r = 0; r < TRB; ++r) acc[r] = (r < nbk && J + r <= i) ? a(i, J + r) : 0.f;
-            for (int c = 0; c < J; c += 8) {                   // J is a multiple of 32; eight loads in flight
-                float wv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) wv[u] = W[(size_t)(c + u) * D + i];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-#pragma unroll
-                    for (int r4 = 0; r4 < TRB / 4; ++r4) {
-                        const float4 bv = *reinterpret_cast<const float4*>(Wb + (c + u) * TRB + 4 * r4);
-                        acc[4 * r4] = fmaf(-wv[u], bv.x, acc[4 * r4]);
-                        acc[4 * r4 + 1] = fmaf(-wv[u], bv.y, acc[4 * r4 + 1]);
-                        acc[4 * r4 + 2] = fmaf(-wv[u], bv.z, acc[4 * r4 + 2]);
-                        acc[4 * r4 + 3] = fmaf(-wv[u], bv.w, acc[4 * r4 + 3]);
-                    }
-                }
-            }
+            for (int r = 0; r < TRB; ++r)
+                acc[r] = (r < nbk && J + r <= i) ? a(i, J + r) - (J > 0 ? Sm[(size_t)i * (TRB + 1) + r] : 0.f) : 0.f;
             if (i < J + nbk) {
 #pragma unroll
                 for (int r = 0; r < TRB; ++r) Dg[(i - J) * (TRB + 1) + r] = acc[r];
