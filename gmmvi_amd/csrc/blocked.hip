@@ -1141,7 +1141,13 @@ __device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs
             if (r < nbk) {
                 float sv = acc[r];
 #pragma unroll
-                for (int q = 0; q < r; ++q) sv = fmaf(-Ts[r * ld + I + q], acc[q], sv);
+                for (int q4 = 0; q4 < r; q4 += 4) {                            // 16-byte broadcast reads of the pivot row
+                    const float4 pr = *reinterpret_cast<const float4*>(Ts + r * ld + I + q4);
+                    sv = fmaf(-pr.x, acc[q4], sv);
+                    if (q4 + 1 < r) sv = fmaf(-pr.y, acc[q4 + 1], sv);
+                    if (q4 + 2 < r) sv = fmaf(-pr.z, acc[q4 + 2], sv);
+                    if (q4 + 3 < r) sv = fmaf(-pr.w, acc[q4 + 3], sv);
+                }
                 acc[r] = sv / Ts[r * ld + I + r];
                 X[(size_t)(I + r) * ldx + t] = acc[r];
             }
@@ -1158,13 +1164,14 @@ __device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs
 // per-thread multiply-adds over broadcast LDS reads was 0.6 M of the factorisation's 1.4 M cycles at D = 300); then every
 // thread finishes its 32 entries, one wave factorises the 32 x 32 diagonal block in LDS (Dg), the other rows solve against
 // it.  LDS: blk_chol_lds_floats(D).  Returns false (block-uniform) on a non-positive or non-finite pivot.
-inline size_t blk_chol_lds_floats(int D) { return (size_t)D * (TRB + 1) + TRB * (TRB + 1) + 4; }
+constexpr int DGS = TRB + 4;                            // row stride of the diagonal block in LDS: 16-byte aligned rows
+inline size_t blk_chol_lds_floats(int D) { return (size_t)(((D * (TRB + 1) + 3) / 4) * 4) + TRB * DGS + 4; }
 
 template <class ElemF>
 __device__ bool blk_cholesky(int D, ElemF a, float* W, float* lds) {
     float* Sm = lds;                                   // [i][33], rows J <= i < D
-    float* Dg = lds + (size_t)D * (TRB + 1);           // [32][33]
-    int* fail = reinterpret_cast<int*>(Dg + TRB * (TRB + 1));
+    float* Dg = lds + (size_t)(((D * (TRB + 1) + 3) / 4) * 4);          // [32][DGS]
+    int* fail = reinterpret_cast<int*>(Dg + TRB * DGS);
     const int i = threadIdx.x;
     const int lane = i & 63, wave = i >> 6, nwave = blockDim.x >> 6;
     const int col = lane & 31, half = lane >> 5;
@@ -1206,26 +1213,46 @@ __device__ bool blk_cholesky(int D, ElemF a, float* W, float* lds) {
                 acc[r] = (r < nbk && J + r <= i) ? a(i, J + r) - (J > 0 ? Sm[(size_t)i * (TRB + 1) + r] : 0.f) : 0.f;
             if (i < J + nbk) {
 #pragma unroll
-                for (int r = 0; r < TRB; ++r) Dg[(i - J) * (TRB + 1) + r] = acc[r];
+                for (int r = 0; r < TRB; ++r) Dg[(i - J) * DGS + r] = acc[r];
             }
         }
         __syncthreads();
-        if (i < 32) {                                  // half of wave 0: 32 x 32 Cholesky in LDS, lane = row
+        if (i < 32) {
+            // half of wave 0: 32 x 32 Cholesky, lane = row.  The lane keeps ITS row in registers; the pivot row r (complete
+            // after step r - 1: every step publishes the new column) comes from LDS as 16-byte broadcast reads; the sums run
+            // over q = 0, 1, .. as before (bit-identical), but with static indices: no dependent LDS read per term (that loop
+            // was 57 k cycles a block: more than half of the factorisation at D = 300)
             const int l = i;
-            for (int r = 0; r < nbk; ++r) {
-                float sv = 0.f;
-                if (l >= r && l < nbk) {
-                    sv = Dg[l * (TRB + 1) + r];
-                    for (int q = 0; q < r; ++q) sv = fmaf(-Dg[l * (TRB + 1) + q], Dg[r * (TRB + 1) + q], sv);
+            float rw[TRB];
+#pragma unroll
+            for (int c = 0; c < TRB; ++c) rw[c] = Dg[l * DGS + c];
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < TRB; ++r) {
+                if (r < nbk && !bad) {
+                    float sv = rw[r];
+#pragma unroll
+                    for (int q4 = 0; q4 < r; q4 += 4) {
+                        const float4 pr = *reinterpret_cast<const float4*>(Dg + r * DGS + q4);
+                        sv = fmaf(-rw[q4], pr.x, sv);
+                        if (q4 + 1 < r) sv = fmaf(-rw[q4 + 1], pr.y, sv);
+                        if (q4 + 2 < r) sv = fmaf(-rw[q4 + 2], pr.z, sv);
+                        if (q4 + 3 < r) sv = fmaf(-rw[q4 + 3], pr.w, sv);
+                    }
+                    const float pv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), r));
+                    if (!(pv > 0.f) || !(pv < FLT_MAX)) {
+                        bad = true;
+                    } else {
+                        const float d = sqrtf(pv);
+                        rw[r] = (l == r) ? d : sv / d;
+                        if (l >= r && l < nbk) Dg[l * DGS + r] = rw[r];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
                 }
-                const float pv = __shfl(sv, r);
-                if (!(pv > 0.f) || !(pv < FLT_MAX)) { if (i == 0) *fail = 1; break; }
-                const float d = sqrtf(pv);
-                if (l >= r && l < nbk) Dg[l * (TRB + 1) + r] = (l == r) ? d : sv / d;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
+            if (bad && i == 0) *fail = 1;
         }
         __syncthreads();
         if (*fail) return false;
@@ -1234,15 +1261,21 @@ __device__ bool blk_cholesky(int D, ElemF a, float* W, float* lds) {
                 const int l = i - J;
 #pragma unroll
                 for (int r = 0; r < TRB; ++r)
-                    if (r <= l) W[(size_t)(J + r) * D + i] = Dg[l * (TRB + 1) + r];
+                    if (r <= l) W[(size_t)(J + r) * D + i] = Dg[l * DGS + r];
             } else {
 #pragma unroll
                 for (int r = 0; r < TRB; ++r) {
                     if (r < nbk) {
                         float sv = acc[r];
 #pragma unroll
-                        for (int q = 0; q < r; ++q) sv = fmaf(-acc[q], Dg[r * (TRB + 1) + q], sv);
-                        acc[r] = sv / Dg[r * (TRB + 1) + r];
+                        for (int q4 = 0; q4 < r; q4 += 4) {                    // 16-byte broadcast reads of the pivot row
+                            const float4 pr = *reinterpret_cast<const float4*>(Dg + r * DGS + q4);
+                            sv = fmaf(-acc[q4], pr.x, sv);
+                            if (q4 + 1 < r) sv = fmaf(-acc[q4 + 1], pr.y, sv);
+                            if (q4 + 2 < r) sv = fmaf(-acc[q4 + 2], pr.z, sv);
+                            if (q4 + 3 < r) sv = fmaf(-acc[q4 + 3], pr.w, sv);
+                        }
+                        acc[r] = sv / Dg[r * DGS + r];
                         W[(size_t)(J + r) * D + i] = acc[r];
                     }
                 }
