@@ -385,3 +385,23 @@ def test_split_operand_route_is_as_accurate_as_the_f32_route(ctx, rng, tmp_path)
     assert err["split"][0] <= 2.0 * err["f32"][0] + 1e-4, err
     assert err["split"][1] <= 2.0 * err["f32"][1] + 1e-6, err
     print("max |ld - fp64| / relative gradient error:", err)
+
+
+def test_split_operand_route_keeps_non_finite_samples_to_themselves(ctx, rng):
+    """A NaN / an infinity in one sample must surface in that sample's results only (the split of x - mu into three bf16 planes
+    turns an infinity into a NaN -- inf - bf16(inf) -- which is what the f32 route's 0 x inf products give as well)."""
+    k, d, n = 2, 300, 256
+    m = random_gmm(rng, k, d)
+    x = m.means[rng.integers(0, k, n)] + rng.normal(size=(n, d))
+    logw, means, chols = upload_model(ctx, m)
+    packed, _ = ops().pack_components(ctx, means, chols)
+    _, lp0, g0 = ops().mixture_eval(ctx, packed, logw, ctx.asarray(x), d, want_lp=True, want_grad=True)
+    xb = x.copy()
+    xb[5, 17] = np.nan
+    xb[130, 299] = np.inf
+    _, lp1, g1 = ops().mixture_eval(ctx, packed, logw, ctx.asarray(xb), d, want_lp=True, want_grad=True)
+    lp0, lp1, g0, g1 = lp0.numpy(), lp1.numpy(), g0.numpy(), g1.numpy()
+    bad = np.zeros(n, bool); bad[[5, 130]] = True
+    assert not np.isfinite(lp1[bad]).any()
+    np.testing.assert_array_equal(lp1[~bad], lp0[~bad])
+    np.testing.assert_array_equal(g1[~bad], g0[~bad])
