@@ -63,6 +63,7 @@ _PROTOS = {
     "gmmvi_fill_f32": (_i, [_p, _p, _f, _sz]),
     "gmmvi_gather_rows": (_i, [_p, _p, _p, _i, _i, _p]),
     "gmmvi_exp_f32": (_i, [_p, _p, _p, _sz]),
+    "gmmvi_logaddexp_f32": (_i, [_p, _p, _p, _f, _p, _f, _sz]),
     "gmmvi_copy_batch": (_i, [_p, _i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_sz)]),
     "gmmvi_unpack_gathered": (_i, [_p, _p, _i, _sz, _i, C.POINTER(_sz), C.POINTER(_p)]),
     "gmmvi_fill_strided_f32": (_i, [_p, _p, _sz, _sz, _f]),

@@ -289,6 +289,28 @@ int gmmvi_exp_f32(gmmvi_ctx* ctx, float* dst_dev, const float* src_dev, size_t c
     return GMMVI_OK;
 }
 
+__global__ void logaddexp_f32_kernel(float* __restrict__ dst, const float* __restrict__ a, float ca,
+                                     const float* __restrict__ b, float cb, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float x = a[i] + ca, y = b[i] + cb;
+        const float m = fmaxf(x, y);
+        dst[i] = m + logf(expf(x - m) + expf(y - m));
+    }
+}
+
+int gmmvi_logaddexp_f32(gmmvi_ctx* ctx, float* dst_dev, const float* a_dev, float ca, const float* b_dev, float cb,
+                        size_t count) {
+    if (count == 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, dst_dev && a_dev && b_dev);
+    int blocks = (int)((count + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(logaddexp_f32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dst_dev, a_dev, ca, b_dev, cb, count);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
 int gmmvi_event_create(gmmvi_ctx* ctx, void** out_event) {
     GMMVI_ARG_CHECK(ctx, out_event != nullptr);
     hipEvent_t ev;

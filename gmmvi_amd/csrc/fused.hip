@@ -60,11 +60,11 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
                              p->l2 && p->num_updates && p->offsets && p->bg_logw && p->db_samples && p->db_tlp &&
                              p->db_tgrad && p->db_mapping && p->reward_next && p->wstate);
     GMMVI_ARG_CHECK(ctx, p->n_old >= 0 && p->max_per_component >= 0);
-    GMMVI_ARG_CHECK(ctx, p->n_old == 0 || (p->bg_packed != nullptr && p->bg_K >= 1));
+    GMMVI_ARG_CHECK(ctx, p->n_old == 0 || (p->bg_packed != nullptr && p->bg_K >= 1 && p->bg_old != nullptr && p->bg_logw_new != nullptr));
     const int n_old = p->n_old;
     const int Na = n_old + N;                          // active samples: the reused ones followed by the new ones
     const size_t KN = (size_t)K * Na, ND = (size_t)Na * D;
-    const size_t floats = KN + 2 * (size_t)Na + ND + (size_t)K * D * D + (size_t)K * D + 3 * (size_t)K + Na + 64;
+    const size_t floats = KN + 4 * (size_t)Na + ND + (size_t)K * D * D + (size_t)K * D + 3 * (size_t)K + Na + 64;
     GMMVI_TRY(arena_reserve(ctx, floats));
     Arena a;
     float* base = (float*)ctx->arena;
@@ -77,6 +77,8 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
     a.E = base; base += K;
     a.success = (int32_t*)base; base += K;
     a.mapping = (int32_t*)base; base += Na;
+    float* bg_a = base; base += Na;                    // reused samples: the two halves of the background density
+    float* bg_b = base; base += Na;
 
     float* x = p->db_samples;          // the new samples are written straight into the database
     float* xa = x - (size_t)n_old * D; // the active samples: the n_old database rows in front of them and the new ones
@@ -115,13 +117,19 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
         ctx->prof_tag = nullptr;
         GMMVI_TRY(rc_dual);
     } else {
-        // reused samples: the background mixture runs over the database's snapshots of the window (bg_K of them), the model
-        // sweep over the current components; both on all active samples
+        // reused samples: the background mixture of the window = the mixture the reused samples came from (bg_K snapshot
+        // components; its density is KNOWN for the reused samples -- bg_old, from the effective-sample-size step -- and is
+        // evaluated for the new samples only) joined with the mixture of the new components over all active samples, each
+        // with its share of the window (SampleDB.get_newest_samples takes the same route: optimization/sample_db.py)
         ctx->prof_tag = "sweep_background";
-        int rc_bg = gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, p->bg_K, D, p->bg_packed, p->bg_logw, xa, Na, nullptr, a.bg,
+        int rc_bg = gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, p->bg_K, D, p->bg_packed, p->bg_logw, x, N, nullptr, bg_a + n_old,
                                        nullptr);
+        if (rc_bg == GMMVI_OK)
+            rc_bg = gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, p->bg_logw_new, xa, Na, nullptr, bg_b, nullptr);
         ctx->prof_tag = nullptr;
         GMMVI_TRY(rc_bg);
+        GMMVI_HIP_CHECK(ctx, hipMemcpyAsync(bg_a, p->bg_old, (size_t)n_old * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        GMMVI_TRY(gmmvi_logaddexp_f32(ctx, a.bg, bg_a, p->bg_log_share_old, bg_b, p->bg_log_share_new, (size_t)Na));
         ctx->defer_combine = true;
         ctx->prof_tag = "sweep_model";
         int rc_m = gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, p->logw, xa, Na, a.ld, a.lq, a.qgrad);

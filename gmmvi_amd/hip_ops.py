@@ -401,6 +401,15 @@ def gather_rows(ctx, src, idx):
     return dst
 
 
+def logaddexp(ctx, a, ca, b, cb):
+    """-> log(exp(a + ca) + exp(b + cb)), element-wise (a, b: [n] float32 DeviceArrays; ca, cb: floats)."""
+    if a.shape != b.shape or a.dtype != F32 or b.dtype != F32:
+        raise ValueError("logaddexp: shape/dtype mismatch")
+    out = ctx.empty(a.shape)
+    ctx.check(ctx.lib.gmmvi_logaddexp_f32(ctx.handle, out.ptr, a.ptr, float(ca), b.ptr, float(cb), a.size))
+    return out
+
+
 def exp_into(ctx, dst, src):
     if dst.shape != src.shape or dst.dtype != F32 or src.dtype != F32:
         raise ValueError("exp_into: shape/dtype mismatch")

@@ -39,6 +39,7 @@ class SamtronPlan(C.Structure):
         ("means", _p), ("chols", _p), ("logw", _p), ("packed", _p), ("packed_new", _p),
         ("stepsizes", _p), ("last_eta", _p), ("l2", _p), ("num_updates", _p), ("success_out", _p),
         ("offsets", _p), ("max_per_component", _i), ("n_old", _i), ("bg_K", _i), ("bg_packed", _p), ("bg_logw", _p),
+        ("bg_old", _p), ("bg_logw_new", _p), ("bg_log_share_old", _f), ("bg_log_share_new", _f),
         ("seed", C.c_uint64), ("first_index", C.c_uint64),
         ("db_samples", _p), ("db_tlp", _p), ("db_tgrad", _p), ("db_mapping", _p), ("mapping_base", _i),
         ("db_means", _p), ("db_chols", _p), ("db_packed", _p),
@@ -116,6 +117,7 @@ class SamtronFastPath:
         bg_old, xs_old, _, _, _ = db.get_newest_samples(n_reuse)
         ld_old = model.component_log_densities(xs_old)
         n_eff = np.floor(sel.get_effective_samples(ld_old, bg_old).numpy()).astype(np.int64)
+        self._bg_old = bg_old            # the window's background density so far: the call extends it instead of redoing it
         return np.maximum(1, s - n_eff), int(xs_old.shape[0])
 
     # ---- one iteration -----------------------------------------------------------------------------------------------------
@@ -158,21 +160,24 @@ class SamtronFastPath:
             bg_logw = ctx.cached_const(("bg_logw", key), lambda: ctx.asarray(np.log(counts / counts.sum()).astype(np.float32)))
             p.n_old, p.bg_K, p.bg_packed = 0, 0, None
         else:
-            active, acounts = db._active_components(s0 - n_old)
+            # the components the reused samples came from, weighted by their counts among the reused samples: exactly the mixture
+            # get_newest_samples(n_old) evaluated for bg_old (same window start, this iteration's entry not counted)
+            active, acounts = db._window_components(s0 - n_old, s0)
+            assert active.max() < c0, "the reused samples come from earlier appends"
             lo, hi = int(active[0]), int(active[-1]) + 1
             if hi - lo == len(active) and (len(active) == 1 or np.all(np.diff(active) == 1)):
                 bg_packed_ptr = db._packed.buf.ptr + lo * stride * 4        # contiguous snapshot range: no gather
                 self._bg_keepalive = None
             else:
-                # snapshots of the reused part gathered; the new components' rows are written by the call itself, so their
-                # blocks are taken from the model (identical contents)
-                old_rows = active[active < c0].astype(np.int32)
-                assert len(active) - len(old_rows) == k, "every current component draws at least one new sample"
-                self._bg_keepalive = hip_ops.concat(ctx, [hip_ops.gather_rows(ctx, db._packed.view(), old_rows), packed_cur])
+                self._bg_keepalive = hip_ops.gather_rows(ctx, db._packed.view(), active.astype(np.int32))
                 bg_packed_ptr = self._bg_keepalive.ptr
             bg_logw = ctx.cached_const(("bg_logw", acounts.tobytes()),
                                        lambda: ctx.asarray(np.log(acounts.astype(np.float64) / acounts.sum()).astype(np.float32)))
+            bg_logw_new = ctx.cached_const(("bg_logw", key), lambda: ctx.asarray(np.log(counts / counts.sum()).astype(np.float32)))
+            self._bg_logw_new_keepalive = bg_logw_new
             p.n_old, p.bg_K, p.bg_packed = n_old, len(active), bg_packed_ptr
+            p.bg_old, p.bg_logw_new = self._bg_old.ptr, bg_logw_new.ptr
+            p.bg_log_share_old, p.bg_log_share_new = db.log_shares(n_old, n)
         p.max_per_component = int(counts.max())
 
         tgt = sel.target_distribution._fast_path_target()
@@ -225,6 +230,8 @@ class SamtronFastPath:
                            (db._means, k), (db._chols, k), (db._packed, k)):
             grow.n += rows
         db._num_samples_written += n
+        if n_old > 0:
+            db._bg_cache = None          # the window's density was extended inside the call (SampleDB.get_newest_samples does the same)
         m.commit_rewards()
         if k > 1:
             m._t_weight += 1

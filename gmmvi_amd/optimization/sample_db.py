@@ -97,6 +97,8 @@ class SampleDB:
         self._num_samples_written = 0
         # append log: (first sample, first component, per-component counts); cleared when the DB is thinned out
         self._segments = []
+        # the last get_newest_samples answer: window [start, stop), its components / counts, its background density
+        self._bg_cache = None
 
     @staticmethod
     def build_from_config(config, num_dimensions):
@@ -201,6 +203,7 @@ class SampleDB:
         self._chols.assign(hip_ops.gather_rows(self.ctx, self.chols, uidx))
         self._packed.assign(hip_ops.gather_rows(self.ctx, self._packed.view(), uidx))
         self._segments = []
+        self._bg_cache = None
 
     def add_samples(self, samples, means, chols, target_lnpdfs, target_grads, mapping, mapping_host=None,
                     packed=None, counts=None):
@@ -239,6 +242,7 @@ class SampleDB:
             hip_ops.copy_batch(ctx, pairs)
         else:                                                                                  # :125-135
             self._segments = [(0, 0, np.asarray(counts, np.int64))] if counts is not None else []
+            self._bg_cache = None
             self._mapping_host.assign(mapping_host)
             self._mapping_dev.assign(mapping.copy())
             self._means.assign(means.copy()); self._chols.assign(chols.copy()); self._packed.assign(packed)
@@ -280,6 +284,61 @@ class SampleDB:
         order = np.argsort(first)
         return uniq[order], counts[order]
 
+    def _window_components(self, start, stop):
+        """unique_with_counts of mapping[start:stop] in first-occurrence order."""
+        acc_active, acc_counts = [], []
+        pos = start
+        for s0, c0, counts in self._segments:
+            if s0 == pos and s0 + int(counts.sum()) <= stop:
+                nz = counts > 0
+                acc_active.append(c0 + np.nonzero(nz)[0])
+                acc_counts.append(counts[nz])
+                pos = s0 + int(counts.sum())
+                if pos == stop:
+                    return np.concatenate(acc_active), np.concatenate(acc_counts)
+        mp = self._mapping_host.view(start)[:stop - start]
+        uniq, first, counts = np.unique(mp, return_index=True, return_counts=True)
+        order = np.argsort(first)
+        return uniq[order], counts[order]
+
+    @staticmethod
+    def log_shares(n_old, n_new):
+        """float32 log(n_old / (n_old + n_new)), log(n_new / (n_old + n_new)): the weights that join the two halves of a window's
+        background density."""
+        tot = float(n_old + n_new)
+        return float(np.float32(np.log(n_old / tot))), float(np.float32(np.log(n_new / tot)))
+
+    def _extend_background(self, start, stop):
+        """Background density of the window [start, stop) from the one of [start, cached stop) returned by the previous call
+        (the effective-sample-size step of the sample selectors asks for the reused samples first, then -- after the append --
+        for the reused and the new ones: sample_selector.py:160-219).  In exact arithmetic identical to evaluating the whole
+        window's mixture on all of its samples (sample_db.py:216-227): that mixture is the share-weighted sum of the mixture the
+        old samples came from (known for the old samples, evaluated for the new ones) and of the new samples' components.
+        -> DeviceArray, or None when the cache does not apply."""
+        c = self._bg_cache
+        if c is None or c["start"] != start or not (c["stop"] < stop) or c["stop"] <= start:
+            return None
+        old_active, old_counts = c["active"], c["counts"]
+        new_active, new_counts = self._window_components(c["stop"], stop)
+        if new_active.min() <= old_active.max():                     # a component with samples in both halves: no clean split
+            return None
+        ctx = self.ctx
+        n_old, n_new = c["stop"] - start, stop - c["stop"]
+
+        def rows(active):
+            lo, hi = int(active[0]), int(active[-1]) + 1
+            if hi - lo == len(active) and (len(active) == 1 or np.all(np.diff(active) == 1)):
+                return self._packed.view(lo, hi)
+            return hip_ops.gather_rows(ctx, self._packed.view(), active.astype(np.int32))
+
+        def logw(counts):
+            return ctx.cached_const(("bg_logw", counts.tobytes()),
+                                    lambda: ctx.asarray(np.log(counts.astype(np.float64) / counts.sum()).astype(np.float32)))
+        part_old = hip_ops.concat(ctx, [c["bg"], self._mixture_lp(rows(old_active), logw(old_counts), self._samples.view(c["stop"]))])
+        part_new = self._mixture_lp(rows(new_active), logw(new_counts), self._samples.view(start))
+        ca, cb = self.log_shares(n_old, n_new)
+        return hip_ops.logaddexp(ctx, part_old, ca, part_new, cb)
+
     def get_newest_samples(self, N, fuse_with_model=None):
         """sample_db.py:194-228 -> (log_pdfs, samples, mapping, target_lnpdfs, target_grads).
         ``fuse_with_model``: a model whose CURRENT components are exactly the snapshot components of the requested
@@ -306,8 +365,16 @@ class SampleDB:
         if (fuse_with_model is not None and self._segments and self._segments[-1][0] == start
                 and len(active) == fuse_with_model.num_components):
             bg = fuse_with_model.eval_with_background(xs, logw)
+            extended = False
         else:
-            bg = self._mixture_lp(packed, logw, xs)                                            # :227
+            bg = self._extend_background(start, self._samples.n)
+            extended = bg is not None
+            if not extended:
+                bg = self._mixture_lp(packed, logw, xs)                                        # :227
+        # an extended answer is not extended again (the single-call iteration, which extends inside its C call, keeps no
+        # array to extend from either: both paths then recompute the next window from scratch and stay bit-equal)
+        self._bg_cache = None if extended else {"start": start, "stop": self._samples.n, "bg": bg, "active": active,
+                                                "counts": counts}
         return (bg, xs, self._mapping_dev.view(start), self._target_lnpdfs.view(start),
                 self._target_grads.view(start))
 

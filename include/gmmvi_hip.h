@@ -97,6 +97,12 @@ int gmmvi_remove_column_f32(gmmvi_ctx* ctx, float* a_dev, int rows, size_t strid
 int gmmvi_add_scalar_i32(gmmvi_ctx* ctx, int32_t* dst_dev, const int32_t* src_dev, int32_t value, size_t count);
 /* dst[i] = exp(src[i])  (GMM.weights, models/gmm.py:171; weight history, models/gmm_wrapper.py:182). */
 int gmmvi_exp_f32(gmmvi_ctx* ctx, float* dst_dev, const float* src_dev, size_t count);
+/* dst[i] = log(exp(a[i] + ca) + exp(b[i] + cb)): joins the two halves of SampleDB's background density when the window grows by
+ * one append -- the mixture of the components that were already in the window (known for the old samples from the previous
+ * get_newest_samples call) and the mixture of the new components (optimization/sample_db.py:216-227 evaluates the whole
+ * window's mixture on all of its samples every time). */
+int gmmvi_logaddexp_f32(gmmvi_ctx* ctx, float* dst_dev, const float* a_dev, float ca, const float* b_dev, float cb,
+                        size_t count);
 /* timing helpers for bench.py: HIP events on the context's stream */
 int gmmvi_event_create(gmmvi_ctx* ctx, void** out_event);
 int gmmvi_event_destroy(gmmvi_ctx* ctx, void* event);
@@ -273,9 +279,14 @@ typedef struct gmmvi_samtron_plan {
     const int32_t* offsets;               /* [K+1] prefix sums of the per-component sample counts */
     int32_t max_per_component;            /* largest per-component count (0: N / K rounded up) */
     int32_t n_old;                        /* reused samples in front of the append position (0: none) */
-    int32_t bg_K;                         /* background components (ignored when bg_packed is NULL: the model's own) */
-    const float* bg_packed;               /* [bg_K, stride] snapshot blocks of the window's sampling components, or NULL */
-    const float* bg_logw;                 /* [bg_K or K] log(count / (n_old + N)): background weights (sample_db.py:225-226) */
+    int32_t bg_K;                         /* n_old > 0: components the reused samples came from (snapshots; the new ones excluded) */
+    const float* bg_packed;               /* [bg_K, stride] their snapshot blocks, or NULL (n_old == 0) */
+    const float* bg_logw;                 /* n_old == 0: [K] log(count / N), the background weights (sample_db.py:225-226);
+                                           * n_old > 0: [bg_K] log(count / n_old) of the components the reused samples came from */
+    const float* bg_old;                  /* n_old > 0: [n_old] background density of the reused samples under those components with
+                                           * those weights (what get_newest_samples(n_old) returned for the effective sample sizes) */
+    const float* bg_logw_new;             /* n_old > 0: [K] log(count / N) of the new samples */
+    float bg_log_share_old, bg_log_share_new;   /* n_old > 0: log(n_old / (n_old + N)), log(N / (n_old + N)) */
     uint64_t seed, first_index;           /* Philox key / global index of the first new sample */
     /* SampleDB append targets, already offset to the first free row (sample_db.py:115-124); snapshots may be NULL */
     float* db_samples; float* db_tlp; float* db_tgrad; int32_t* db_mapping; int32_t mapping_base;

@@ -278,3 +278,38 @@ def test_device_reproduces_golden_trajectory(path):
         np.testing.assert_allclose(m.stepsizes.numpy(), g["stepsizes"][it], rtol=1e-5)
         if it < 5:
             np.testing.assert_array_equal(algo.ng_based_updater.last_info[1].numpy(), g["n_probes"][it])
+
+
+def test_extended_background_equals_the_window_mixture():
+    """SampleDB.get_newest_samples extends the density it returned for the reused samples (effective-sample-size step) when the
+    window grows by one append, instead of evaluating the whole window's mixture again (sample_db.py:216-227): the answer must be
+    that mixture's density -- checked against a from-scratch evaluation of the same window and against the fp64 oracle database."""
+    from oracle.sample_db import SampleDB as OracleDB
+    from gmmvi_amd.optimization.sample_db import SampleDB
+    from gmmvi_amd.device import get_context
+    ctx = get_context()
+    rng = np.random.default_rng(5)
+    d, k = 6, 4
+    db, odb = SampleDB(d, False, True, ctx=ctx), OracleDB(d, False, True)
+    for it in range(4):
+        means = rng.normal(size=(k, d)) * 2
+        a = rng.normal(size=(k, d, d)) * 0.3
+        chols = np.linalg.cholesky(a @ a.transpose(0, 2, 1) + np.eye(d))
+        counts = rng.integers(1, 40, k)
+        mapping = np.repeat(np.arange(k, dtype=np.int32), counts)
+        xs = means[mapping] + np.einsum("nij,nj->ni", chols[mapping], rng.normal(size=(len(mapping), d)))
+        n_before = db.samples.shape[0]
+        if it > 0:
+            db.get_newest_samples(150)                   # what a selector asks first: the reused samples
+            assert db._bg_cache is not None
+        args = (xs.astype(np.float32), means.astype(np.float32), chols.astype(np.float32), np.zeros(len(mapping), np.float32),
+                np.zeros((len(mapping), d), np.float32), mapping)
+        db.add_samples(*args, counts=counts)
+        odb.add_samples(*[np.asarray(v, np.float64) if v.dtype != np.int32 else v for v in args])
+        n_win = min(n_before, 150) + len(mapping)
+        bg = db.get_newest_samples(n_win)[0].numpy()
+        if it > 0:
+            assert db._bg_cache is None                  # this answer was an extension
+        fresh = db.get_newest_samples(n_win)[0].numpy()  # no cache now: the whole window's mixture on all of its samples
+        np.testing.assert_allclose(bg, fresh, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(bg, odb.get_newest_samples(n_win)[0], rtol=1e-4, atol=1e-4)
