@@ -1,5 +1,6 @@
 // Context, error, memory and event entry points of the C ABI (include/gmmvi_hip.h).
 #include "common.h"
+#include <cstring>
 #include "blocked.h"
 
 std::string g_gmmvi_global_err;
@@ -59,6 +60,10 @@ void gmmvi_ctx_destroy(gmmvi_ctx* ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->bimg) (void)hipFree(ctx->bimg);
+    if (ctx->up_ring) {
+        for (int i = 0; i < gmmvi_ctx::UP_SLOTS; ++i) (void)hipEventDestroy(ctx->up_event[i]);
+        (void)hipHostFree(ctx->up_ring);
+    }
     if (ctx->defer_ws) (void)hipFree(ctx->defer_ws);
     delete ctx;
 }
@@ -89,6 +94,25 @@ int gmmvi_free(gmmvi_ctx* ctx, void* dev) {
 int gmmvi_upload(gmmvi_ctx* ctx, void* dst_dev, const void* src_host, size_t nbytes) {
     if (nbytes == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, dst_dev && src_host);
+    if (nbytes <= gmmvi_ctx::UP_SLOT_BYTES) {
+        // small copies (weights, offsets, index lists: several per iteration of the sample-reuse path): through a pinned staging
+        // slot, stream-ordered, WITHOUT waiting for the work already queued -- a synchronous copy drains the stream every time
+        // (46 us each behind a queued iteration).  A slot is reused only after the copy that last read it has completed.
+        if (ctx->up_ring == nullptr) {
+            GMMVI_HIP_CHECK(ctx, hipHostMalloc((void**)&ctx->up_ring, gmmvi_ctx::UP_SLOTS * gmmvi_ctx::UP_SLOT_BYTES, hipHostMallocDefault));
+            for (int i = 0; i < gmmvi_ctx::UP_SLOTS; ++i)
+                GMMVI_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->up_event[i], hipEventDisableTiming));
+        }
+        const int slot = ctx->up_next;
+        ctx->up_next = (slot + 1) % gmmvi_ctx::UP_SLOTS;
+        if (ctx->up_used[slot]) GMMVI_HIP_CHECK(ctx, hipEventSynchronize(ctx->up_event[slot]));
+        unsigned char* stage = ctx->up_ring + (size_t)slot * gmmvi_ctx::UP_SLOT_BYTES;
+        memcpy(stage, src_host, nbytes);
+        GMMVI_HIP_CHECK(ctx, hipMemcpyAsync(dst_dev, stage, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        GMMVI_HIP_CHECK(ctx, hipEventRecord(ctx->up_event[slot], ctx->stream));
+        ctx->up_used[slot] = true;
+        return GMMVI_OK;
+    }
     // pageable host memory: the runtime stages the copy, the call returns when the source may be reused
     GMMVI_HIP_CHECK(ctx, hipMemcpyAsync(dst_dev, src_host, nbytes, hipMemcpyHostToDevice, ctx->stream));
     GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -307,6 +331,46 @@ int gmmvi_logaddexp_f32(gmmvi_ctx* ctx, float* dst_dev, const float* a_dev, floa
     int blocks = (int)((count + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(logaddexp_f32_kernel, dim3(blocks), dim3(256), 0, ctx->stream, dst_dev, a_dev, ca, b_dev, cb, count);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+// out[g * out_stride + col0 + n] = log sum_{j in [off[g], off[g+1])} exp(logw[j] + ld[j * N + n])
+__global__ void segment_lse_kernel(const int32_t* __restrict__ off, const float* __restrict__ logw, const float* __restrict__ ld,
+                                   int N, float* __restrict__ out, size_t out_stride, int col0) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (n >= N) return;
+    float m = -3.0e38f, sum = 0.f;
+    for (int j = off[g]; j < off[g + 1]; ++j) {
+        const float v = logw[j] + ld[(size_t)j * N + n];
+        if (v > m) { sum = sum * expf(m - v) + 1.f; m = v; }
+        else sum += expf(v - m);
+    }
+    out[(size_t)g * out_stride + col0 + n] = m + logf(sum);
+}
+
+int gmmvi_segment_lse_f32(gmmvi_ctx* ctx, int G, const int32_t* offsets_dev, const float* logw_dev, const float* ld_dev, int N,
+                          float* out_dev, size_t out_stride, int col0) {
+    if (G <= 0 || N <= 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, offsets_dev && logw_dev && ld_dev && out_dev && col0 >= 0 && out_stride >= (size_t)col0 + N);
+    hipLaunchKernelGGL(segment_lse_kernel, dim3((N + 255) / 256, G), dim3(256), 0, ctx->stream, offsets_dev, logw_dev, ld_dev, N,
+                       out_dev, out_stride, col0);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+__global__ void copy_2d_f32_kernel(float* __restrict__ dst, size_t dst_stride, const float* __restrict__ src, size_t src_stride,
+                                   int cols) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c < cols) dst[(size_t)r * dst_stride + c] = src[(size_t)r * src_stride + c];
+}
+
+int gmmvi_copy_2d_f32(gmmvi_ctx* ctx, float* dst_dev, size_t dst_stride, const float* src_dev, size_t src_stride, int rows,
+                      int cols) {
+    if (rows <= 0 || cols <= 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, dst_dev && src_dev && dst_stride >= (size_t)cols && src_stride >= (size_t)cols);
+    hipLaunchKernelGGL(copy_2d_f32_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, ctx->stream, dst_dev, dst_stride, src_dev,
+                       src_stride, cols);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }

@@ -31,6 +31,13 @@ struct gmmvi_ctx {
     uint64_t ws_epoch = 0;       // bumped by every gmmvi_ws_reserve: the scratch contents belong to the call that reserved them
     void* arena = nullptr;       // persistent scratch of the single-call iteration (fused.hip)
     size_t arena_bytes = 0;
+    // small host -> device copies go through a ring of pinned staging slots and do not wait for the stream (api.hip: gmmvi_upload)
+    static constexpr int UP_SLOTS = 64;
+    static constexpr size_t UP_SLOT_BYTES = 64 * 1024;
+    unsigned char* up_ring = nullptr;
+    hipEvent_t up_event[UP_SLOTS] = {};
+    bool up_used[UP_SLOTS] = {};
+    int up_next = 0;
     void* bimg = nullptr;        // split bf16 images of the B operands of the blocked contractions (blocked.hip), grown on demand
     size_t bimg_bytes = 0;
     bool defer_combine = false;  // set by fused.hip around a sweep whose merge the next launch carries

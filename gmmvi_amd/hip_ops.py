@@ -410,6 +410,29 @@ def logaddexp(ctx, a, ca, b, cb):
     return out
 
 
+def segment_lse_into(ctx, out, col0, offsets, logw, ld):
+    """out[g, col0 + n] = log sum_{j in [offsets[g], offsets[g+1])} exp(logw[j] + ld[j, n]); out: [rows >= G, width] DeviceArray,
+    offsets: int32 DeviceArray [G + 1], ld: [Kw, N]."""
+    kw, n = ld.shape
+    g = offsets.shape[0] - 1
+    if out.ndim != 2 or out.shape[0] < g or out.shape[1] < col0 + n or logw.shape != (kw,):
+        raise ValueError("segment_lse_into: shape mismatch")
+    ctx.check(ctx.lib.gmmvi_segment_lse_f32(ctx.handle, g, offsets.ptr, logw.ptr, ld.ptr, n, out.ptr, out.shape[1], int(col0)))
+    return out
+
+
+def copy_2d(ctx, dst, dst_row, dst_col, src, src_row, src_col, rows, cols):
+    """dst[dst_row + r, dst_col + c] = src[src_row + r, src_col + c] (2-D float32 DeviceArrays)."""
+    if rows <= 0 or cols <= 0:
+        return dst
+    if (dst_row + rows > dst.shape[0] or dst_col + cols > dst.shape[1] or src_row + rows > src.shape[0]
+            or src_col + cols > src.shape[1]):
+        raise ValueError("copy_2d: block out of range")
+    ctx.check(ctx.lib.gmmvi_copy_2d_f32(ctx.handle, dst.ptr + (dst_row * dst.shape[1] + dst_col) * 4, dst.shape[1],
+                                        src.ptr + (src_row * src.shape[1] + src_col) * 4, src.shape[1], int(rows), int(cols)))
+    return dst
+
+
 def exp_into(ctx, dst, src):
     if dst.shape != src.shape or dst.dtype != F32 or src.dtype != F32:
         raise ValueError("exp_into: shape/dtype mismatch")

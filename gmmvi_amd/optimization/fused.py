@@ -118,6 +118,7 @@ class SamtronFastPath:
         ld_old = model.component_log_densities(xs_old)
         n_eff = np.floor(sel.get_effective_samples(ld_old, bg_old).numpy()).astype(np.int64)
         self._bg_old = bg_old            # the window's background density so far: the call extends it instead of redoing it
+        self._bg_mix = db._bg_cache["mix"]     # ... and the mixture it belongs to
         return np.maximum(1, s - n_eff), int(xs_old.shape[0])
 
     # ---- one iteration -----------------------------------------------------------------------------------------------------
@@ -161,21 +162,14 @@ class SamtronFastPath:
             p.n_old, p.bg_K, p.bg_packed = 0, 0, None
         else:
             # the components the reused samples came from, weighted by their counts among the reused samples: exactly the mixture
-            # get_newest_samples(n_old) evaluated for bg_old (same window start, this iteration's entry not counted)
-            active, acounts = db._window_components(s0 - n_old, s0)
-            assert active.max() < c0, "the reused samples come from earlier appends"
-            lo, hi = int(active[0]), int(active[-1]) + 1
-            if hi - lo == len(active) and (len(active) == 1 or np.all(np.diff(active) == 1)):
-                bg_packed_ptr = db._packed.buf.ptr + lo * stride * 4        # contiguous snapshot range: no gather
-                self._bg_keepalive = None
-            else:
-                self._bg_keepalive = hip_ops.gather_rows(ctx, db._packed.view(), active.astype(np.int32))
-                bg_packed_ptr = self._bg_keepalive.ptr
-            bg_logw = ctx.cached_const(("bg_logw", acounts.tobytes()),
-                                       lambda: ctx.asarray(np.log(acounts.astype(np.float64) / acounts.sum()).astype(np.float32)))
+            # get_newest_samples(n_old) evaluated for bg_old (same window; this iteration's entry not counted)
+            mix = self._bg_mix() if callable(self._bg_mix) else self._bg_mix
+            assert int(mix.active.max()) < c0, "the reused samples come from earlier appends"
+            self._bg_keepalive = (mix.packed, mix.logw_dev)
+            bg_packed_ptr, bg_logw = mix.packed.ptr, mix.logw_dev
             bg_logw_new = ctx.cached_const(("bg_logw", key), lambda: ctx.asarray(np.log(counts / counts.sum()).astype(np.float32)))
             self._bg_logw_new_keepalive = bg_logw_new
-            p.n_old, p.bg_K, p.bg_packed = n_old, len(active), bg_packed_ptr
+            p.n_old, p.bg_K, p.bg_packed = n_old, len(mix.active), bg_packed_ptr
             p.bg_old, p.bg_logw_new = self._bg_old.ptr, bg_logw_new.ptr
             p.bg_log_share_old, p.bg_log_share_new = db.log_shares(n_old, n)
         p.max_per_component = int(counts.max())

@@ -99,6 +99,10 @@ class SampleDB:
         self._segments = []
         # the last get_newest_samples answer: window [start, stop), its components / counts, its background density
         self._bg_cache = None
+        # per-append partial densities of the sliding window (_sliding_background)
+        self._pd = None
+        self._epoch = 0                   # bumped whenever samples are re-indexed (thinning, non-keeping assign)
+        self._seg_start, self._seg_size, self._seg_info = [], [], {}      # search keys / per-append component lists of the append log
 
     @staticmethod
     def build_from_config(config, num_dimensions):
@@ -204,6 +208,9 @@ class SampleDB:
         self._packed.assign(hip_ops.gather_rows(self.ctx, self._packed.view(), uidx))
         self._segments = []
         self._bg_cache = None
+        self._pd = None
+        self._epoch += 1
+        self._seg_start, self._seg_size, self._seg_info = [], [], {}
 
     def add_samples(self, samples, means, chols, target_lnpdfs, target_grads, mapping, mapping_host=None,
                     packed=None, counts=None):
@@ -229,6 +236,8 @@ class SampleDB:
                 self._segments.append((self._samples.n, offset, np.asarray(counts, np.int64)))
             else:
                 self._segments = []
+                self._pd = None
+                self._seg_start, self._seg_size, self._seg_info = [], [], {}
             self._mapping_host.append(mapping_host + offset)
             self._mapping_dev.reserve(n_new)
             if n_new:
@@ -243,6 +252,9 @@ class SampleDB:
         else:                                                                                  # :125-135
             self._segments = [(0, 0, np.asarray(counts, np.int64))] if counts is not None else []
             self._bg_cache = None
+            self._pd = None
+            self._epoch += 1
+            self._seg_start, self._seg_size, self._seg_info = [], [], {}
             self._mapping_host.assign(mapping_host)
             self._mapping_dev.assign(mapping.copy())
             self._means.assign(means.copy()); self._chols.assign(chols.copy()); self._packed.assign(packed)
@@ -308,6 +320,37 @@ class SampleDB:
         tot = float(n_old + n_new)
         return float(np.float32(np.log(n_old / tot))), float(np.float32(np.log(n_new / tot)))
 
+    def _rows_of(self, active):
+        """Snapshot blocks of the components ``active`` (ascending DB rows), as a view when they are consecutive."""
+        lo, hi = int(active[0]), int(active[-1]) + 1
+        if hi - lo == len(active):
+            return self._packed.view(lo, hi)
+        return hip_ops.gather_rows(self.ctx, self._packed.view(), active.astype(np.int32))
+
+    class _Mixture:
+        """The mixture a window's samples came from: components (DB rows), their sample counts inside the window, and -- built
+        on first use -- the device arrays the kernels take (log weights count / window size, snapshot blocks)."""
+        def __init__(self, db, active, counts, logw_dev=None):
+            self.db, self.active, self.counts, self._logw, self._packed = db, active, counts, logw_dev, None
+
+        @property
+        def logw_dev(self):
+            if self._logw is None:
+                c = self.counts
+                self._logw = self.db.ctx.cached_const(
+                    ("bg_logw", c.tobytes()), lambda: self.db.ctx.asarray(np.log(c.astype(np.float64) / c.sum()).astype(np.float32)))
+            return self._logw
+
+        @property
+        def packed(self):
+            if self._packed is None:
+                a = self.active
+                if len(a) > 1 and not np.all(np.diff(a) > 0):          # first-occurrence order that is not ascending
+                    self._packed = hip_ops.gather_rows(self.db.ctx, self.db._packed.view(), a.astype(np.int32))
+                else:
+                    self._packed = self.db._rows_of(a)
+            return self._packed
+
     def _extend_background(self, start, stop):
         """Background density of the window [start, stop) from the one of [start, cached stop) returned by the previous call
         (the effective-sample-size step of the sample selectors asks for the reused samples first, then -- after the append --
@@ -318,26 +361,142 @@ class SampleDB:
         c = self._bg_cache
         if c is None or c["start"] != start or not (c["stop"] < stop) or c["stop"] <= start:
             return None
-        old_active, old_counts = c["active"], c["counts"]
+        old = c["mix"]() if callable(c["mix"]) else c["mix"]
         new_active, new_counts = self._window_components(c["stop"], stop)
-        if new_active.min() <= old_active.max():                     # a component with samples in both halves: no clean split
+        if new_active.min() <= old.active.max():                     # a component with samples in both halves: no clean split
             return None
         ctx = self.ctx
         n_old, n_new = c["stop"] - start, stop - c["stop"]
-
-        def rows(active):
-            lo, hi = int(active[0]), int(active[-1]) + 1
-            if hi - lo == len(active) and (len(active) == 1 or np.all(np.diff(active) == 1)):
-                return self._packed.view(lo, hi)
-            return hip_ops.gather_rows(ctx, self._packed.view(), active.astype(np.int32))
-
-        def logw(counts):
-            return ctx.cached_const(("bg_logw", counts.tobytes()),
-                                    lambda: ctx.asarray(np.log(counts.astype(np.float64) / counts.sum()).astype(np.float32)))
-        part_old = hip_ops.concat(ctx, [c["bg"], self._mixture_lp(rows(old_active), logw(old_counts), self._samples.view(c["stop"]))])
-        part_new = self._mixture_lp(rows(new_active), logw(new_counts), self._samples.view(start))
+        new = SampleDB._Mixture(self, new_active, new_counts)
+        part_old = hip_ops.concat(ctx, [c["bg"], self._mixture_lp(old.packed, old.logw_dev, self._samples.view(c["stop"]))])
+        part_new = self._mixture_lp(new.packed, new.logw_dev, self._samples.view(start))
         ca, cb = self.log_shares(n_old, n_new)
         return hip_ops.logaddexp(ctx, part_old, ca, part_new, cb)
+
+    # the partial densities of a window hold at most this many floats of component log densities at a time
+    _PD_MAX_LD_FLOATS = 1 << 27
+
+    def _segment_info(self, idx, logW):
+        """(DB rows, counts, float32 log(count / W)) of the components with samples in append ``idx``."""
+        key = (idx, logW)
+        info = self._seg_info.get(key)
+        if info is None:
+            s0, c0, counts = self._segments[idx]
+            nz = np.nonzero(counts > 0)[0]
+            cnt = counts[nz]
+            info = (c0 + nz, cnt, (np.log(cnt.astype(np.float64)) - logW).astype(np.float32))
+            self._seg_info[key] = info
+        return info
+
+    def _sliding_background(self, start, stop):
+        """Background density of the window [start, stop) of FIXED length (the reuse window once the database is longer than it)
+        from per-append partial densities.  The window's mixture weights a component by its samples inside the window
+        (sample_db.py:221-226); for an append g that lies wholly inside, those are the append's own counts, so
+        P_g[n] = log sum_{j in g} count_j / W  N_j(x_n) does not depend on where the window starts: the rows of such appends are
+        kept from call to call (the surviving block is moved, the new samples' columns and the new appends' rows are evaluated);
+        only the append the window cuts through is evaluated again with its counts inside the window.  The answer is the
+        log-sum-exp of the rows: the same mixture, summed in groups.  -> (DeviceArray, mixture) or None (caller evaluates from
+        scratch).  Host work per call is O(appends entering or leaving the window), not O(appends inside)."""
+        ctx, W = self.ctx, stop - start
+        segs = self._segments
+        if self.diagonal_covariances or not segs or W <= 0:
+            return None
+        if len(self._seg_start) != len(segs):                           # append log grew: extend the search keys
+            for s0, c0, counts in segs[len(self._seg_start):]:
+                self._seg_start.append(s0)
+                self._seg_size.append(int(counts.sum()))
+        hi = len(segs) - 1
+        if self._seg_start[hi] + self._seg_size[hi] != stop:
+            return None
+        import bisect
+        lo = bisect.bisect_left(self._seg_start, start)                 # first append that starts inside the window
+        cut = None
+        if lo == 0:
+            if self._seg_start[0] != start:
+                return None                                             # samples in front of the recorded appends
+        elif self._seg_start[lo - 1] + self._seg_size[lo - 1] > start:
+            cut = lo - 1
+        if lo > hi and cut is None:
+            return None
+        logW = float(np.log(float(W)))
+        if len(self._seg_info) > 4 * (hi - lo + 8):
+            self._seg_info = {k: v for k, v in self._seg_info.items() if k[0] >= lo}
+        pd = self._pd
+        reuse = (pd is not None and pd["epoch"] == self._epoch and pd["W"] == W and pd["start"] <= start
+                 and pd["stop"] <= stop and pd["stop"] > start and pd["hi"] >= lo and pd["lo"] <= lo)
+        n_inside = max(0, hi - lo + 1)
+        n_rows = n_inside + (1 if cut is not None else 0)
+        P = ctx.empty((n_rows, W))
+        xs = self._samples.view(start)
+        if reuse:
+            n_kept = pd["hi"] - lo + 1
+            drop_segs = lo - pd["lo"]
+            drop_comps = int(pd["nseg"][:drop_segs].sum())
+            k_active, k_counts, k_nseg = pd["active"][drop_comps:], pd["counts"][drop_comps:], pd["nseg"][drop_segs:]
+            k_logw = pd["logw_dev"].rows(drop_comps, pd["logw_dev"].shape[0])
+            keep_cols = pd["stop"] - start
+            hip_ops.copy_2d(ctx, P, 0, 0, pd["P"], drop_segs, start - pd["start"], n_kept, keep_cols)
+            new_cols = W - keep_cols
+            if new_cols > 0:
+                if len(k_active) * new_cols > self._PD_MAX_LD_FLOATS:
+                    return None
+                offsets = np.concatenate([[0], np.cumsum(k_nseg)]).astype(np.int32)
+                ld = hip_ops.mixture_eval(ctx, self._rows_of(k_active), k_logw, self._samples.view(pd["stop"]), self._dim,
+                                          want_ld=True, want_lp=False)[0]
+                hip_ops.segment_lse_into(ctx, P, keep_cols, ctx.asarray(offsets, np.int32), k_logw, ld)
+            fresh = range(pd["hi"] + 1, hi + 1)
+        else:
+            n_kept = 0
+            k_active = k_counts = np.zeros(0, np.int64)
+            k_nseg = np.zeros(0, np.int64)
+            k_logw = None
+            fresh = range(lo, hi + 1)
+        # rows of the appends that are new to the window (normally one): their mixture on all window samples
+        infos = [self._segment_info(i, logW) for i in fresh]
+        row = n_kept
+        f_logw_dev = []
+        if len(infos) > 2:
+            active = np.concatenate([i[0] for i in infos])
+            if len(active) * W > self._PD_MAX_LD_FLOATS:
+                return None
+            offsets = np.concatenate([[0], np.cumsum([len(i[0]) for i in infos])]).astype(np.int32)
+            lw = ctx.asarray(np.concatenate([i[2] for i in infos]))
+            f_logw_dev.append(lw)
+            ld = hip_ops.mixture_eval(ctx, self._rows_of(active), lw, xs, self._dim, want_ld=True, want_lp=False)[0]
+            hip_ops.segment_lse_into(ctx, P.rows(row, row + len(infos)), 0, ctx.asarray(offsets, np.int32), lw, ld)
+            row += len(infos)
+        else:
+            for act, cnt, lw_host in infos:
+                lw = ctx.asarray(lw_host)
+                f_logw_dev.append(lw)
+                P.rows(row, row + 1).reshape(W).copy_from(self._mixture_lp(self._rows_of(act), lw, xs))
+                row += 1
+        # the append the window cuts through, with its counts inside the window
+        cut_part = None
+        if cut is not None:
+            mp = self._mapping_host.view(start)[:self._seg_start[cut] + self._seg_size[cut] - start]
+            uniq, cnt = np.unique(mp, return_counts=True)
+            lw = ctx.asarray((np.log(cnt.astype(np.float64)) - logW).astype(np.float32))
+            P.rows(row, row + 1).reshape(W).copy_from(self._mixture_lp(self._rows_of(uniq), lw, xs))
+            cut_part = (uniq.astype(np.int64), cnt.astype(np.int64), lw)
+            row += 1
+        assert row == n_rows
+        active = np.concatenate([k_active] + [i[0] for i in infos]) if infos else k_active
+        counts = np.concatenate([k_counts] + [i[1] for i in infos]) if infos else k_counts
+        nseg = np.concatenate([k_nseg, np.array([len(i[0]) for i in infos], np.int64)])
+        parts = ([k_logw] if k_logw is not None and k_logw.shape[0] else []) + f_logw_dev
+        logw_dev = parts[0] if len(parts) == 1 else (hip_ops.concat(ctx, parts) if parts else None)
+        self._pd = {"epoch": self._epoch, "W": W, "start": start, "stop": stop, "lo": lo, "hi": hi, "P": P, "active": active,
+                    "counts": counts, "nseg": nseg, "logw_dev": logw_dev}
+        bg = P.reshape(W).copy() if n_rows == 1 else hip_ops.combine_partials(ctx, P, None, self._dim)[0]
+
+        def mixture():
+            # oldest first: the cut append's components, then the appends inside
+            if cut_part is None:
+                return SampleDB._Mixture(self, active, counts, logw_dev)
+            return SampleDB._Mixture(self, np.concatenate([cut_part[0], active]), np.concatenate([cut_part[1], counts]),
+                                     hip_ops.concat(ctx, [cut_part[2], logw_dev]) if logw_dev is not None else cut_part[2])
+        return bg, mixture
 
     def get_newest_samples(self, N, fuse_with_model=None):
         """sample_db.py:194-228 -> (log_pdfs, samples, mapping, target_lnpdfs, target_grads).
@@ -350,31 +509,33 @@ class SampleDB:
             return (ctx.empty((0,)), ctx.empty((0, d)), ctx.empty((0,), np.int32), ctx.empty((0,)),
                     ctx.empty((0, d)))
         start = max(0, self._samples.n - N)                                                    # :216
+        stop = self._samples.n
         xs = self._samples.view(start)
-        active, counts = self._active_components(start)                                        # :221
-        lo, hi = int(active[0]), int(active[-1]) + 1
-        if hi - lo == len(active) and (len(active) == 1 or np.all(np.diff(active) == 1)):
-            packed = self._packed.view(lo, hi)                 # contiguous snapshot range: no gather
-        else:
-            packed = hip_ops.gather_rows(ctx, self._packed.view(), active.astype(np.int32))
+        whole = None                    # the window's components and counts, worked out only by the routes that need them
 
-        def build():
-            w = counts.astype(np.float64) / counts.sum()                                       # :225-226
-            return ctx.asarray(np.log(w).astype(np.float32))
-        logw = ctx.cached_const(("bg_logw", counts.tobytes()), build)
-        if (fuse_with_model is not None and self._segments and self._segments[-1][0] == start
-                and len(active) == fuse_with_model.num_components):
-            bg = fuse_with_model.eval_with_background(xs, logw)
-            extended = False
-        else:
-            bg = self._extend_background(start, self._samples.n)
+        def window_mixture():
+            nonlocal whole
+            if whole is None:
+                whole = SampleDB._Mixture(self, *self._window_components(start, stop))         # :221, :225-226
+            return whole
+
+        bg, mix, extended = None, window_mixture, False
+        if fuse_with_model is not None and self._segments and self._segments[-1][0] == start:
+            if len(window_mixture().active) == fuse_with_model.num_components:
+                bg = fuse_with_model.eval_with_background(xs, window_mixture().logw_dev)
+        if bg is None:
+            bg = self._extend_background(start, stop)
             extended = bg is not None
-            if not extended:
-                bg = self._mixture_lp(packed, logw, xs)                                        # :227
+        if bg is None and start > 0:                           # a full-length window that slides: per-append partial densities
+            ans = self._sliding_background(start, stop)
+            if ans is not None:
+                bg, mix = ans
+        if bg is None:
+            m = window_mixture()
+            bg = self._mixture_lp(m.packed, m.logw_dev, xs)                                    # :227
         # an extended answer is not extended again (the single-call iteration, which extends inside its C call, keeps no
         # array to extend from either: both paths then recompute the next window from scratch and stay bit-equal)
-        self._bg_cache = None if extended else {"start": start, "stop": self._samples.n, "bg": bg, "active": active,
-                                                "counts": counts}
+        self._bg_cache = None if extended else {"start": start, "stop": stop, "bg": bg, "mix": mix}
         return (bg, xs, self._mapping_dev.view(start), self._target_lnpdfs.view(start),
                 self._target_grads.view(start))
 

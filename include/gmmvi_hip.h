@@ -103,6 +103,16 @@ int gmmvi_exp_f32(gmmvi_ctx* ctx, float* dst_dev, const float* src_dev, size_t c
  * window's mixture on all of its samples every time). */
 int gmmvi_logaddexp_f32(gmmvi_ctx* ctx, float* dst_dev, const float* a_dev, float ca, const float* b_dev, float cb,
                         size_t count);
+/* Per-append partial densities of SampleDB's background mixture: the components of a window are grouped by the append that
+ * contributed them (G groups, offsets [G+1] into the component axis); out[g * out_stride + col0 + n] = log sum_{j in group g}
+ * exp(logw[j] + ld[j, n]) from the component log densities ld [Kw, N].  The window's density (optimization/sample_db.py:
+ * 216-227) is the log-sum-exp of those rows (gmmvi_combine_partials); rows of appends that stay wholly inside the sliding
+ * window are kept from one iteration to the next (gmmvi_copy_2d_f32 moves the surviving block). */
+int gmmvi_segment_lse_f32(gmmvi_ctx* ctx, int G, const int32_t* offsets_dev, const float* logw_dev, const float* ld_dev, int N,
+                          float* out_dev, size_t out_stride, int col0);
+/* dst[r * dst_stride + c] = src[r * src_stride + c], r < rows, c < cols. */
+int gmmvi_copy_2d_f32(gmmvi_ctx* ctx, float* dst_dev, size_t dst_stride, const float* src_dev, size_t src_stride, int rows,
+                      int cols);
 /* timing helpers for bench.py: HIP events on the context's stream */
 int gmmvi_event_create(gmmvi_ctx* ctx, void** out_event);
 int gmmvi_event_destroy(gmmvi_ctx* ctx, void* event);

@@ -313,3 +313,51 @@ def test_extended_background_equals_the_window_mixture():
         fresh = db.get_newest_samples(n_win)[0].numpy()  # no cache now: the whole window's mixture on all of its samples
         np.testing.assert_allclose(bg, fresh, rtol=2e-6, atol=2e-6)
         np.testing.assert_allclose(bg, odb.get_newest_samples(n_win)[0], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("new_per_append", [(3, 9), (20, 60)])
+def test_sliding_window_background_equals_the_window_mixture(new_per_append):
+    """Once the database is longer than the reuse window, SampleDB.get_newest_samples keeps per-append partial densities of the
+    window (rows of appends that stay wholly inside are moved, not recomputed): every answer must equal the window mixture's
+    density evaluated from scratch and the fp64 oracle database's; appends of very different sizes, so that the window cuts
+    through an append at most offsets and several appends leave it at once."""
+    from oracle.sample_db import SampleDB as OracleDB
+    from gmmvi_amd.optimization.sample_db import SampleDB
+    from gmmvi_amd.device import get_context
+    ctx = get_context()
+    rng = np.random.default_rng(11)
+    d, k, window = 5, 4, 150
+    db, odb = SampleDB(d, False, True, ctx=ctx), OracleDB(d, False, True)
+    used_rows = 0
+    for it in range(14):
+        means = rng.normal(size=(k, d)) * 2
+        a = rng.normal(size=(k, d, d)) * 0.3
+        chols = np.linalg.cholesky(a @ a.transpose(0, 2, 1) + np.eye(d))
+        counts = rng.integers(new_per_append[0], new_per_append[1], k)
+        if it % 5 == 4:
+            counts[rng.integers(0, k)] = 0                      # a component without a sample in this append
+        mapping = np.repeat(np.arange(k, dtype=np.int32), counts)
+        xs = means[mapping] + np.einsum("nij,nj->ni", chols[mapping], rng.normal(size=(len(mapping), d)))
+        args = (xs.astype(np.float32), means.astype(np.float32), chols.astype(np.float32), np.zeros(len(mapping), np.float32),
+                np.zeros((len(mapping), d), np.float32), mapping)
+        db.add_samples(*args, counts=counts)
+        odb.add_samples(*[np.asarray(v, np.float64) if v.dtype != np.int32 else v for v in args])
+        bg = db.get_newest_samples(window)[0].numpy()
+        if db.samples.shape[0] > window:
+            assert db._pd is not None and db._pd["stop"] == db.samples.shape[0]      # the sliding route answered
+            used_rows += 1
+            keep, db._pd, db._bg_cache = db._pd, None, None
+            scratch = db._mixture_lp(*_window_mixture(db, window))                    # all components x all samples
+            np.testing.assert_allclose(bg, scratch.numpy(), rtol=3e-6, atol=3e-6)
+            db._pd = keep
+        np.testing.assert_allclose(bg, odb.get_newest_samples(window)[0], rtol=1e-4, atol=1e-4)
+    assert used_rows >= 5
+
+
+def _window_mixture(db, window):
+    start = db.samples.shape[0] - window
+    active, counts = db._active_components(start)
+    from gmmvi_amd import hip_ops
+    packed = hip_ops.gather_rows(db.ctx, db._packed.view(), active.astype(np.int32))
+    logw = db.ctx.asarray(np.log(counts / counts.sum()).astype(np.float32))
+    return packed, logw, db._samples.view(start)
