@@ -340,11 +340,23 @@ __global__ void segment_lse_kernel(const int32_t* __restrict__ off, const float*
                                    int N, float* __restrict__ out, size_t out_stride, int col0) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
     if (n >= N) return;
+    // eight independent loads in flight per round (a load per dependent step made this kernel 36 us for 3 000 components x 300
+    // samples), one rescale of the running sum per round
     float m = -3.0e38f, sum = 0.f;
-    for (int j = off[g]; j < off[g + 1]; ++j) {
-        const float v = logw[j] + ld[(size_t)j * N + n];
-        if (v > m) { sum = sum * expf(m - v) + 1.f; m = v; }
-        else sum += expf(v - m);
+    const int j1 = off[g + 1];
+    for (int j = off[g]; j < j1; j += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = j + u < j1 ? logw[j + u] + ld[(size_t)(j + u) * N + n] : -3.0e38f;
+        float mr = v[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u) mr = fmaxf(mr, v[u]);
+        const float mn = fmaxf(m, mr);
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) part += expf(v[u] - mn);
+        sum = sum * expf(m - mn) + part;
+        m = mn;
     }
     out[(size_t)g * out_stride + col0 + n] = m + logf(sum);
 }
