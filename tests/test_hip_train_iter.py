@@ -361,3 +361,29 @@ def _window_mixture(db, window):
     packed = hip_ops.gather_rows(db.ctx, db._packed.view(), active.astype(np.int32))
     logw = db.ctx.asarray(np.log(counts / counts.sum()).astype(np.float32))
     return packed, logw, db._samples.view(start)
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["modular", "single_call"])
+def test_sample_reuse_with_adaptive_components(fused):
+    """Reuse ratio 2 AND an adaptive number of components: the appends inside the sliding reuse window then have different
+    numbers of components, components are added between appends, the window cuts through appends at varying offsets -- the
+    per-append partial densities of SampleDB must keep reproducing the oracle's background densities (effective sample sizes
+    decide how many samples every component draws: a wrong density changes the database sizes compared below)."""
+    ad = {"del_iters": 7, "add_iters": 3, "max_components": 7, "thresholds_for_add_heuristic": [50., 20., 10.],
+          "min_weight_for_del_heuristic": 1e-6, "num_database_samples": 100, "num_prior_samples": 0}
+    cfg = samtron_config(30, reuse_ratio=2.0, adaptive=ad)
+    o = make_oracle("gmm", 3, 2, 30, 9, cfg)
+    g = make_device("gmm", 3, 2, 30, 9, cfg, o)
+    if not fused:
+        g._fast_path.enabled = False
+    slid = 0
+    for it in range(18):
+        o.train_iter()
+        g.train_iter()
+        assert g.model.num_components == o.model.num_components
+        assert g.sample_db.samples.shape[0] == o.sample_db.samples.shape[0], f"iteration {it}: different numbers of new samples"
+        slid += g.sample_db._pd is not None and g.sample_db._pd["stop"] >= g.sample_db.samples.shape[0] - 400
+    assert g.model.num_components > 2 and slid >= 5
+    np.testing.assert_array_equal(g.sample_db.mapping.numpy(), o.sample_db.mapping)
+    dev = np.abs(g.model.means.numpy() - o.model.means).max() / max(1.0, np.abs(o.model.means).max())
+    assert dev <= 0.1, dev
