@@ -1773,9 +1773,18 @@ __global__ __launch_bounds__(256) void blk_upd_prep_kernel(int D, const float* _
         o[e] = (j <= i) ? R[e] : R[(size_t)j * D + i];
     }
     for (int t = blockIdx.y * 256 + threadIdx.x; t < D; t += gridDim.y * 256) {
-        float g = g_neg[(size_t)k * D + t];
-        for (int j = t + 1; j < D; ++j) g = fmaf(R[(size_t)j * D + t] - R[(size_t)t * D + j], mu[j], g);
-        gt[(size_t)k * D + t] = g;
+        // four independent partial sums: the loads of four terms are in flight together (one chain of D dependent
+        // load + multiply-add steps made this loop 100 of the kernel's 112 us at D = 300)
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int j = t + 1;
+        for (; j + 3 < D; j += 4) {
+            a0 = fmaf(R[(size_t)j * D + t] - R[(size_t)t * D + j], mu[j], a0);
+            a1 = fmaf(R[(size_t)(j + 1) * D + t] - R[(size_t)t * D + j + 1], mu[j + 1], a1);
+            a2 = fmaf(R[(size_t)(j + 2) * D + t] - R[(size_t)t * D + j + 2], mu[j + 2], a2);
+            a3 = fmaf(R[(size_t)(j + 3) * D + t] - R[(size_t)t * D + j + 3], mu[j + 3], a3);
+        }
+        for (; j < D; ++j) a0 = fmaf(R[(size_t)j * D + t] - R[(size_t)t * D + j], mu[j], a0);
+        gt[(size_t)k * D + t] = g_neg[(size_t)k * D + t] + ((a0 + a1) + (a2 + a3));
     }
 }
 
@@ -1798,8 +1807,17 @@ __global__ __launch_bounds__(256) void blk_upd_sym_kernel(int D, const float* __
         }
     }
     for (int t = blockIdx.y * 256 + threadIdx.x; t < D; t += gridDim.y * 256) {
-        float a = 0.f;
-        for (int c = t; c < D; ++c) a = fmaf(L[(size_t)c * D + t], gt[(size_t)k * D + c], a);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;              // four independent partial sums (as in blk_upd_prep_kernel)
+        const float* gk = gt + (size_t)k * D;
+        int c = t;
+        for (; c + 3 < D; c += 4) {
+            a0 = fmaf(L[(size_t)c * D + t], gk[c], a0);
+            a1 = fmaf(L[(size_t)(c + 1) * D + t], gk[c + 1], a1);
+            a2 = fmaf(L[(size_t)(c + 2) * D + t], gk[c + 2], a2);
+            a3 = fmaf(L[(size_t)(c + 3) * D + t], gk[c + 3], a3);
+        }
+        for (; c < D; ++c) a0 = fmaf(L[(size_t)c * D + t], gk[c], a0);
+        const float a = (a0 + a1) + (a2 + a3);
         w[(size_t)k * D + t] = a;
         wt[(size_t)k * D + t] = a;
     }
