@@ -2269,7 +2269,9 @@ __global__ __launch_bounds__(64) void blk_search_kernel(int D, const float* __re
         wt[i] = wt_all[(size_t)k * D + i];
     }
     __syncthreads();
-    float* scratch = scratch_all + (size_t)k * 2 * D * 64;
+    // pivot columns of the 64 lanes: in LDS when they fit (2 D x 64 floats: D <= 310 -- the backward recurrence reads them back
+    // one dependent load per step, 262 us per launch from global memory at D = 300), else in global scratch
+    float* scratch = scratch_all != nullptr ? scratch_all + (size_t)k * 2 * D * 64 : sm + 3 * D;
     const float eps = stepsizes[k];
     const float last = last_eta[k];
     float lb, ub;
@@ -2490,8 +2492,20 @@ int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* c
         }
         GMMVI_LAUNCH_CHECK(ctx);
     }
-    hipLaunchKernelGGL(blk_search_kernel, dim3(K), dim3(64), (size_t)3 * D * sizeof(float), ctx->stream, D, td, te, wt, stepsizes,
-                       last_eta, temperature, scratch, state);
+    {
+        const size_t lds_cols = ((size_t)3 * D + (size_t)2 * D * 64) * sizeof(float);
+        const bool in_lds = lds_cols <= 160 * 1024;
+        if (in_lds) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         160 * 1024));
+                attr_done = true;
+            }
+        }
+        hipLaunchKernelGGL(blk_search_kernel, dim3(K), dim3(64), in_lds ? lds_cols : (size_t)3 * D * sizeof(float), ctx->stream, D,
+                           td, te, wt, stepsizes, last_eta, temperature, in_lds ? nullptr : scratch, state);
+    }
     GMMVI_LAUNCH_CHECK(ctx);
     {
         static bool attr_done = false;
