@@ -1071,13 +1071,14 @@ __host__ __device__ inline int blk_trsm_ld(int D) {
     const int ld = ((D + 3) / 4) * 4 + 4;
     return (ld / 4) % 2 == 0 ? ld + 4 : ld;
 }
-inline size_t blk_trsm_lds_floats(int D) { return (size_t)TRB * blk_trsm_ld(D); }
+inline size_t blk_trsm_lds_floats(int D) { return (size_t)TRB * blk_trsm_ld(D) + (size_t)(D + 1) * (TRB + 1); }     // + sums of up to D + 1 right-hand sides
 
 template <bool TCM, class RhsF>
 __device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs, int i0, float* X, int ldx, float* Ts) {
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6, nwave = blockDim.x >> 6, col = lane & 31, half = lane >> 5;
     const int ld = blk_trsm_ld(D);
+    float* Ss = Ts + (size_t)TRB * ld;                     // [rhs][33]: what the solved rows contribute to the current block
     for (int I = 0; I < D; I += TRB) {
         const int nbk = min(TRB, D - I), w = I + nbk;
         __syncthreads();
@@ -1095,7 +1096,7 @@ __device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs
         __syncthreads();
         // what the solved rows contribute to this block, S[r][t] = sum_{c < I} T[I + r][c] x_c(t), as matrix-core tiles (wave w
         // takes the 32-rhs tiles w, w + waves, ..: A operand from the staged rows, B operand = dword loads of X from the L2),
-        // parked in the block's own rows of X until their owners pick them up (this sum as per-thread multiply-adds over
+        // handed to the right-hand sides' threads through LDS (this sum as per-thread multiply-adds over
         // broadcast LDS reads was the bulk of the 0.96 M cycles of the solve at D = 300)
         if (I > 0) {
             const int ntile = (nrhs + TRB - 1) / TRB;
@@ -1118,10 +1119,7 @@ __device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs
                 }
                 if (t0 + col < nrhs) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int r = (j & 3) + 8 * (j >> 2) + 4 * half;
-                        if (r < nbk) X[(size_t)(I + r) * ldx + t0 + col] = sacc[j];
-                    }
+                    for (int j = 0; j < 16; ++j) Ss[(size_t)(t0 + col) * (TRB + 1) + (j & 3) + 8 * (j >> 2) + 4 * half] = sacc[j];
                 }
             }
             __syncthreads();
@@ -1135,7 +1133,7 @@ __device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs
             continue;
         }
 #pragma unroll
-        for (int r = 0; r < TRB; ++r) acc[r] = (r < nbk) ? rhs(I + r, t) - (I > 0 ? X[(size_t)(I + r) * ldx + t] : 0.f) : 0.f;
+        for (int r = 0; r < TRB; ++r) acc[r] = (r < nbk) ? rhs(I + r, t) - (I > 0 ? Ss[(size_t)t * (TRB + 1) + r] : 0.f) : 0.f;
 #pragma unroll
         for (int r = 0; r < TRB; ++r) {
             if (r < nbk) {
@@ -1430,7 +1428,7 @@ static int blk_threads(int D) { return ((D + 63) / 64) * 64; }
 static int blk_lds_attr(gmmvi_ctx* ctx) {
     static bool done = false;
     if (done) return GMMVI_OK;
-    const int lim = 96 * 1024;
+    const int lim = 156 * 1024;            // (the kernels also hold a few static words)
     GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_cholesky_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     done = true;
@@ -2511,7 +2509,7 @@ int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* c
         static bool attr_done = false;
         if (!attr_done) {
             GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_upd_final_kernel,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
             attr_done = true;
         }
         const size_t a = blk_trsm_lds_floats(D), b = blk_chol_lds_floats(D);
@@ -2572,7 +2570,7 @@ int gmmvi_blocked_update_plain(gmmvi_ctx* ctx, int mode, int K, int D, float* me
         static bool attr_done = false;
         if (!attr_done) {
             GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_upd_final_kernel,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
             attr_done = true;
         }
         const size_t a = blk_trsm_lds_floats(D), b = blk_chol_lds_floats(D);
