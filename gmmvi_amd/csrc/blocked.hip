@@ -1088,9 +1088,9 @@ __device__ void blk_trsm(int D, const float* __restrict__ Tm, int nrhs, RhsF rhs
                 if (r < nbk) Ts[r * ld + c] = (c <= I + r) ? Tm[(size_t)c * D + I + r] : 0.f;
             }
         } else {
-            for (int e = t; e < nbk * w; e += blockDim.x) {
-                const int r = e / w, c = e % w;
-                Ts[r * ld + c] = Tm[(size_t)(I + r) * D + c];
+            for (int c = t; c < w; c += blockDim.x) {          // row by row: no index divisions, every load independent
+#pragma unroll 8
+                for (int r = 0; r < nbk; ++r) Ts[r * ld + c] = Tm[(size_t)(I + r) * D + c];
             }
         }
         __syncthreads();
