@@ -1287,7 +1287,7 @@ __device__ bool blk_cholesky(int D, ElemF a, float* W, float* lds) {
 // ---------------------------------------------------------------------------------------------------------------------------
 // component blocks: [mu | const | pad | L^-1]
 // ---------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void blk_pack_kernel(int family, float nu, int D, const float* __restrict__ means,
+__global__ __launch_bounds__(704) void blk_pack_kernel(int family, float nu, int D, const float* __restrict__ means,
                                                        const float* __restrict__ chols, float* __restrict__ packed,
                                                        size_t ps, int lo, float* __restrict__ inv_out) {
     extern __shared__ __align__(16) float dyn[];
@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__(512) void blk_pack_kernel(int family, float nu, int
     }
 }
 
-__global__ __launch_bounds__(512) void blk_cholesky_kernel(int D, const float* __restrict__ covs, float* __restrict__ W,
+__global__ __launch_bounds__(704) void blk_cholesky_kernel(int D, const float* __restrict__ covs, float* __restrict__ W,
                                                            float* __restrict__ chols, int32_t* __restrict__ ok) {
     extern __shared__ __align__(16) float dyn[];
     const int k = blockIdx.x, t = threadIdx.x;
@@ -1423,6 +1423,9 @@ int blk_forward(gmmvi_ctx* ctx, int D, const float* packed, int k0, int kn, cons
 #define BLK_TRY(call) do { int rc__ = (call); if (rc__ != GMMVI_OK) return rc__; } while (0)
 
 static int blk_threads(int D) { return ((D + 63) / 64) * 64; }
+// factorisation kernels: one wavefront per 32-row / 32-rhs tile of the matrix-core sums when that fits (D <= 320: <= 11 waves),
+// else one thread per row as everywhere
+static int blk_threads_mm(int D) { return D <= 320 ? 64 * ((D + 31) / 32) : blk_threads(D); }
 
 // the factorisation kernels stage up to ~70 KB of LDS at D = 512: raise the dynamic limit once
 static int blk_lds_attr(gmmvi_ctx* ctx) {
@@ -1439,7 +1442,7 @@ int gmmvi_blocked_pack(gmmvi_ctx* ctx, int family, float nu, int K, int D, const
                        float* packed, float* inv_chols) {
     GMMVI_PROF(ctx, "blocked_pack");
     BLK_TRY(blk_lds_attr(ctx));
-    hipLaunchKernelGGL(blk_pack_kernel, dim3(K), dim3(blk_threads(D)), blk_trsm_lds_floats(D) * sizeof(float), ctx->stream, family,
+    hipLaunchKernelGGL(blk_pack_kernel, dim3(K), dim3(blk_threads_mm(D)), blk_trsm_lds_floats(D) * sizeof(float), ctx->stream, family,
                        nu, D, means, chols, packed, gmmvi_blocked_stride(D), gmmvi_blocked_linv_ofs(D), inv_chols);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
@@ -1448,7 +1451,7 @@ int gmmvi_blocked_pack(gmmvi_ctx* ctx, int family, float nu, int K, int D, const
 int gmmvi_blocked_cholesky(gmmvi_ctx* ctx, int K, int D, const float* covs, float* chols, int32_t* ok) {
     BLK_TRY(gmmvi_ws_reserve(ctx, (size_t)K * D * D * sizeof(float)));
     BLK_TRY(blk_lds_attr(ctx));
-    hipLaunchKernelGGL(blk_cholesky_kernel, dim3(K), dim3(blk_threads(D)), blk_chol_lds_floats(D) * sizeof(float), ctx->stream, D,
+    hipLaunchKernelGGL(blk_cholesky_kernel, dim3(K), dim3(blk_threads_mm(D)), blk_chol_lds_floats(D) * sizeof(float), ctx->stream, D,
                        covs, (float*)ctx->ws, chols, ok);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
@@ -2324,7 +2327,7 @@ __global__ __launch_bounds__(64) void blk_search_kernel(int D, const float* __re
 // modes 1 / 2 (direct :97-141, iBLR :160-223): Mc holds the new precision Q' (lower triangle read, as tf.linalg.cholesky
 // does); Q' = U U^T the same way, the new factor is L' = U^-T (rows of the identity as right-hand sides), the new mean
 // L' (U^-1 lin') for the direct update (w = new linear term), the precomputed mean (w) for iBLR.
-__global__ __launch_bounds__(576) void blk_upd_final_kernel(int D, int mode, const float* __restrict__ Mc_all,
+__global__ __launch_bounds__(704) void blk_upd_final_kernel(int D, int mode, const float* __restrict__ Mc_all,
                                                             const float* __restrict__ w_all, float* __restrict__ W_all,
                                                             float* __restrict__ X_all, const float* __restrict__ state,
                                                             float* __restrict__ means, float* __restrict__ chols,
@@ -2513,7 +2516,7 @@ int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* c
             attr_done = true;
         }
         const size_t a = blk_trsm_lds_floats(D), b = blk_chol_lds_floats(D);
-        hipLaunchKernelGGL(blk_upd_final_kernel, dim3(K), dim3(blk_threads(D + 1)), (a > b ? a : b) * sizeof(float), ctx->stream, D,
+        hipLaunchKernelGGL(blk_upd_final_kernel, dim3(K), dim3(blk_threads_mm(D + 1)), (a > b ? a : b) * sizeof(float), ctx->stream, D,
                            0, Mc, w, T1, Xs, state, means, chols, l2_init, last_eta, l2, num_updates, success_out, kl_out,
                            nprobes_out);
     }
@@ -2574,7 +2577,7 @@ int gmmvi_blocked_update_plain(gmmvi_ctx* ctx, int mode, int K, int D, float* me
             attr_done = true;
         }
         const size_t a = blk_trsm_lds_floats(D), b = blk_chol_lds_floats(D);
-        hipLaunchKernelGGL(blk_upd_final_kernel, dim3(K), dim3(blk_threads(D + 1)), (a > b ? a : b) * sizeof(float), ctx->stream, D,
+        hipLaunchKernelGGL(blk_upd_final_kernel, dim3(K), dim3(blk_threads_mm(D + 1)), (a > b ? a : b) * sizeof(float), ctx->stream, D,
                            mode == 0 ? 1 : 2, Qp, vec, W, Xs, nullptr, means, chols, l2_init, nullptr, l2, num_updates,
                            success_out, nullptr, nullptr);
         GMMVI_LAUNCH_CHECK(ctx);
