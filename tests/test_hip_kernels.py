@@ -613,3 +613,19 @@ def test_mixture_eval_dual(ctx, rng, k, d, n):
     np.testing.assert_allclose(bg.numpy(), bg1.numpy(), rtol=1e-6, atol=1e-6)
     ref = logsumexp(m.component_log_densities(x.astype(np.float32).astype(np.float64)) + np.log(counts / counts.sum())[:, None], axis=0)
     np.testing.assert_allclose(bg.numpy(), ref, rtol=1e-4, atol=2e-4)
+
+
+def test_small_uploads_through_the_staging_ring_keep_their_contents(ctx, rng):
+    """Host -> device copies of up to 64 KB go through a ring of 64 pinned staging slots without waiting for the stream
+    (csrc/api.hip: gmmvi_upload): several laps around the ring, sizes up to the slot size and just above it (the synchronous
+    route), interleaved with kernels on the same stream -- every array must arrive intact."""
+    host, dev = [], []
+    sizes = [1, 7, 300, 4096, 16384, 16385, 20000, 3]            # floats: 16384 = one full slot, 16385 takes the other route
+    for i in range(300):
+        a = rng.normal(size=sizes[i % len(sizes)]).astype(np.float32)
+        host.append(a)
+        dev.append(ctx.asarray(a))
+        if i % 5 == 0:                                           # keep the stream busy between the copies
+            ops().exp_into(ctx, ctx.empty((1 << 16,)), ctx.zeros((1 << 16,)))
+    for a, d in zip(host, dev):
+        np.testing.assert_array_equal(d.numpy(), a)
