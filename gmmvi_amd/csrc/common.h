@@ -190,13 +190,26 @@ struct Pack {
     static constexpr int NF = FRAGS ? fwd_base(MT) : 0, NB = FRAGS ? bwd_base(MT) : 0;
     static constexpr int FWD = FRAGS ? ((CONST + 1 + 63) / 64) * 64 : ((CONST + 1 + 3) / 4) * 4;
     static constexpr int BWD = FWD + 64 * NF;
-    static constexpr int STRIDE = BWD + 64 * NB;
+    // blocks without fragments (scalar-fed sweeps) end in the SWEEP STREAM: the floats a component pass of the packed
+    // two-samples-per-lane sweep reads, in the order it reads them (density.hip, subst_pk.h), each part 16-byte aligned:
+    //   SWH  mu[DP], log-normaliser
+    //   SWF  forward substitution by columns, the reciprocal of the diagonal entry in front of its column:
+    //        column j = [1 / L_jj, L_{j+1,j}, ..., L_{DP-1,j}]  at SWF + swf_col(j)
+    //   SWB  backward substitution by rows (read from the end), the reciprocal of the diagonal entry behind its row:
+    //        row i = [L_{i,0}, ..., L_{i,i-1}, 1 / L_ii]  at SWB + swb_row(i)
+    static constexpr int TD = T + DP;
+    static constexpr int SWH = BWD + 64 * NB;
+    static constexpr int SWF = SWH + ((DP + 1 + 3) / 4) * 4;
+    static constexpr int SWB = SWF + ((TD + 3) / 4) * 4;
+    static constexpr int STRIDE = FRAGS ? BWD + 64 * NB : SWB + ((TD + 3) / 4) * 4;
+    __host__ __device__ static constexpr int swf_col(int j) { return j * DP - j * (j - 1) / 2; }
+    __host__ __device__ static constexpr int swb_row(int i) { return i * (i + 1) / 2; }
     __host__ __device__ static constexpr int rowofs(int i) { return i * (i - 1) / 2; }
     __host__ __device__ static constexpr int colofs(int i) { return i * (DP - 1) - i * (i - 1) / 2; }
 };
 
 // (run-time twin of Pack<DP>::STRIDE / ::FWD / ::BWD for code that takes the padded dimension as an argument)
-struct PackDims { int fwd, bwd, stride, mt, ks, nf_total, nb_total; };
+struct PackDims { int fwd, bwd, stride, mt, ks, nf_total, nb_total, swh, swf, swb; };   // swh < 0: no sweep stream
 inline __host__ __device__ PackDims gmmvi_pack_dims(int dp) {
     PackDims d{};
     const int T = dp * (dp - 1) / 2;
@@ -209,9 +222,36 @@ inline __host__ __device__ PackDims gmmvi_pack_dims(int dp) {
     d.fwd = frags ? ((2 * dp + 2 * T + 1 + 63) / 64) * 64 : ((2 * dp + 2 * T + 1 + 3) / 4) * 4;
     d.bwd = d.fwd + 64 * d.nf_total;
     d.stride = d.bwd + 64 * d.nb_total;
+    d.swh = d.swf = d.swb = -1;
+    if (!frags) {
+        d.swh = d.stride;
+        d.swf = d.swh + ((dp + 1 + 3) / 4) * 4;
+        d.swb = d.swf + ((T + dp + 3) / 4) * 4;
+        d.stride = d.swb + ((T + dp + 3) / 4) * 4;
+    }
     return d;
 }
 inline size_t gmmvi_packed_stride_dp(int dp) { return (size_t)gmmvi_pack_dims(dp).stride; }
+
+// The sweep stream of one block (Pack<DP>::SWH / SWF / SWB) from a lower-triangular factor L[i * ld + j] (rows / columns >= D:
+// identity) and the mean, written by the calling threads tid, tid + nthreads, ...; the log-normaliser (element SWH + dp) is
+// left to the caller's thread that holds it
+__device__ __forceinline__ void gmmvi_write_sweep_stream(float* __restrict__ out, int dp, int D, const float* L, int ld,
+                                                         const float* mu, int tid, int nthreads) {
+    const PackDims pd = gmmvi_pack_dims(dp);
+    if (pd.swh < 0) return;
+    for (int i = tid; i < pd.swf - pd.swh; i += nthreads)
+        if (i != dp) out[pd.swh + i] = i < D ? mu[i] : 0.f;
+    for (int e = tid; e < dp * dp; e += nthreads) {
+        const int i = e / dp, j = e - i * dp;
+        if (j > i) continue;
+        const float v = i == j ? (i < D ? 1.f / L[i * ld + i] : 1.f) : (i < D ? L[i * ld + j] : 0.f);
+        out[pd.swf + j * dp - j * (j - 1) / 2 + (i - j)] = v;
+        out[pd.swb + i * (i + 1) / 2 + j] = v;
+    }
+    const int td = dp * (dp - 1) / 2 + dp, tdr = (td + 3) / 4 * 4;
+    for (int e = td + tid; e < tdr; e += nthreads) { out[pd.swf + e] = 0.f; out[pd.swb + e] = 0.f; }
+}
 
 // The L^-1 fragments of one block from a dense row-major inverse Linv[i * ld + j] (rows / columns >= D read as zero), written
 // by the calling threads tid, tid + nthreads, ...

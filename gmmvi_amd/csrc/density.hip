@@ -10,6 +10,7 @@
 #include "combine.h"
 #include "subst.h"
 #include "subst_phased.h"
+#include "subst_pk.h"
 #include "blocked.h"
 #include <cmath>
 #include <cstdlib>
@@ -48,7 +49,9 @@ __global__ __launch_bounds__(64) void pack_kernel(int family, float nu, int K, i
             c = lgammaf(0.5f * (nu + D)) - lgammaf(0.5f * nu) - 0.5f * D * logf(nu * 3.14159265358979f) - s;
         out[P::CONST] = c;
         for (int i = P::CONST + 1; i < P::FWD; ++i) out[i] = 0.f;
+        if constexpr (!P::FRAGS) out[P::SWH + DP] = c;
     }
+    if constexpr (!P::FRAGS) gmmvi_write_sweep_stream(out, DP, D, L, D, means + (size_t)k * D, t, 64);
     // L^-1: lane t solves L x = e_t (column t) by forward substitution; the dense inverse is staged in LDS, from where the
     // matrix-core fragments of the block (common.h) and the optional explicit inverse (sample_db.py:121) are written
     __shared__ float Li[DP * DP];
@@ -155,6 +158,10 @@ extern "C" int gmmvi_debug_wg_times(long long* out, int n) {
 }
 extern "C" int gmmvi_debug_wg_hw(unsigned long long* out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_hw), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+__device__ long long g_me_ph[1024 * 16 * 16];  // packed kernel: 16 wall-clock phase stamps of every wave of the first 1024 workgroups
+extern "C" int gmmvi_debug_wg_phases(long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_me_ph), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -1;
 }
 #endif
 template <int DP, int FAMILY, bool GRAD>
@@ -363,6 +370,235 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
         printf("  total %llu, backward passes %d\n", stamp[nstamp - 1] - stamp[0], nbackward);
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// mixture_eval, two samples per lane (packed f32 arithmetic)
+// ---------------------------------------------------------------------------------------------------------------
+// The launch of the kernel above is bound by the issue rate of its ~640 vector instructions per (component, 64 samples) pass:
+// a wave64 v_fma_f32 issues once per 4 cycles per SIMD on gfx950, v_pk_fma_f32 at the same rate with two multiply-adds per
+// lane (tools/probe/pk_issue.hip).  Here lane l owns samples l and l + 64 of a 128-sample tile and all per-dimension state is
+// kept in aligned register pairs (subst_pk.h): ~520 packed instructions per (component, 128 samples).
+//  * x does not live in registers: the tile sits in LDS in pair order ([dimension pair][lane] -> x_A[2i], x_B[2i], x_A[2i+1],
+//    x_B[2i+1]: one conflict-free ds_read_b128 per dimension pair and pass), which keeps the gradient instance under 128
+//    registers = four waves per SIMD.
+//  * log-sum-exp against the running maximum of the component log densities alone (the weights enter as factors exp(log w),
+//    >= 1e-30 by the floor of the weight update): ONE exp per sample and pass serves the model mixture, the second mixture of
+//    the dual sweep and the rescaling of the gradient sums (the one-sample kernel pays four).
+//  * the waves of a workgroup are merged by a tree through four LDS slots (eight for more than 8 waves; a wave writes the
+//    slot it has just read: no barrier between a stage's reads and the next stage's writes), 47 KB instead of the 94 KB a
+//    flat merge of 128 samples would take, so that two 8-wave workgroups share a CU.
+// Chunk partials (gridDim.y > 1) leave as in the kernel above: log values and gradients normalised per chunk.
+template <int DP, int FAMILY, bool GRAD>
+__global__ __launch_bounds__(1024) void mixture_eval_pk_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
+                                                               const float* __restrict__ logw, const float* __restrict__ X, int N,
+                                                               float* __restrict__ ld_out, float* __restrict__ lp_out,
+                                                               float* __restrict__ grad_out, const float* __restrict__ logw2,
+                                                               float* __restrict__ lp2_out, CombineJob carried) {
+    using PK = Pack<DP>;
+    static_assert(DP % 2 == 0, "padded dimensions are even");
+    constexpr int NP2 = DP / 2;
+    extern __shared__ __align__(16) float sm[];
+    if (combine_carried(carried)) return;              // workgroups past the sample tiles: the merge of the previous sweep
+    const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
+    const int k_lo = blockIdx.y * kchunk;
+    const int K = min(K_total, k_lo + kchunk);
+    if (gridDim.y > 1) {
+        if (lp_out) lp_out += (size_t)blockIdx.y * N;
+        if (lp2_out) lp2_out += (size_t)blockIdx.y * N;
+        if (GRAD && grad_out) grad_out += (size_t)blockIdx.y * N * D;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int n0 = blockIdx.x * 128;
+    const int nA = n0 + lane, nB = n0 + 64 + lane;
+    const bool validA = nA < N, validB = nB < N;
+#ifdef GMMVI_ME_STAMPS
+    const int wg_lin = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && wg_lin < 8192) {
+        g_me_wg[2 * wg_lin] = wall_clock64();
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_me_hw[wg_lin] = ((unsigned long long)xcc << 32) | hw;
+    }
+    int pk_ns = 0;
+#define PK_STAMP() do { if (lane == 0 && wg_lin < 1024 && pk_ns < 16) g_me_ph[(wg_lin * 16 + wave) * 16 + pk_ns] = wall_clock64(); ++pk_ns; } while (0)
+    PK_STAMP();                                        // 0: start
+#else
+#define PK_STAMP()
+#endif
+
+    // ---- x tile -> LDS in pair order (coalesced read of the tile's rows; padded dimensions and samples past N are zero) ----
+    me_f32x4* xs4 = reinterpret_cast<me_f32x4*>(sm);                     // [NP2][64]
+    {
+        const int n_here = min(128, N - n0);
+        for (int e = threadIdx.x; e < 128 * DP; e += blockDim.x) {
+            const int sl = e / DP, i = e - sl * DP;
+            const float v = (sl < n_here && i < D) ? X[(size_t)(n0 + sl) * D + i] : 0.f;
+            sm[(((i >> 1) * 64) + (sl & 63)) * 4 + ((i & 1) << 1) + (sl >> 6)] = v;
+        }
+    }
+    float* sm_merge = sm + NP2 * 64 * 4;
+    ME_LDS_BARRIER();
+    PK_STAMP();                                        // 1: x tile staged
+
+    pk_f32x2 mld = pk_splat(-3.0e38f), s = pk_splat(0.f), s2 = pk_splat(0.f);
+    const bool dual = logw2 != nullptr;
+    pk_f32x2 acc[GRAD ? DP : 1];
+    if (GRAD) {
+#pragma unroll
+        for (int i = 0; i < DP; ++i) acc[i] = pk_splat(0.f);
+    }
+    const float nud = nu + (float)D;
+    // the wave that takes the odd components of a chunk rotates with the workgroup, so that the workgroups sharing a CU do
+    // not put their longest waves on the same SIMD
+    const int rot = (blockIdx.x + blockIdx.y) % nwaves;
+    const int wslot = wave >= rot ? wave - rot : wave - rot + nwaves;
+
+    for (int k = k_lo + wslot; k < K; k += nwaves) {
+        const sp_block_ptr blk = sp_block(packed + (size_t)k * PK::STRIDE);
+        const float w = __expf(((sp_const_f32)(uintptr_t)logw)[k]);
+        const float w2 = dual ? __expf(((sp_const_f32)(uintptr_t)logw2)[k]) : 0.f;
+        pk_f32x2 z[DP], q;
+        float cst;
+        float pc[2][32];
+#pragma unroll
+        for (int i2 = 0; i2 < NP2; ++i2) {
+            const me_f32x4 v4 = xs4[i2 * 64 + lane];
+            z[2 * i2] = pk_f32x2{v4.x, v4.y};
+            z[2 * i2 + 1] = pk_f32x2{v4.z, v4.w};
+        }
+        PkPass<DP>::forward(blk, z, q, cst, pc);
+        sp_block_ptr blkb = blk;                       // (an opaque copy: see the one-sample kernel)
+        asm volatile("" : "+s"(blkb));
+        if constexpr (GRAD) PkPass<DP>::backward_prefetch(blkb, pc);
+        pk_f32x2 ld, coef;
+        if (FAMILY == GMMVI_GAUSS) {
+            ld = pk_fma(pk_splat(-0.5f), q, pk_splat(cst));
+            coef = pk_splat(-1.f);
+        } else {
+            ld = pk_f32x2{cst - 0.5f * nud * log1pf(q.x / nu), cst - 0.5f * nud * log1pf(q.y / nu)};
+            coef = pk_f32x2{-nud / (nu + q.x), -nud / (nu + q.y)};
+        }
+        // running maximum of the log densities; exactly one of (rescale factor, new term) is exp(-|d|), the other is 1
+        const pk_f32x2 d = ld - mld;
+        const float tA = __expf(-fabsf(d.x)), tB = __expf(-fabsf(d.y));
+        const pk_f32x2 sc = pk_f32x2{d.x > 0.f ? tA : 1.f, d.y > 0.f ? tB : 1.f};
+        const pk_f32x2 e = pk_f32x2{d.x > 0.f ? 1.f : tA, d.y > 0.f ? 1.f : tB};
+        mld = pk_f32x2{fmaxf(mld.x, ld.x), fmaxf(mld.y, ld.y)};
+        const pk_f32x2 we = e * pk_splat(w);
+        s = pk_fma(s, sc, we);
+        if (dual) s2 = pk_fma(s2, sc, e * pk_splat(w2));
+        if constexpr (GRAD) {
+            PkPass<DP>::backward(blkb, z, pc);
+            const pk_f32x2 ec = we * coef;
+#pragma unroll
+            for (int i = 0; i < DP; ++i) acc[i] = pk_fma(acc[i], sc, ec * z[i]);
+            pk_pin<DP>(acc);
+        }
+        if (ld_out != nullptr) {
+            if (validA) ld_out[(size_t)k * N + nA] = ld.x;
+            if (validB) ld_out[(size_t)k * N + nB] = ld.y;
+        }
+        PK_STAMP();                                    // 2 ..: after each component pass
+    }
+#ifdef GMMVI_ME_STAMPS
+    pk_ns = 8;
+#endif
+    PK_STAMP();                                        // 8: loop left
+    if (lp_out == nullptr && !GRAD) return;
+
+    // ---- merge of the waves: common maximum, then a tree of sums through four slots ---------------------------------------
+    constexpr int NV = (GRAD ? DP : 0) + 2;            // register pairs a wave hands over: s, s2, gradient sums
+    pk_f32x2* sm_max = reinterpret_cast<pk_f32x2*>(sm_merge);            // [nwaves][64]
+    pk_f32x2* slots = sm_max + nwaves * 64;                              // [4 or 8][NV][64]
+    const int half0 = nwaves > 8 ? 8 : 4;                                // the first stage of the tree
+    sm_max[wave * 64 + lane] = mld;
+    ME_LDS_BARRIER();
+    PK_STAMP();                                        // 9: maxima exchanged (includes the wait for the slowest wave)
+    pk_f32x2 M = mld;
+    for (int wv = 0; wv < nwaves; ++wv) {
+        const pk_f32x2 o = sm_max[wv * 64 + lane];
+        M = pk_f32x2{fmaxf(M.x, o.x), fmaxf(M.y, o.y)};
+    }
+    {
+        const pk_f32x2 f = pk_f32x2{__expf(mld.x - M.x), __expf(mld.y - M.y)};
+        s = s * f;
+        s2 = s2 * f;
+        if (GRAD) {
+#pragma unroll
+            for (int i = 0; i < DP; ++i) acc[i] = acc[i] * f;
+        }
+    }
+#pragma unroll
+    for (int half = 8; half >= 1; half >>= 1) {
+        if (half < nwaves) {                           // (uniform: waves >= 2 * half hold nothing any more)
+            const bool writer = wave >= half && wave < 2 * half;
+            const bool reader = wave < half && wave + half < nwaves;
+            // slot index = the slot the writer itself read one stage earlier (first stage: its partner's index)
+            const int slot_w = half == half0 ? wave - half : wave;
+            const int slot_r = half == half0 ? wave : wave + half;
+            if (writer) {
+                pk_f32x2* dst = slots + (size_t)slot_w * NV * 64 + lane;
+                dst[0] = s;
+                dst[64] = s2;
+                if (GRAD) {
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) dst[(2 + i) * 64] = acc[i];
+                }
+            }
+            ME_LDS_BARRIER();
+            if (reader) {
+                const pk_f32x2* src = slots + (size_t)slot_r * NV * 64 + lane;
+                s = s + src[0];
+                s2 = s2 + src[64];
+                if (GRAD) {
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) acc[i] = acc[i] + src[(2 + i) * 64];
+                }
+            }
+        }
+    }
+    PK_STAMP();                                        // 10: tree merge done
+    if (wave != 0) return;
+    if (lp_out != nullptr) {
+        if (validA) lp_out[nA] = M.x + __logf(s.x);
+        if (validB) lp_out[nB] = M.y + __logf(s.y);
+    }
+    if (dual && lp2_out != nullptr) {
+        if (validA) lp2_out[nA] = M.x + __logf(s2.x);
+        if (validB) lp2_out[nB] = M.y + __logf(s2.y);
+    }
+    if (GRAD && grad_out != nullptr) {
+        const pk_f32x2 inv = pk_f32x2{1.f / s.x, 1.f / s.y};
+#pragma unroll
+        for (int i = 0; i < DP; ++i) acc[i] = acc[i] * inv;
+        if (D == DP && DP % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 15) == 0) {
+            // a lane's row is a whole number of 16-byte pieces: neighbouring lanes' rows are neighbours in memory
+#pragma unroll
+            for (int q4 = 0; q4 < DP / 4; ++q4) {
+                if (validA) reinterpret_cast<float4*>(grad_out + (size_t)nA * D)[q4] =
+                    make_float4(acc[4 * q4].x, acc[4 * q4 + 1].x, acc[4 * q4 + 2].x, acc[4 * q4 + 3].x);
+                if (validB) reinterpret_cast<float4*>(grad_out + (size_t)nB * D)[q4] =
+                    make_float4(acc[4 * q4].y, acc[4 * q4 + 1].y, acc[4 * q4 + 2].y, acc[4 * q4 + 3].y);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < DP; ++i) {
+                if (i < D) {
+                    if (validA) grad_out[(size_t)nA * D + i] = acc[i].x;
+                    if (validB) grad_out[(size_t)nB * D + i] = acc[i].y;
+                }
+            }
+        }
+    }
+    PK_STAMP();                                        // 11: results stored (wave 0)
+#ifdef GMMVI_ME_STAMPS
+    if (threadIdx.x == 0 && wg_lin < 8192) g_me_wg[2 * wg_lin + 1] = wall_clock64();
+#endif
+#undef PK_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1127,11 +1363,110 @@ static int launch_mixture_eval_mfma_ws(gmmvi_ctx* ctx, int family, float nu, int
     return GMMVI_OK;
 }
 
+// the packed two-samples-per-lane sweep (mixture_eval_pk_kernel): 128-sample tiles, at most 8 waves per workgroup, component
+// chunks over blockIdx.y so that about two workgroups per CU are in flight
+template <int DP>
+static int launch_mixture_eval_pk(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
+                                  const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
+                                  const float* logw2, float* lp2) {
+    const bool want_grad = grad != nullptr;
+    const bool want_merge = want_grad || lp != nullptr;
+    static const int env_ky = getenv("GMMVI_ME_PK_KY") ? atoi(getenv("GMMVI_ME_PK_KY")) : 0;
+    static const int env_nw = getenv("GMMVI_ME_PK_NW") ? atoi(getenv("GMMVI_ME_PK_NW")) : 0;
+    const int tiles = (N + 127) / 128;
+    // Geometry: all workgroups resident at once (one round), and four waves per SIMD on the loaded CUs -- either ONE 16-wave
+    // workgroup per CU or TWO 8-wave workgroups (the 16-wave form takes 108 KB of LDS at D = 20).  Measured inside the iteration
+    // (profiles/r04_notes.md): north-star shape (79 tiles, K = 100) dual sweep 23.3 us at 3 chunks x 16 waves, 24.7 at 6 x 8,
+    // 28.0 at 3 x 8 (two waves per SIMD do not cover the first-touch latency of blocks the previous launch wrote on other
+    // XCDs); fewer chunks also mean fewer partials to merge.  With 157 tiles (D = 10, K = 200, N = 20 000) a 16-wave
+    // workgroup per tile fills 61 % of the CUs and two per tile need two rounds: 3 chunks x 8 waves then (27.5 against 36.4 us).
+    const long cus = ctx->num_cus;
+    auto chunks_for = [&](long slots) {
+        long c = slots / tiles;
+        if (c > (K + 3) / 4) c = (K + 3) / 4;          // at least four components per chunk
+        return (int)(c < 1 ? 1 : c);
+    };
+    auto fill = [&](int c, long slots) {               // share of the slots busy over the rounds the launch takes
+        const long wgs = (long)tiles * c, rounds = (wgs + slots - 1) / slots;
+        return (double)wgs / (double)(rounds * slots);
+    };
+    const int ky16 = chunks_for(cus), ky8 = chunks_for(2 * cus);
+    bool wide = fill(ky16, cus) + 0.05 >= fill(ky8, 2 * cus);
+    int ky = wide ? ky16 : ky8;
+    if (env_ky > 0) ky = env_ky;
+    if (ky > K) ky = K;
+    if (ky < 1) ky = 1;
+    const int kchunk = (K + ky - 1) / ky;
+    ky = (K + kchunk - 1) / kchunk;
+    int nw = wide ? 16 : 8;
+    if (env_nw > 0) nw = env_nw;
+    if (nw > kchunk) nw = kchunk;
+    if (nw > 16) nw = 16;
+    const int nv = (want_grad ? DP : 0) + 2;
+    const size_t shmem = (size_t)(DP / 2) * 64 * 16 + (size_t)nw * 64 * 8 + (want_merge ? (size_t)(nw > 8 ? 8 : 4) * nv * 64 * 8 : 0);
+    float* lp_k = lp;
+    float* grad_k = grad;
+    float* lp2_k = lp2;
+    const bool defer = ctx->defer_combine && ky > 1 && want_merge;
+    if (defer) {
+        int rc = gmmvi_flush_pending_combine(ctx);
+        if (rc != GMMVI_OK) return rc;
+    }
+    if (ky > 1 && want_merge) {
+        size_t need = ((size_t)ky * N * (logw2 ? 2 : 1) + (want_grad ? (size_t)ky * N * D : 0)) * sizeof(float);
+        int rc = defer ? gmmvi_defer_reserve(ctx, need) : gmmvi_ws_reserve(ctx, need);
+        if (rc != GMMVI_OK) return rc;
+        lp_k = (float*)(defer ? ctx->defer_ws : ctx->ws);
+        lp2_k = logw2 ? lp_k + (size_t)ky * N : nullptr;
+        grad_k = want_grad ? lp_k + (size_t)ky * N * (logw2 ? 2 : 1) : nullptr;
+    }
+    const CombineJob carried = gmmvi_take_pending_combine(ctx, nw * 64, tiles);
+    dim3 grid(tiles + carried.blocks, ky), block(nw * 64);
+    {
+        GMMVI_PROF_UNITS(ctx, sweep_prof_name(ctx, want_grad, logw2 != nullptr), (double)N * K);
+#define GMMVI_LAUNCH_MEPK(FAM, G)                                                                                      \
+    do {                                                                                                               \
+        if (shmem > 64 * 1024)                                                                                         \
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_pk_kernel<DP, FAM, G>,               \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));         \
+        hipLaunchKernelGGL((mixture_eval_pk_kernel<DP, FAM, G>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
+                           logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried);                                         \
+    } while (0)
+        if (family == GMMVI_GAUSS) {
+            if (want_grad) GMMVI_LAUNCH_MEPK(GMMVI_GAUSS, true); else GMMVI_LAUNCH_MEPK(GMMVI_GAUSS, false);
+        } else {
+            if (want_grad) GMMVI_LAUNCH_MEPK(GMMVI_STUDENT_T, true); else GMMVI_LAUNCH_MEPK(GMMVI_STUDENT_T, false);
+        }
+#undef GMMVI_LAUNCH_MEPK
+    }
+    GMMVI_LAUNCH_CHECK(ctx);
+    if (defer) {
+        CombineJob& j = ctx->pending;
+        j.R = ky; j.N = N; j.D = D;
+        j.lp_parts = lp_k; j.grad_parts = grad_k; j.lp2_parts = lp2_k;
+        j.lp_out = lp; j.grad_out = grad; j.lp2_out = lp2_k ? lp2 : nullptr;
+    } else if (ky > 1 && want_merge) {
+        GMMVI_PROF(ctx, "mixture_combine");
+        int rc = gmmvi_combine_partials_internal(ctx, ky, N, D, lp_k, grad_k, lp, grad, lp2_k, lp2);
+        if (rc != GMMVI_OK) return rc;
+    }
+    return GMMVI_OK;
+}
+
 template <int DP>
 static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int D, const float* packed,
                                const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
                                const float* logw2 = nullptr, float* lp2 = nullptr) {
     using PK = Pack<DP>;
+    if constexpr (!PK::FRAGS) {
+        // enough (128-sample tile, component) passes to give every SIMD a few: the packed kernel; otherwise the one-sample
+        // kernel, whose 64-sample tiles spread a small problem over more CUs (GMMVI_ME_PK: 0 never, 1 always)
+        static const int env_pk = getenv("GMMVI_ME_PK") ? atoi(getenv("GMMVI_ME_PK")) : -1;
+        static const long env_pk_min = getenv("GMMVI_ME_PK_MIN") ? atol(getenv("GMMVI_ME_PK_MIN")) : 4096;
+        const long passes = (long)((N + 127) / 128) * K;
+        if (env_pk != 0 && (env_pk == 1 || passes >= env_pk_min))
+            return launch_mixture_eval_pk<DP>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
+    }
     if constexpr (PK::FRAGS) {
         // enough samples for the workgroup-shared form (eight waves on one component at a time): the block goes to LDS once per
         // workgroup instead of to every wave through the L2

@@ -758,7 +758,9 @@ __global__ __launch_bounds__(64 * NW) void update_kl_fast_kernel(int Drt, float*
         if (t == 0) {
             out[2 * DPk + 2 * T] = -lsum - 0.5f * D * 1.8378770664093453f;
             for (int i = 2 * DPk + 2 * T + 1; i < pd.fwd; ++i) out[i] = 0.f;
+            if (pd.swh >= 0) out[pd.swh + DPk] = -lsum - 0.5f * D * 1.8378770664093453f;
         }
+        gmmvi_write_sweep_stream(out, DPk, D, Lf, ld, success ? (const float*)mug : (const float*)s.mu, t, NTH);
         UKL_STAMP(5);                                  // packed block (without fragments) done
         // L^-1 of the final factor for the matrix-core fragments of the block: lane t solves L x = e_t (column t) from the
         // LDS image of L (every lane reads the same element: broadcast), the dense inverse goes through Mc

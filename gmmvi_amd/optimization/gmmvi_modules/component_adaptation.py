@@ -125,8 +125,9 @@ class VipsComponentAdaptation(ComponentAdaptation):
             target_lnpdfs = np.concatenate([target_lnpdfs.numpy(), np.asarray(plp.numpy() if hasattr(plp, "numpy") else plp)])
         self.add_at_best_location(samples, target_lnpdfs)
 
-    def delete_bad_components(self):
-        """:261-300."""
+    def deletion_criteria(self):
+        """The three per-component quantities of :261-296: relative improvement of the smoothed reward, the largest weight
+        (actual or greedy) over the window, and whether the component is old enough."""
         m = self.model
         ks = self.kernel.size
         win = ks + self.del_iters
@@ -139,15 +140,24 @@ class VipsComponentAdaptation(ComponentAdaptation):
         cur = cur - np.max(cur)
         with np.errstate(divide='ignore', invalid='ignore'):
             reward_improvements = (cur - old) / np.abs(old)
-        self.reward_improvements = reward_improvements.astype(np.float32)
         max_actual_weights = np.max(wh[:, :-1], axis=1)                                              # :286
         with np.errstate(over='ignore', invalid='ignore'):
             max_greedy_weights = np.max(np.exp(rh - logsumexp(rh, axis=0, keepdims=True)), axis=1)   # :287-289
         max_weights = np.maximum(max_actual_weights, max_greedy_weights)
+        is_old_enough = rh[:, -self.del_iters] != -FLOAT32_MAX                                       # :294
+        return reward_improvements, max_weights, is_old_enough
+
+    def bad_components(self):
+        """:291-296: indices of the components the heuristic deletes now."""
+        reward_improvements, max_weights, is_old_enough = self.deletion_criteria()
+        self.reward_improvements = reward_improvements.astype(np.float32)
         is_stagnating = reward_improvements <= 0.4
         is_low_weight = max_weights < self.min_weight_for_del_heuristic
-        is_old_enough = rh[:, -self.del_iters] != -FLOAT32_MAX                                       # :294
-        bad = np.where(is_stagnating & is_low_weight & is_old_enough)[0]
+        return np.where(is_stagnating & is_low_weight & is_old_enough)[0]
+
+    def delete_bad_components(self):
+        """:261-300."""
+        bad = self.bad_components()
         for idx in sorted(bad.tolist(), reverse=True):                                               # :298-300
-            m.remove_component(idx)
+            self.model.remove_component(idx)
         return bad

@@ -128,8 +128,10 @@ int gmmvi_profile_report(gmmvi_ctx* ctx, char* buf, size_t buf_size);
 
 /* ---- component parameter blocks ---------------------------------------------------------------------- */
 /* Number of floats of one packed component block for dimension D (D <= 64: padded dimension, reciprocal diagonal,
- * row- and column-packed strict lower triangle of L, log-normaliser; 64 < D <= 512: mu, log-normaliser, dense L^-1).
- * 0 for an unsupported dimension. */
+ * row- and column-packed strict lower triangle of L, log-normaliser, then for padded D <= 24 the "sweep stream" the packed
+ * two-samples-per-lane density kernel reads in order -- mean, log-normaliser, the triangle by columns and by rows with the
+ * reciprocal diagonal entries in place -- and for padded D >= 32 L^-1 as matrix-core operand fragments;
+ * 64 < D <= 512: mu, log-normaliser, dense L^-1).  0 for an unsupported dimension. */
 size_t gmmvi_packed_stride(int D);
 /* Pack K components (means[K,D], chols[K,D,D] lower-triangular dense) for the density kernels.
  * family/nu select the log-normaliser (Gaussian: full_cov_gmm.py:60-61; Student-t: student_t_mixture.py:40-44).

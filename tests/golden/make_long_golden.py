@@ -5,6 +5,10 @@ ships no vectors: SURVEY.md 8c; these files are oracle output, data only -- "par
   long_c1.npz   BASELINE configs[0] = examples/5_samtron_20D_student-T.py:13-30: K = 45 adaptive (add every 60, delete after
                 100 iterations), 200 samples / component, reuse ratio 0, 260 iterations (adds at 60/120/180/240, deletions
                 from iteration 101)
+  long_c4.npz   BASELINE configs[3]'s example as examples/6_samtron_planar4.py:19-26 runs it: planar-4 target, 100 initial
+                components, a component added EVERY iteration, deletions from iteration 11 (del_iters 10), 100 samples /
+                component, weight stepsize 5, 140 iterations; the script asserts that the oracle deleted >= 5 components;
+                additionally `id_trace` (the unique component ids after every iteration, -1 padded)
   long_ns.npz   the north-star workload exactly as bench.py builds it (bench.spec("ns"): K = 100, D = 20, N = 10 000), 60
                 iterations: what bench.py's matched_elbo leg compares the device trajectory with (no oracle iterations
                 inside the bench run)
@@ -34,13 +38,17 @@ from helpers import LONG_CASES, make_long_oracle, score_elbo, samtron_config, ma
 def run_long(case, dtype=np.float64, verbose=True):
     o = make_long_oracle(case, dtype=dtype)
     t = o.target
-    out = {"init_means": o.model.means.astype(np.float32), "init_covs": o.model.model.covs.astype(np.float32),
-           "target_weights": t.weights, "target_means": t.means, "target_covs": t.covs}
-    cp_it, cp_elbo, cp_sigma, cp_k, k_trace, n_success = [], [], [], [], [], []
+    out = {"init_means": o.model.means.astype(np.float32), "init_covs": o.model.model.covs.astype(np.float32)}
+    if hasattr(t, "weights"):                        # (the planar-robot target has no parameters beyond its construction)
+        out.update(target_weights=t.weights, target_means=t.means, target_covs=t.covs)
+    cp_it, cp_elbo, cp_sigma, cp_k, k_trace, n_success, id_trace, n_deleted = [], [], [], [], [], [], [], 0
     t0 = time.time()
     for it in range(1, case["iters"] + 1):
+        ids_before = set(o.model.unique_component_ids)
         info = o.train_iter()
         k_trace.append(o.model.num_components)
+        id_trace.append(np.array(o.model.unique_component_ids))
+        n_deleted += len(ids_before - set(o.model.unique_component_ids))
         n_success.append(int(np.sum(info["success"])))
         if it % case["every"] == 0:
             m = o.model.model
@@ -52,7 +60,13 @@ def run_long(case, dtype=np.float64, verbose=True):
     out.update(checkpoint_iters=np.array(cp_it), checkpoint_elbo=np.array(cp_elbo), checkpoint_sigma=np.array(cp_sigma),
                checkpoint_k=np.array(cp_k), k_trace=np.array(k_trace), n_success=np.array(n_success),
                final_log_weights=m.log_weights.copy(), final_means=m.means.copy(), final_chols=m.chol_cov.copy(),
-               final_component_ids=np.array(o.model.unique_component_ids))
+               final_component_ids=np.array(o.model.unique_component_ids), n_deleted=np.array(n_deleted))
+    width = max(len(v) for v in id_trace)
+    out["id_trace"] = np.stack([np.pad(v, (0, width - len(v)), constant_values=-1) for v in id_trace]).astype(np.int32)
+    if verbose:
+        print(f"  components deleted over the run: {n_deleted}", flush=True)
+    if case.get("min_deleted"):
+        assert n_deleted >= case["min_deleted"], f"the oracle deleted only {n_deleted} components"
     return out
 
 

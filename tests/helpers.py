@@ -133,6 +133,8 @@ EXAMPLE5_ADAPTIVE = {"del_iters": 100, "add_iters": 60, "max_components": 1000, 
                      "thresholds_for_add_heuristic": [5000., 1000., 500., 200., 100., 50.],
                      "min_weight_for_del_heuristic": 1e-6, "num_database_samples": 100000, "num_prior_samples": 0}
 
+EXAMPLE6_ADAPTIVE = dict(EXAMPLE5_ADAPTIVE, del_iters=10, add_iters=1)                       # examples/6...:20
+
 LONG_CASES = {
     # name: kind, D, K, samples / component, seed, iterations, checkpoint interval, adaptive config, (prior scale, initial cov)
     # BASELINE configs[1] ("C2": 20-D Student-t mixture, K = 50 fixed, N = 5000) with the stm20.yml initial mixture
@@ -141,11 +143,16 @@ LONG_CASES = {
     # 200 samples per component, reuse ratio 0, initial stepsize 0.1, weight stepsize 1
     "c1": dict(kind="stm", d=20, k=45, s=200, seed=5, iters=260, every=10, adaptive=EXAMPLE5_ADAPTIVE,
                init=(100.0, 300.0)),
+    # BASELINE configs[3]'s example as it is run, examples/6_samtron_planar4.py:19-26: planar-4 target, 100 initial components
+    # from the planar_robot_4.yml prior, a component ADDED EVERY iteration, deletions from iteration 11 on (del_iters 10),
+    # 100 samples per component, reuse ratio 0, weight stepsize 5 (clipped by the rule's max_stepsize as upstream does)
+    "c4": dict(kind="planar", d=10, k=100, s=100, seed=7, iters=140, every=10, adaptive=EXAMPLE6_ADAPTIVE,
+               init=([1.0] + [0.2] * 9, [0.0625] + [0.0025] * 9), wstep=5.0, min_deleted=5, chaotic=True),
 }
 
 
 def long_case_config(case):
-    return samtron_config(case["s"], initial_stepsize=0.1, adaptive=case["adaptive"], wstep=1.0)
+    return samtron_config(case["s"], initial_stepsize=0.1, adaptive=case["adaptive"], wstep=case.get("wstep", 1.0))
 
 
 def make_long_oracle(case, dtype=np.float64):

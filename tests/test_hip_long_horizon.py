@@ -20,44 +20,132 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+# The examples/6 regime (planar-4 target, likelihood std 0.01: log-density curvature ~1e4) is CHAOTIC at the component level:
+# tools/debug_newcomp.py shows the fp32 device and the fp64 oracle separating by a factor ~4 per iteration in the parameters of
+# components that sit on the steep flanks (1e-7 -> 1e-2 within ten iterations; the same holds between any two fp32
+# implementations).  Deletions act on exactly those low-weight components, so "the same ids after every iteration" can only be
+# demanded while the trajectories are still correlated.  What the test demands instead:
+#   (A) at EVERY iteration the device's deletion decision equals the oracle's decision rule (oracle/adaptation.py, the line-cited
+#       restatement of component_adaptation.py:261-300) evaluated on the device's OWN reward / weight histories -- exact;
+#   (B) K and the unique component ids equal the fixture's after every one of the first LOCKSTEP_ITERS iterations (the fixture
+#       deletes components from iteration 11 on, several before that horizon);
+#   (C) over the whole run: ELBO at every 10th iteration within the tolerance below, |K - K_oracle| <= K_BAND at every
+#       iteration, the number of deleted components within a factor two of the oracle's.
+LOCKSTEP_ITERS = 40
+K_BAND = 10
+
+
+class _HistoryStub:
+    def __init__(self, rh, wh):
+        self.reward_history, self.weight_history, self.removed = rh, wh, []
+
+    def remove_component(self, idx):
+        self.removed.append(int(idx))
+
+
+def _check_deletion_rule(g, state):
+    """(A): wrap the device's decision and compare it with the oracle's rule on the same histories."""
+    from oracle.adaptation import VipsComponentAdaptation as OracleRule
+    ad = g.num_component_adapter
+    own_rule = ad.bad_components
+
+    def bad_components():
+        own = own_rule()
+        win = ad.kernel.size + ad.del_iters
+        rule = object.__new__(OracleRule)
+        rule.model = _HistoryStub(g.model.reward_window(win).astype(np.float64), g.model.weight_window(win).astype(np.float64))
+        rule.kernel, rule.del_iters = ad.kernel.astype(np.float64), ad.del_iters
+        rule.min_weight_for_del_heuristic = ad.min_weight_for_del_heuristic
+        rule.delete_bad_components()
+        assert sorted(int(i) for i in own) == sorted(rule.model.removed), \
+            f"iteration {state['it']}: device deletes {sorted(own)}, the reference rule on the same histories {sorted(rule.model.removed)}"
+        state["deleted"] += len(own)
+        state["checked"] += 1
+        return own
+
+    ad.bad_components = bad_components
+
+
 def _run_long(name, modular):
     case = LONG_CASES[name]
     fx = np.load(os.path.join(GOLDEN, f"long_{name}.npz"))
     o = make_long_oracle(case)                      # construction only: target, initial mixture (never iterated here)
     # the fixture's inputs are what this test feeds the device
     np.testing.assert_array_equal(o.model.means.astype(np.float32), fx["init_means"])
-    np.testing.assert_allclose(o.target.means, fx["target_means"])
+    if "target_means" in fx:
+        np.testing.assert_allclose(o.target.means, fx["target_means"])
     g = make_long_device(case, o)
     if modular:
         g.ng_based_updater.want_info = True         # makes the single-call path step aside
     else:
         assert g._fast_path.eligible(), "expected the single-call iteration for this configuration"
     cps = {int(i): j for j, i in enumerate(fx["checkpoint_iters"])}
-    worst = 0.0
+    chaotic = bool(case.get("chaotic"))             # examples/6 regime: see the comment above
+    state = {"it": 0, "deleted": 0, "checked": 0}
+    if case["adaptive"]:
+        _check_deletion_rule(g, state)
+    worst, k_dev_max, in_lockstep = 0.0, 0, True
     for it in range(1, case["iters"] + 1):
+        state["it"] = it
         g.train_iter()
-        assert g.model.num_components == int(fx["k_trace"][it - 1]), \
-            f"iteration {it}: K = {g.model.num_components}, oracle {int(fx['k_trace'][it - 1])}"
+        k_fx = int(fx["k_trace"][it - 1])
+        if not chaotic or it <= LOCKSTEP_ITERS:
+            assert g.model.num_components == k_fx, f"iteration {it}: K = {g.model.num_components}, oracle {k_fx}"
+            if "id_trace" in fx:                     # WHICH components were added / deleted, not only how many
+                ids = fx["id_trace"][it - 1]
+                np.testing.assert_array_equal(g.model.unique_component_ids, ids[ids >= 0], err_msg=f"iteration {it}")
+        else:
+            k_dev_max = max(k_dev_max, abs(g.model.num_components - k_fx))
+            assert abs(g.model.num_components - k_fx) <= K_BAND, f"iteration {it}: K = {g.model.num_components}, oracle {k_fx}"
+            if in_lockstep and "id_trace" in fx:
+                ids = fx["id_trace"][it - 1]
+                in_lockstep = np.array_equal(g.model.unique_component_ids, ids[ids >= 0])
+                if not in_lockstep:
+                    print(f"long_{name}: component ids equal the oracle's through iteration {it - 1}")
         if it in cps:
             j = cps[it]
             e, _ = score_elbo(o.target, g.model.log_weights.numpy(), g.model.means.numpy(), g.model.chol_cov.numpy())
-            tol = 3.0 * float(fx["checkpoint_sigma"][j]) + 1e-2
+            # decorrelated trajectories differ by the run-to-run spread of the algorithm itself, not by rounding: 0.15 nats
+            # (the oracle's ELBO moves by 1.0 nat over the last 60 iterations of this fixture)
+            tol = 3.0 * float(fx["checkpoint_sigma"][j]) + (0.15 if chaotic and it > LOCKSTEP_ITERS else 1e-2)
             dev = abs(e - float(fx["checkpoint_elbo"][j]))
             worst = max(worst, dev / tol)
             assert dev <= tol, f"iteration {it}: ELBO {e:.4f} vs oracle {float(fx['checkpoint_elbo'][j]):.4f} (tol {tol:.4f})"
+    if case["adaptive"]:
+        assert state["checked"] >= case["iters"] - case["adaptive"]["del_iters"] - 1
+    if chaotic:
+        n_fx = int(fx["n_deleted"])
+        assert n_fx // 2 <= state["deleted"] <= 2 * n_fx, (state["deleted"], n_fx)
+        print(f"long_{name} ({'modular' if modular else 'single-call'}): worst |dELBO|/tol {worst:.3f}, deleted {state['deleted']} "
+              f"(oracle {n_fx}), max |K - K_oracle| {k_dev_max}, ids in lock-step to the end: {in_lockstep}")
+        if not in_lockstep:
+            return
     np.testing.assert_array_equal(g.model.unique_component_ids, fx["final_component_ids"])
     w_dev = np.abs(np.exp(g.model.log_weights.numpy()) - np.exp(fx["final_log_weights"])).max()
     m_dev = np.abs(g.model.means.numpy() - fx["final_means"]).max() / np.abs(fx["final_means"]).max()
     c_dev = np.abs(g.model.chol_cov.numpy() - fx["final_chols"]).max() / np.abs(fx["final_chols"]).max()
     print(f"long_{name} ({'modular' if modular else 'single-call'}): worst |dELBO|/tol {worst:.3f}, final weights {w_dev:.2e}, "
           f"means {m_dev:.2e}, chols {c_dev:.2e}")
-    assert w_dev <= 2e-3 and m_dev <= 2e-2 and c_dev <= 2e-2, (w_dev, m_dev, c_dev)
+    if not chaotic:
+        assert w_dev <= 2e-3 and m_dev <= 2e-2 and c_dev <= 2e-2, (w_dev, m_dev, c_dev)
 
 
 @pytest.mark.parametrize("modular", [False, True], ids=["single_call", "modular"])
 def test_long_horizon_c2(modular):
     """BASELINE configs[1]: 20-D Student-t mixture, K = 50 fixed, N = 5000 samples / iteration, 120 iterations."""
     _run_long("c2", modular)
+
+
+@pytest.mark.parametrize("modular", [False, True], ids=["single_call", "modular"])
+def test_long_horizon_c4_example6(modular):
+    """BASELINE configs[3] as its example runs it, examples/6_samtron_planar4.py:19-26: planar-4 target, 100 initial
+    components, a component ADDED EVERY iteration and the deletion heuristic active from iteration 11
+    (component_adaptation.py:186-190, :261-300; the fixture's oracle run deletes >= 5 components), 100 samples per component,
+    weight stepsize 5, 140 iterations.  The deletion rule is checked at every iteration on the device's own histories, K and
+    the unique component ids against the fixture in lock-step for the first 40 iterations, then statistically (see above)."""
+    fx = np.load(os.path.join(GOLDEN, "long_c4.npz"))
+    assert int(fx["n_deleted"]) >= 5
+    _run_long("c4", modular)
 
 
 @pytest.mark.parametrize("modular", [False, True], ids=["single_call", "modular"])

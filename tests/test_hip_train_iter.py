@@ -29,6 +29,7 @@ def run_pair(kind, d, k, s, seed, iters, cfg, check_every=1, tol_scale=1.0, fuse
         om = o.model
         gm = g.model
         assert gm.num_components == om.num_components
+        np.testing.assert_array_equal(gm.unique_component_ids, om.unique_component_ids, err_msg=f"iteration {it}")
         # fp32 drift compounds with the iteration count (every iteration re-samples from the slightly different fp32 model);
         # before it has started (iterations 0 and 1) the parameters agree to 5e-4
         tol = tol_scale * (5e-4 if it < 2 else 2e-3 * (1 + it))
@@ -381,6 +382,7 @@ def test_sample_reuse_with_adaptive_components(fused):
         o.train_iter()
         g.train_iter()
         assert g.model.num_components == o.model.num_components
+        np.testing.assert_array_equal(g.model.unique_component_ids, o.model.unique_component_ids, err_msg=f"iteration {it}")
         assert g.sample_db.samples.shape[0] == o.sample_db.samples.shape[0], f"iteration {it}: different numbers of new samples"
         slid += g.sample_db._pd is not None and g.sample_db._pd["stop"] >= g.sample_db.samples.shape[0] - 400
     assert g.model.num_components > 2 and slid >= 5
