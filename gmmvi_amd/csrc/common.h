@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include "../../include/gmmvi_hip.h"
+#include "iter_prep.h"
 
 // a merge of component-chunk partials (combine.h) that has not been launched yet: the single-call iteration lets the next
 // launch carry it (density.hip defers, the target / expected-log-ratio launches take it)
@@ -20,6 +21,26 @@ struct CombineJob {
     float* grad_out = nullptr;
     float* lp2_out = nullptr;
 };
+
+// work that rides as extra workgroups in a density launch of the single-call iteration (riders.h)
+struct SampleJob {
+    int K = 0, D = 0, uniform_count = 0;
+    const float* means = nullptr; const float* chols = nullptr; const int32_t* offsets = nullptr;
+    unsigned long long seed = 0, first_index = 0;
+    float* X = nullptr; int32_t* mapping = nullptr; int32_t mapping_base = 0;
+};
+
+struct Riders {
+    int first_block = 0;          // the carrying launch's own workgroups and its carried merge end here
+    int prep_blocks = 0;          // workgroups first_block .. : iter_prep_block
+    int sample_blocks = 0;        // then: sample_block, workgroup i = (component i % K, 256-sample chunk i / K)
+    PrepArgs prep;
+    SampleJob sample;
+};
+
+inline size_t riders_lds_bytes(const Riders& r) {
+    return r.sample_blocks > 0 ? ((size_t)r.sample.D * r.sample.D + r.sample.D + 256 * (size_t)(r.sample.D | 1)) * sizeof(float) : 0;
+}
 
 struct gmmvi_ctx {
     int device = 0;
@@ -42,6 +63,7 @@ struct gmmvi_ctx {
     size_t bimg_bytes = 0;
     bool defer_combine = false;  // set by fused.hip around a sweep whose merge the next launch carries
     CombineJob pending;          // R > 0: partials in defer_ws wait for their merge
+    Riders riders;               // prep_blocks / sample_blocks > 0: riders wait for the next density launch (riders.h)
     void* defer_ws = nullptr;    // partials of a deferred merge (ctx->ws is reused by the launches in between)
     size_t defer_bytes = 0;
     void* comm = nullptr;        // ncclComm_t
@@ -101,7 +123,6 @@ int gmmvi_sample_components_bounded(gmmvi_ctx* ctx, int K, int D, const float* m
                                     const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed,
                                     uint64_t first_index, int stream_id, const float* eps_dev, float* X_out_dev,
                                     int32_t* mapping_out_dev);
-struct PrepArgs;
 int gmmvi_sample_components_prep(gmmvi_ctx* ctx, int K, int D, const float* means_dev, const float* chols_dev,
                                  const int32_t* offsets_dev, int N, int max_per_component, uint64_t seed, uint64_t first_index,
                                  float* X_out_dev, int32_t* mapping_out_dev, int32_t mapping_base, const PrepArgs& prep);
@@ -114,6 +135,10 @@ int gmmvi_combine_partials_internal(gmmvi_ctx* ctx, int R, int N, int D, const f
 int gmmvi_defer_reserve(gmmvi_ctx* ctx, size_t nbytes);
 int gmmvi_flush_pending_combine(gmmvi_ctx* ctx);
 CombineJob gmmvi_take_pending_combine(gmmvi_ctx* ctx, int threads, int first_block, bool light = false);
+// comm.hip: riders.  take: hand the pending riders to a density launch whose own and merge workgroups end at `first_block`;
+// flush: launch pending riders on their own (nothing took them)
+Riders gmmvi_take_pending_riders(gmmvi_ctx* ctx, int first_block, int threads, bool prep_only = false);
+int gmmvi_flush_pending_riders(gmmvi_ctx* ctx);
 // stein.hip / update_kl.hip: the Stein estimate split at the partial slab (single-call iteration, fused.hip)
 struct SteinSlab;
 int gmmvi_stein_partials(gmmvi_ctx* ctx, int K, int D, const float* packed_dev, const float* X_dev, int N, const float* ld_dev,

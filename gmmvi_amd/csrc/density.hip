@@ -8,6 +8,7 @@
 // through LDS.
 #include "common.h"
 #include "combine.h"
+#include "riders.h"
 #include "subst.h"
 #include "subst_phased.h"
 #include "subst_pk.h"
@@ -169,10 +170,10 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
                                                             const float* __restrict__ logw, const float* __restrict__ X,
                                                             int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
                                                             float* __restrict__ grad_out, const float* __restrict__ logw2,
-                                                            float* __restrict__ lp2_out, CombineJob carried) {
+                                                            float* __restrict__ lp2_out, CombineJob carried, Riders riders) {
     using PK = Pack<DP>;
     extern __shared__ __align__(16) float sm[];
-    if (combine_carried(carried)) return;              // workgroups past the sample tiles: the merge of the previous sweep
+    if (combine_carried(carried) || riders_carried<DP>(riders, sm)) return;   // workgroups past the sample tiles: the merge of the previous sweep, riders
     const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
     const int k_lo = blockIdx.y * kchunk;
     const int K = min(K_total, k_lo + kchunk);
@@ -394,12 +395,12 @@ __global__ __launch_bounds__(1024) void mixture_eval_pk_kernel(float nu, int K_t
                                                                const float* __restrict__ logw, const float* __restrict__ X, int N,
                                                                float* __restrict__ ld_out, float* __restrict__ lp_out,
                                                                float* __restrict__ grad_out, const float* __restrict__ logw2,
-                                                               float* __restrict__ lp2_out, CombineJob carried) {
+                                                               float* __restrict__ lp2_out, CombineJob carried, Riders riders) {
     using PK = Pack<DP>;
     static_assert(DP % 2 == 0, "padded dimensions are even");
     constexpr int NP2 = DP / 2;
     extern __shared__ __align__(16) float sm[];
-    if (combine_carried(carried)) return;              // workgroups past the sample tiles: the merge of the previous sweep
+    if (combine_carried(carried) || riders_carried<DP>(riders, sm)) return;   // workgroups past the sample tiles: the merge of the previous sweep, riders
     const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
     const int k_lo = blockIdx.y * kchunk;
     const int K = min(K_total, k_lo + kchunk);
@@ -625,14 +626,14 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_kernel(float nu, int K_
                                                                 const float* __restrict__ logw, const float* __restrict__ X,
                                                                 int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
                                                                 float* __restrict__ grad_out, const float* __restrict__ logw2,
-                                                                float* __restrict__ lp2_out, CombineJob carried) {
+                                                                float* __restrict__ lp2_out, CombineJob carried, Riders riders) {
     using PK = Pack<DP>;
     constexpr int MT = PK::MT, KS = PK::KS;
-    if (combine_carried(carried)) return;              // workgroups past the sample tiles: the merge of the previous sweep
+    extern __shared__ __align__(16) float sm[];
+    if (combine_carried(carried) || riders_carried<DP>(riders, sm)) return;   // workgroups past the sample tiles: the merge of the previous sweep, riders
     constexpr int TS = 16 * NTS;                       // samples per workgroup tile
     constexpr int KSP = ((KS + 3) / 4) * 4;            // k-steps per lane in the z image, padded to 16-byte reads
     constexpr int ZW = 4 * KSP + 4;                    // row stride of the z image
-    extern __shared__ __align__(16) float sm[];
     const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
     const int k_lo = blockIdx.y * kchunk;
     const int K = min(K_total, k_lo + kchunk);
@@ -956,7 +957,7 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_ws_kernel(float nu, int
                                                                    const float* __restrict__ logw, const float* __restrict__ X,
                                                                    int N, float* __restrict__ ld_out, float* __restrict__ lp_out,
                                                                    float* __restrict__ grad_out, const float* __restrict__ logw2,
-                                                                   float* __restrict__ lp2_out, CombineJob carried) {
+                                                                   float* __restrict__ lp2_out, CombineJob carried, Riders riders) {
     using PK = Pack<DP>;
     constexpr int MT = PK::MT, KS = PK::KS;
     constexpr int TSW = 16 * NTS;                      // samples per wave
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(512) void mixture_eval_mfma_ws_kernel(float nu, int
     constexpr int BLK = NFR + ((DP + 1 + 3) / 4) * 4;                   // + mu[DP], log-normaliser
     constexpr int NPRE = (BLK + 511) / 512;
     extern __shared__ __align__(16) float sm[];
-    if (combine_carried(carried)) return;
+    if (combine_carried(carried) || riders_carried<DP>(riders, sm)) return;
     const int kchunk = (K_total + gridDim.y - 1) / gridDim.y;
     const int k_lo = blockIdx.y * kchunk;
     const int K = min(K_total, k_lo + kchunk);
@@ -1261,8 +1262,11 @@ static int launch_mixture_eval_mfma(gmmvi_ctx* ctx, int family, float nu, int K,
         lp2_k = logw2 ? lp_k + (size_t)ky * N : nullptr;
         grad_k = want_grad ? lp_k + (size_t)ky * N * (logw2 ? 2 : 1) : nullptr;
     }
-    const CombineJob carried = gmmvi_take_pending_combine(ctx, nw * 64, tiles);
-    dim3 grid(tiles + carried.blocks, ky), block(nw * 64);
+    // block order: the launch's own tiles, the riders (the stepsize block first: it is the longest of them), the carried merge
+    const Riders riders = gmmvi_take_pending_riders(ctx, tiles, nw * 64);
+    const CombineJob carried = gmmvi_take_pending_combine(ctx, nw * 64, tiles + riders.prep_blocks + riders.sample_blocks);
+    if (riders_lds_bytes(riders) > shmem) shmem = riders_lds_bytes(riders);
+    dim3 grid(tiles + carried.blocks + riders.prep_blocks + riders.sample_blocks, ky), block(nw * 64);
     {
         GMMVI_PROF_UNITS(ctx, sweep_prof_name(ctx, want_grad, logw2 != nullptr), (double)N * K);
 #define GMMVI_LAUNCH_MM(FAM, G)                                                                                     \
@@ -1271,7 +1275,7 @@ static int launch_mixture_eval_mfma(gmmvi_ctx* ctx, int family, float nu, int K,
             GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_mfma_kernel<DP, FAM, G, NTS>,        \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
         hipLaunchKernelGGL((mixture_eval_mfma_kernel<DP, FAM, G, NTS>), grid, block, shmem, ctx->stream, nu, K, D,  \
-                           packed, logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried);                             \
+                           packed, logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried, riders);                             \
     } while (0)
         if (family == GMMVI_GAUSS) {
             if (want_grad) GMMVI_LAUNCH_MM(GMMVI_GAUSS, true); else GMMVI_LAUNCH_MM(GMMVI_GAUSS, false);
@@ -1304,7 +1308,7 @@ static int launch_mixture_eval_mfma_ws(gmmvi_ctx* ctx, int family, float nu, int
     const bool want_merge = want_grad || lp != nullptr;
     const int nfr = 64 * (PK::NF + (want_grad ? PK::NB : 0));
     const int blk = nfr + ((DP + 1 + 3) / 4) * 4;
-    const size_t shmem = ((size_t)2 * blk + (want_grad ? (size_t)8 * NTS * 16 * ZW : 0)) * sizeof(float);
+    size_t shmem = ((size_t)2 * blk + (want_grad ? (size_t)8 * NTS * 16 * ZW : 0)) * sizeof(float);
     const int tiles = (N + TS - 1) / TS;
     // component chunks so that every CU gets a workgroup (two where the LDS allows), at least eight components each (the
     // block pipeline has a prologue and every chunk writes partial outputs)
@@ -1330,8 +1334,11 @@ static int launch_mixture_eval_mfma_ws(gmmvi_ctx* ctx, int family, float nu, int
         lp2_k = logw2 ? lp_k + (size_t)ky * N : nullptr;
         grad_k = want_grad ? lp_k + (size_t)ky * N * (logw2 ? 2 : 1) : nullptr;
     }
-    const CombineJob carried = gmmvi_take_pending_combine(ctx, 512, tiles);
-    dim3 grid(tiles + carried.blocks, ky), block(512);
+    // block order: the launch's own tiles, the riders (the stepsize block first: it is the longest of them), the carried merge
+    const Riders riders = gmmvi_take_pending_riders(ctx, tiles, 512);
+    const CombineJob carried = gmmvi_take_pending_combine(ctx, 512, tiles + riders.prep_blocks + riders.sample_blocks);
+    if (riders_lds_bytes(riders) > shmem) shmem = riders_lds_bytes(riders);
+    dim3 grid(tiles + carried.blocks + riders.prep_blocks + riders.sample_blocks, ky), block(512);
     {
         GMMVI_PROF_UNITS(ctx, sweep_prof_name(ctx, want_grad, logw2 != nullptr), (double)N * K);
 #define GMMVI_LAUNCH_WS(FAM, G)                                                                                     \
@@ -1340,7 +1347,7 @@ static int launch_mixture_eval_mfma_ws(gmmvi_ctx* ctx, int family, float nu, int
             GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_mfma_ws_kernel<DP, FAM, G, NTS>,     \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
         hipLaunchKernelGGL((mixture_eval_mfma_ws_kernel<DP, FAM, G, NTS>), grid, block, shmem, ctx->stream, nu, K,  \
-                           D, packed, logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried);                          \
+                           D, packed, logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried, riders);                          \
     } while (0)
         if (family == GMMVI_GAUSS) {
             if (want_grad) GMMVI_LAUNCH_WS(GMMVI_GAUSS, true); else GMMVI_LAUNCH_WS(GMMVI_GAUSS, false);
@@ -1403,7 +1410,7 @@ static int launch_mixture_eval_pk(gmmvi_ctx* ctx, int family, float nu, int K, i
     if (nw > kchunk) nw = kchunk;
     if (nw > 16) nw = 16;
     const int nv = (want_grad ? DP : 0) + 2;
-    const size_t shmem = (size_t)(DP / 2) * 64 * 16 + (size_t)nw * 64 * 8 + (want_merge ? (size_t)(nw > 8 ? 8 : 4) * nv * 64 * 8 : 0);
+    size_t shmem = (size_t)(DP / 2) * 64 * 16 + (size_t)nw * 64 * 8 + (want_merge ? (size_t)(nw > 8 ? 8 : 4) * nv * 64 * 8 : 0);
     float* lp_k = lp;
     float* grad_k = grad;
     float* lp2_k = lp2;
@@ -1420,8 +1427,11 @@ static int launch_mixture_eval_pk(gmmvi_ctx* ctx, int family, float nu, int K, i
         lp2_k = logw2 ? lp_k + (size_t)ky * N : nullptr;
         grad_k = want_grad ? lp_k + (size_t)ky * N * (logw2 ? 2 : 1) : nullptr;
     }
-    const CombineJob carried = gmmvi_take_pending_combine(ctx, nw * 64, tiles);
-    dim3 grid(tiles + carried.blocks, ky), block(nw * 64);
+    // block order: the launch's own tiles, the riders (the stepsize block first: it is the longest of them), the carried merge
+    const Riders riders = gmmvi_take_pending_riders(ctx, tiles, nw * 64);
+    const CombineJob carried = gmmvi_take_pending_combine(ctx, nw * 64, tiles + riders.prep_blocks + riders.sample_blocks);
+    if (riders_lds_bytes(riders) > shmem) shmem = riders_lds_bytes(riders);
+    dim3 grid(tiles + carried.blocks + riders.prep_blocks + riders.sample_blocks, ky), block(nw * 64);
     {
         GMMVI_PROF_UNITS(ctx, sweep_prof_name(ctx, want_grad, logw2 != nullptr), (double)N * K);
 #define GMMVI_LAUNCH_MEPK(FAM, G)                                                                                      \
@@ -1430,7 +1440,7 @@ static int launch_mixture_eval_pk(gmmvi_ctx* ctx, int family, float nu, int K, i
             GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_pk_kernel<DP, FAM, G>,               \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));         \
         hipLaunchKernelGGL((mixture_eval_pk_kernel<DP, FAM, G>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
-                           logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried);                                         \
+                           logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried, riders);                                         \
     } while (0)
         if (family == GMMVI_GAUSS) {
             if (want_grad) GMMVI_LAUNCH_MEPK(GMMVI_GAUSS, true); else GMMVI_LAUNCH_MEPK(GMMVI_GAUSS, false);
@@ -1535,8 +1545,11 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
         lp2_k = logw2 ? lp_k + (size_t)ky * N : nullptr;
         grad_k = want_grad ? lp_k + (size_t)ky * N * (logw2 ? 2 : 1) : nullptr;
     }
-    const CombineJob carried = gmmvi_take_pending_combine(ctx, nw * 64, tiles);
-    dim3 grid(tiles + carried.blocks, ky), block(nw * 64);
+    // block order: the launch's own tiles, the riders (the stepsize block first: it is the longest of them), the carried merge
+    const Riders riders = gmmvi_take_pending_riders(ctx, tiles, nw * 64);
+    const CombineJob carried = gmmvi_take_pending_combine(ctx, nw * 64, tiles + riders.prep_blocks + riders.sample_blocks);
+    if (riders_lds_bytes(riders) > shmem) shmem = riders_lds_bytes(riders);
+    dim3 grid(tiles + carried.blocks + riders.prep_blocks + riders.sample_blocks, ky), block(nw * 64);
     {
         GMMVI_PROF_UNITS(ctx, sweep_prof_name(ctx, want_grad, logw2 != nullptr), (double)N * K);
 #define GMMVI_LAUNCH_ME(FAM, G)                                                                                     \
@@ -1545,7 +1558,7 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
             GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)mixture_eval_kernel<DP, FAM, G>,               \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));      \
         hipLaunchKernelGGL((mixture_eval_kernel<DP, FAM, G>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
-                           logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried);                                      \
+                           logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried, riders);                                      \
     } while (0)
         if (family == GMMVI_GAUSS) {
             if (want_grad) GMMVI_LAUNCH_ME(GMMVI_GAUSS, true); else GMMVI_LAUNCH_ME(GMMVI_GAUSS, false);

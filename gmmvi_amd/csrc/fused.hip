@@ -46,6 +46,7 @@ extern "C" int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan
     if (rc == GMMVI_OK) rc = train_iter_samtron_body(ctx, p);
     if (rc != GMMVI_OK) {
         ctx->pending = CombineJob();
+        ctx->riders.prep_blocks = ctx->riders.sample_blocks = 0;
         ctx->defer_combine = false;
         ctx->prof_tag = nullptr;
     }
@@ -87,6 +88,8 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
     // ---- sample selection: draw, evaluate the target, append to the DB (sample_selector.py:160-219) --------------------
     // the element-wise bookkeeping (model snapshot into the DB, the two stepsize rules) rides in extra blocks of the
     // sampling launch, and the sampling blocks write the DB mapping (component index + base) directly
+    PrepArgs prep_later{};
+    bool prep_pending = false;
     {
         PrepArgs q{};
         if (p->db_means && p->db_chols && p->db_packed) {
@@ -101,8 +104,17 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
         q.ws_mode = p->weight_stepsize_mode; q.logw = p->logw; q.wstate = p->wstate;
         q.ws_min = p->ws_min; q.ws_max = p->ws_max; q.ws_inc = p->ws_inc; q.ws_dec = p->ws_dec;
         const int max_pc = p->max_per_component > 0 ? p->max_per_component : (N + K - 1) / K;
-        GMMVI_TRY(gmmvi_sample_components_prep(ctx, K, D, p->means, p->chols, p->offsets, N, max_pc, p->seed,
-                                               p->first_index, x, p->db_mapping, p->mapping_base, q));
+        if (p->presampled && n_old == 0) {
+            // the previous call drew this iteration's samples behind its component update (below): only the bookkeeping is
+            // left, and it rides in the target evaluation (riders.h) -- nothing before the component update reads what it
+            // writes.  (Not in the dual sweep: at one 108 KB workgroup per CU that launch has no room for extra workgroups,
+            // 16 riders made it 36 us instead of 24.)
+            prep_later = q;
+            prep_pending = true;
+        } else {
+            GMMVI_TRY(gmmvi_sample_components_prep(ctx, K, D, p->means, p->chols, p->offsets, N, max_pc, p->seed,
+                                                   p->first_index, x, p->db_mapping, p->mapping_base, q));
+        }
     }
     // ---- background + model density / gradient (sample_db.py:194-228, gmm.py:274-300) ------------------------------------
     // issued BEFORE the target evaluation, which does not depend on them: the merge of the model sweep's component-chunk
@@ -137,6 +149,10 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
         ctx->prof_tag = nullptr;
         GMMVI_TRY(rc_m);
     }
+    if (prep_pending) {
+        ctx->riders.prep = prep_later;
+        ctx->riders.prep_blocks = K < 64 ? K : 64;
+    }
     if (p->target_kind == 1) {
         GMMVI_TRY(gmmvi_target_planar(ctx, D, p->planar_prior_std, p->planar_goals_count, p->planar_goals,
                                       p->planar_likelihood_std, x, N, p->db_tlp, p->db_tgrad));
@@ -148,6 +164,7 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
         GMMVI_TRY(rc_t);
     }
     GMMVI_TRY(gmmvi_flush_pending_combine(ctx));       // nothing left unless the target launch could not carry it
+    GMMVI_TRY(gmmvi_flush_pending_riders(ctx));        // (the planar-robot target kernel carries no riders: their own launch)
     // ---- component update (gmmvi.py:165-169) -----------------------------------------------------------------------------
     // the Stein estimate stops at its partial slab; its last step (slab sum, Sigma^-1, normalisation) is the prologue of the
     // update kernel where that is instantiated, the stand-alone launch otherwise -- the same arithmetic either way
@@ -164,8 +181,21 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
     ctx->defer_combine = false;
     ctx->prof_tag = nullptr;
     GMMVI_TRY(rc_post);
+    if (p->presample_next && n_old == 0) {
+        // the next iteration's draw from the UPDATED components rides in the expected-log-ratio launch, whose K workgroups leave most CUs idle (riders.h;
+        // the draw needs neither the weights nor anything this launch writes).  Inside the post-update sweep it would queue behind
+        // that launch's workgroups: every workgroup of a launch gets the launch's LDS size, 108 KB there
+        const int max_pc = p->max_per_component > 0 ? p->max_per_component : (N + K - 1) / K;
+        SampleJob& sj = ctx->riders.sample;
+        sj.K = K; sj.D = D; sj.uniform_count = (long)K * max_pc == N ? max_pc : 0;
+        sj.means = p->means; sj.chols = p->chols; sj.offsets = p->offsets;
+        sj.seed = p->seed; sj.first_index = p->first_index + (uint64_t)N;
+        sj.X = x + (size_t)N * D; sj.mapping = p->db_mapping + N; sj.mapping_base = p->mapping_base + K;
+        ctx->riders.sample_blocks = K * ((max_pc + 255) / 256);
+    }
     GMMVI_TRY(gmmvi_expected_log_ratios(ctx, K, Na, a.ld, a.bg, tlp_a, a.lq, p->temperature, p->logw,
                                         (p->stein_flags & GMMVI_SELF_NORMALIZED) ? 1 : 0, a.E, p->reward_next, nullptr));
+    GMMVI_TRY(gmmvi_flush_pending_riders(ctx));        // (nothing is left normally)
     if (K > 1) {
         GMMVI_TRY(gmmvi_update_weights_internal(ctx, p->weight_update_mode == 0 ? 0 : 1, K, p->logw, a.E, p->wstate,
                                                 p->temperature, nullptr, p->weight_slot));

@@ -5,10 +5,11 @@
 #include "common.h"
 #include "philox.h"
 #include "iter_prep.h"
+#include "sample_block.h"
+#include "riders.h"
 #include "blocked.h"
 
-// grid = (component, 256-sample chunk of that component); (mu_k, L_k) staged in LDS and read as broadcasts, eps and x in
-// registers (DP = padded dimension, loops unrolled), the output tile leaves through LDS with coalesced stores.
+// grid = (component, 256-sample chunk of that component): sample_block.h
 template <int DP>
 __global__ __launch_bounds__(256) void sample_components_kernel(int K, int D, const float* __restrict__ means,
                                                                 const float* __restrict__ chols,
@@ -22,120 +23,37 @@ __global__ __launch_bounds__(256) void sample_components_kernel(int K, int D, co
         iter_prep_block(prep, blockIdx.x, gridDim.x);
         return;
     }
-    const int k = blockIdx.x;
-    // equal counts known to the caller (single-call iteration): no dependent load in front of everything else
-    const int begin = uniform_count > 0 ? k * uniform_count : offsets[k];
-    const int end = uniform_count > 0 ? begin + uniform_count : offsets[k + 1];
-    const int base = begin + blockIdx.y * 256;
-    if (base >= end) return;
-    const int n_here = min(256, end - base);
-    float* Ls = sm;                      // [D][D]
-    float* mus = sm + D * D;             // [D]
-    float* tile = mus + D;               // [256][ldx]
-    const int ldx = D | 1;
-    const int t = threadIdx.x;
-    // (mu, L) are fetched into registers first and reach LDS after the random numbers are made: the loads (L2 round trips:
-    // the previous iteration's update kernel wrote them on other CUs) overlap the Philox rounds
-    constexpr int NL = (DP * DP + 255) / 256;
-    float lreg[NL];
-#pragma unroll
-    for (int u = 0; u < NL; ++u) lreg[u] = (t + 256 * u < D * D) ? chols[(size_t)k * D * D + t + 256 * u] : 0.f;
-    const float mreg = t < D ? means[(size_t)k * D + t] : 0.f;
-    if (eps_in) {
-        for (int e = t; e < n_here * D; e += 256) tile[(e / D) * ldx + (e % D)] = eps_in[(size_t)base * D + e];
-    }
-    const bool valid = t < n_here;
-    if (!eps_in) {
-        // the standard normals of the tile, four per Philox block (counter = sample index, block): the (sample, block) items are
-        // spread over ALL threads -- a thread that made all of its sample's blocks itself spent 4 us of a 9 us launch in the
-        // Philox rounds and the Box-Muller transforms (D = 20: five blocks a sample, 100 samples on 256 threads)
-        constexpr int NB4 = (DP + 3) / 4;
-        for (int item = t; item < n_here * NB4; item += 256) {
-            const int smp = item / NB4, b = item - smp * NB4;
-            float nn[4];
-            philox_normal4(seed, first_index + (uint64_t)(base + smp), (uint32_t)b, stream_id, nn);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (4 * b + j < D) tile[smp * ldx + 4 * b + j] = nn[j];
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < NL; ++u)
-        if (t + 256 * u < D * D) Ls[t + 256 * u] = lreg[u];
-    if (t < D) mus[t] = mreg;
-    __syncthreads();
-    if constexpr (DP >= 32) {
-        // X = mu + eps L^T as a matrix-core product (v_mfma_f32_16x16x4_f32): a wave owns 64 samples (four 16-row tiles of
-        // eps), A = eps[16 mt + i][4 s + kk], B = L^T: B[kk][j] = L[16 nt + j][4 s + kk], k-steps beyond the diagonal block of
-        // the lower-triangular L skipped.  (One lane per sample with the row of L broadcast from LDS is a chain of D^2 / 2
-        // dependent multiply-adds on 100 of the 256 threads: 16 of the 21 us of the launch at D = 50.)
-        typedef float sc_f32x4 __attribute__((ext_vector_type(4)));
-        constexpr int NT = (DP + 15) / 16, KS = (DP + 3) / 4;
-        const int wave = t >> 6, lane = t & 63, i16 = lane & 15, kk = lane >> 4;
-        const int s0 = 64 * wave;                      // first sample of this wave
-        if (s0 < n_here) {
-            sc_f32x4 acc[4][NT];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = sc_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s4 = 0; s4 < KS; ++s4) {
-                const int kcol = 4 * s4 + kk;
-                float a[4], b[NT];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const int smp = s0 + 16 * mt + i16;
-                    a[mt] = (smp < n_here && kcol < D) ? tile[smp * ldx + kcol] : 0.f;
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int row = 16 * nt + i16;
-                    b[nt] = (row < D && kcol <= row) ? Ls[row * D + kcol] : 0.f;      // lower triangle only (and kcol < D)
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if (4 * s4 > 16 * nt + 15) continue;                                // this k-step lies above the diagonal block
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
-                }
-            }
-            // every eps value of the wave's rows has been read (by this wave only): the results overwrite them in place.
-            // D[i][j]: lane l, register r -> sample 16 mt + 4 (l >> 4) + r, dimension 16 nt + (l & 15)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int smp = s0 + 16 * mt + 4 * kk + r, dim = 16 * nt + i16;
-                        if (smp < n_here && dim < D) tile[smp * ldx + dim] = acc[mt][nt][r] + mus[dim];
-                    }
-        }
-        if (valid && mapping) mapping[base + t] = k + mapping_base;
-    } else {
-    float eps[DP];
-#pragma unroll
-    for (int i = 0; i < DP; ++i) eps[i] = (valid && i < D) ? tile[t * ldx + i] : 0.f;
-    __syncthreads();
-    if (valid) {
-#pragma unroll
-        for (int i = 0; i < DP; ++i) {
-            if (i < D) {
-                float v = mus[i];
-#pragma unroll
-                for (int j = 0; j <= i; ++j) v = fmaf(Ls[i * D + j], eps[j], v);
-                tile[t * ldx + i] = v;
-            }
-        }
-        if (mapping) mapping[base + t] = k + mapping_base;
-    }
-    }
-    __syncthreads();
-    for (int e = t; e < n_here * D; e += 256) X[(size_t)base * D + e] = tile[(e / D) * ldx + (e % D)];
+    sample_block<DP>(sm, blockIdx.x, blockIdx.y, D, means, chols, offsets, seed, first_index, stream_id, eps_in, X, mapping,
+                     mapping_base, uniform_count);
+}
+
+// riders nothing carried (riders.h): their own launch
+template <int DP>
+__global__ __launch_bounds__(256) void riders_kernel(Riders r) {
+    extern __shared__ float sm[];
+    riders_carried<DP>(r, sm);
+}
+
+Riders gmmvi_take_pending_riders(gmmvi_ctx* ctx, int first_block, int threads, bool prep_only) {
+    Riders r = ctx->riders;
+    r.first_block = first_block;
+    if (threads < 64 || threads % 64) { r.prep_blocks = 0; r.sample_blocks = 0; return r; }
+    ctx->riders.prep_blocks = 0;
+    if (threads < 256 || prep_only) r.sample_blocks = 0;      // sample_block needs 256 threads: that rider stays pending
+    else ctx->riders.sample_blocks = 0;
+    return r;
+}
+
+int gmmvi_flush_pending_riders(gmmvi_ctx* ctx) {
+    if ((ctx->riders.prep_blocks | ctx->riders.sample_blocks) == 0) return GMMVI_OK;
+    const Riders r = gmmvi_take_pending_riders(ctx, 0, 256);
+    const int D = r.sample_blocks > 0 ? r.sample.D : 2;
+    const int dp = gmmvi_padded_dim(D);
+    GMMVI_PROF(ctx, "riders");
+    GMMVI_DISPATCH_DP(dp, hipLaunchKernelGGL((riders_kernel<DP>), dim3(r.prep_blocks + r.sample_blocks), dim3(256),
+                                             riders_lds_bytes(r), ctx->stream, r));
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
 }
 
 __global__ void philox_normals_kernel(uint64_t seed, uint64_t first_index, uint32_t stream_id, int N, int D,

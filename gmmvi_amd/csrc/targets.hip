@@ -3,11 +3,12 @@
 // gmmvi_mixture_eval (density.hip).
 #include "common.h"
 #include "combine.h"
+#include "riders.h"
 
 __global__ void planar_kernel(int D, const float* __restrict__ prior_std, int G, const float* __restrict__ goals,
                               float lik_std, const float* __restrict__ X, int N, float* __restrict__ lp,
-                              float* __restrict__ grad, CombineJob carried) {
-    if (combine_carried(carried)) return;              // workgroups past the samples: the merge of the previous sweep
+                              float* __restrict__ grad, CombineJob carried, Riders riders) {
+    if (combine_carried(carried) || riders_carried_prep(riders)) return;   // workgroups past the samples: the merge of the previous sweep, bookkeeping
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float* th = X + (size_t)n * D;
@@ -51,9 +52,10 @@ extern "C" int gmmvi_target_planar(gmmvi_ctx* ctx, int D, const float* prior_std
     if (N == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, prior_std_dev && goals_dev && X_dev);
     GMMVI_PROF(ctx, "target_planar");
-    const CombineJob carried = gmmvi_take_pending_combine(ctx, 128, (N + 127) / 128, true);
-    hipLaunchKernelGGL(planar_kernel, dim3((N + 127) / 128 + carried.blocks), dim3(128), 0, ctx->stream, D, prior_std_dev, G,
-                       goals_dev, likelihood_std, X_dev, N, lp_out_dev, grad_out_dev, carried);
+    const Riders riders = gmmvi_take_pending_riders(ctx, (N + 127) / 128, 128, true);
+    const CombineJob carried = gmmvi_take_pending_combine(ctx, 128, (N + 127) / 128 + riders.prep_blocks, true);
+    hipLaunchKernelGGL(planar_kernel, dim3((N + 127) / 128 + riders.prep_blocks + carried.blocks), dim3(128), 0, ctx->stream, D,
+                       prior_std_dev, G, goals_dev, likelihood_std, X_dev, N, lp_out_dev, grad_out_dev, carried, riders);
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }

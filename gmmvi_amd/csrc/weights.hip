@@ -2,6 +2,7 @@
 // weight update (:164-279), the direct update (:123-141) and the improvement-based
 // stepsize rules (component_stepsize_adaptation.py:165-188, weight_stepsize_adaptation.py:141-156).
 #include "common.h"
+#include "riders.h"
 #include "stepsize_rules.h"
 #include "wave_reduce.h"
 #include "combine.h"
@@ -67,11 +68,11 @@ __device__ __forceinline__ void elr_accumulate(int N, const float* __restrict__ 
 // One 1024-thread workgroup per component: E_k = sum_n softmax_n(ld[k,n] - bg[n]) * (tlp[n] - beta logq[n]) in a single
 // pass (per-thread running maximum with rescaling), then a fixed-order tree over the 16 waves.
 // logq_R > 0: logq holds the logq_R chunk partials [logq_R][N] of a component-split sweep, merged here as combine.h does.
-__global__ __launch_bounds__(1024) void elr_kernel(int N, const float* __restrict__ ld, const float* __restrict__ bg,
-                                                   const float* __restrict__ tlp, const float* __restrict__ logq, int logq_R,
-                                                   float beta, const float* __restrict__ logw, int self_normalized,
-                                                   float* __restrict__ E_out, float* __restrict__ reward_out,
-                                                   float* __restrict__ ess_out) {
+__device__ __forceinline__ void elr_body(int N, const float* __restrict__ ld, const float* __restrict__ bg,
+                                         const float* __restrict__ tlp, const float* __restrict__ logq, int logq_R,
+                                         float beta, const float* __restrict__ logw, int self_normalized,
+                                         float* __restrict__ E_out, float* __restrict__ reward_out,
+                                         float* __restrict__ ess_out) {
     __shared__ float red[4][16];
     const int k = blockIdx.x;
     const float* row = ld + (size_t)k * N;
@@ -111,6 +112,28 @@ __global__ __launch_bounds__(1024) void elr_kernel(int N, const float* __restric
         if (reward_out) reward_out[k] = beta * logw[k] + E;                              // :73
         if (ess_out) ess_out[k] = (S * S) / S2;                                          // sample_selector.py:154-158
     }
+}
+
+__global__ __launch_bounds__(1024) void elr_kernel(int N, const float* __restrict__ ld, const float* __restrict__ bg,
+                                                   const float* __restrict__ tlp, const float* __restrict__ logq, int logq_R,
+                                                   float beta, const float* __restrict__ logw, int self_normalized,
+                                                   float* __restrict__ E_out, float* __restrict__ reward_out,
+                                                   float* __restrict__ ess_out) {
+    elr_body(N, ld, bg, tlp, logq, logq_R, beta, logw, self_normalized, E_out, reward_out, ess_out);
+}
+
+// the same launch carrying riders (riders.h): the single-call iteration's draw of the NEXT iteration's samples runs on the
+// CUs the K workgroups of this launch leave idle (K = 100: 156 of 256)
+template <int DP>
+__global__ __launch_bounds__(1024) void elr_riders_kernel(int N, const float* __restrict__ ld, const float* __restrict__ bg,
+                                                          const float* __restrict__ tlp, const float* __restrict__ logq,
+                                                          int logq_R, float beta, const float* __restrict__ logw,
+                                                          int self_normalized, float* __restrict__ E_out,
+                                                          float* __restrict__ reward_out, float* __restrict__ ess_out,
+                                                          Riders riders) {
+    extern __shared__ __align__(16) float sm_riders[];
+    if (riders_carried<DP>(riders, sm_riders)) return;
+    elr_body(N, ld, bg, tlp, logq, logq_R, beta, logw, self_normalized, E_out, reward_out, ess_out);
 }
 
 // log-sum-exp over K values held in LDS by one wavefront
@@ -325,8 +348,17 @@ int gmmvi_expected_log_ratios(gmmvi_ctx* ctx, int K, int N, const float* ld_dev,
         }
     }
     GMMVI_PROF(ctx, "expected_log_ratios");
-    hipLaunchKernelGGL(elr_kernel, dim3(K), dim3(1024), 0, ctx->stream, N, ld_dev, bg_dev, tlp_dev, logq_dev, logq_R, beta,
-                       logw_dev, self_normalized, E_out_dev, reward_out_dev, ess_out_dev);
+    const Riders riders = gmmvi_take_pending_riders(ctx, K, 1024);
+    if (riders.prep_blocks + riders.sample_blocks > 0) {
+        const int dp = gmmvi_padded_dim(riders.sample_blocks > 0 ? riders.sample.D : 2);
+        GMMVI_DISPATCH_DP(dp, hipLaunchKernelGGL((elr_riders_kernel<DP>), dim3(K + riders.prep_blocks + riders.sample_blocks),
+                                                 dim3(1024), riders_lds_bytes(riders), ctx->stream, N, ld_dev, bg_dev, tlp_dev,
+                                                 logq_dev, logq_R, beta, logw_dev, self_normalized, E_out_dev, reward_out_dev,
+                                                 ess_out_dev, riders));
+    } else {
+        hipLaunchKernelGGL(elr_kernel, dim3(K), dim3(1024), 0, ctx->stream, N, ld_dev, bg_dev, tlp_dev, logq_dev, logq_R, beta,
+                           logw_dev, self_normalized, E_out_dev, reward_out_dev, ess_out_dev);
+    }
     GMMVI_LAUNCH_CHECK(ctx);
     return GMMVI_OK;
 }

@@ -26,6 +26,7 @@ from .gmmvi_modules.component_stepsize_adaptation import (FixedComponentStepsize
 from .gmmvi_modules.weight_stepsize_adaptation import (FixedWeightStepsizeAdaptation,
                                                        ImprovementBasedWeightStepsizeAdaptation)
 from .gmmvi_modules.weight_updater import DirectWeightUpdater, TrustRegionBasedWeightUpdater
+from .gmmvi_modules.component_adaptation import FixedComponentAdaptation
 
 _f, _i, _p = C.c_float, C.c_int32, C.c_void_p
 
@@ -47,7 +48,7 @@ class SamtronPlan(C.Structure):
         ("temperature", _f), ("l2_init", _f),
         ("component_stepsize_mode", _i), ("cs_min", _f), ("cs_max", _f), ("cs_inc", _f), ("cs_dec", _f),
         ("weight_stepsize_mode", _i), ("ws_min", _f), ("ws_max", _f), ("ws_inc", _f), ("ws_dec", _f),
-        ("weight_update_mode", _i), ("stein_flags", _i),
+        ("weight_update_mode", _i), ("stein_flags", _i), ("presample_next", _i), ("presampled", _i),
     ]
 
 
@@ -60,6 +61,10 @@ class SamtronFastPath:
         # True: the Stein estimate is materialised exactly as the modules do it (bit-equal trajectories); False: the update
         # kernel whitens the moment sums directly where it can (csrc/update_kl.hip), same mathematics with fewer roundings
         self.explicit_estimate = os.environ.get("GMMVI_EXPLICIT_ESTIMATE", "0") == "1"
+        # the NEXT iteration's draw rides in this iteration's post-update sweep (csrc/riders.h) when nothing can change the
+        # components, the counts or the database in between: fixed number of components, reuse ratio 0
+        self.presample = os.environ.get("GMMVI_PRESAMPLE", "1") != "0"
+        self._presample_token = None
         lib = _lib.load()
         lib.gmmvi_train_iter_samtron.restype = C.c_int
         lib.gmmvi_train_iter_samtron.argtypes = [C.c_void_p, C.POINTER(SamtronPlan)]
@@ -141,9 +146,14 @@ class SamtronFastPath:
             sel._last_mapping_host = np.repeat(np.arange(k, dtype=np.int32), counts)
         sel._last_counts = counts
 
-        # SampleDB: reserve room, remember the append position (sample_db.py:113-124)
-        for grow, rows in ((db._samples, n), (db._target_lnpdfs, n), (db._target_grads, n), (db._mapping_dev, n),
-                           (db._means, k), (db._chols, k), (db._packed, k)):
+        # may this call draw the next iteration's samples as well?  (sample_selector.py:204-219: the draw needs the updated
+        # components only)  Only when the next iteration is bound to be this same call on the same shapes.
+        presample_next = (self.presample and n_old == 0 and sel.reused_samples_per_component == 0
+                          and type(g.num_component_adapter) is FixedComponentAdaptation
+                          and (db.max_samples is None or db._samples.n + 2 * n <= db.max_samples))
+        # SampleDB: reserve room (for the early draw too), remember the append position (sample_db.py:113-124)
+        for grow, rows in ((db._samples, 2 * n if presample_next else n), (db._target_lnpdfs, n), (db._target_grads, n),
+                           (db._mapping_dev, 2 * n if presample_next else n), (db._means, k), (db._chols, k), (db._packed, k)):
             grow.reserve(rows)
         s0, c0 = db._samples.n, db._means.n
         stride = db._packed.inner[0]
@@ -217,7 +227,21 @@ class SamtronFastPath:
         if self.explicit_estimate:
             p.stein_flags |= _lib.EXPLICIT_ESTIMATE
 
-        ctx.check(self._fn(ctx.handle, C.byref(p)))
+        # this iteration's samples may already be there: drawn by the previous call behind its component update
+        here = (db._samples.buf.ptr, db._mapping_dev.buf.ptr, s0, c0, n, k, key, int(db._num_samples_written),
+                int(model.seed), model.means.ptr, model.chol_cov.ptr, offsets_dev.ptr)
+        tok, self._presample_token = self._presample_token, None
+        p.presampled = int(tok is not None and n_old == 0 and tok[0] == here and tok[1] is model._packed)
+        p.presample_next = int(presample_next)
+
+        try:
+            ctx.check(self._fn(ctx.handle, C.byref(p)))
+        except Exception:
+            # the host mirror of the mapping and the append log are one entry ahead of the device buffers: take it back
+            db._mapping_host.n -= len(sel._last_mapping_host)
+            db._segments.pop()
+            db._seg_start, db._seg_size, db._seg_info = [], [], {}
+            raise
 
         # bookkeeping the modules would have done
         for grow, rows in ((db._samples, n), (db._target_lnpdfs, n), (db._target_grads, n), (db._mapping_dev, n),
@@ -231,5 +255,9 @@ class SamtronFastPath:
             m._t_weight += 1
         model._packed = packed_new
         model._eval_cache = None
+        if presample_next:
+            self._presample_token = ((db._samples.buf.ptr, db._mapping_dev.buf.ptr, s0 + n, c0 + k, n, k, key,
+                                      int(db._num_samples_written), int(model.seed), model.means.ptr, model.chol_cov.ptr,
+                                      offsets_dev.ptr), packed_new)
         g.ng_based_updater.last_success = success
         g.num_updates.assign_add(1)

@@ -315,6 +315,15 @@ typedef struct gmmvi_samtron_plan {
     int32_t weight_update_mode;           /* 0 trust-region, 1 direct */
     int32_t stein_flags;                  /* enum gmmvi_stein_flags (own-samples-only is not supported here;
                                            * GMMVI_EXPLICIT_ESTIMATE: results bit-equal to the module-by-module calls) */
+    /* Drawing the NEXT iteration's samples early (n_old == 0 only).  x = mu + L eps needs the updated components, not the
+     * weights (sample_selector.py:204-219), so the draw of iteration i + 1 can ride as extra workgroups in the post-update
+     * sweep of iteration i instead of opening iteration i + 1 with a launch of its own.
+     * presample_next != 0: after the component update, draw the N samples of the next iteration (same offsets, Philox
+     *   indices first_index + N ..) into db_samples + N * D and their mapping (base mapping_base + K) into db_mapping + N;
+     *   the caller has reserved those rows.
+     * presampled != 0: db_samples / db_mapping already hold this iteration's draw (made by the previous call with
+     *   presample_next, nothing touched the components, the offsets or the database since): no sampling launch. */
+    int32_t presample_next, presampled;
 } gmmvi_samtron_plan;
 int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan* plan);
 
