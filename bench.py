@@ -41,6 +41,13 @@ def kernel_peak(name):
     return PEAK_FP32_TFLOPS
 PEAK_HBM_GBS = 8000.0
 
+
+def kernel_bound(name, d):
+    """Which unit bounds a kernel: the scalar-fed density sweeps (padded D <= 24: csrc/density.hip mixture_eval_kernel /
+    mixture_eval_pk_kernel) are vector-ALU kernels (v_fma_f32 / v_pk_fma_f32 fed from scalar registers), every other
+    FLOP-carrying kernel contracts on the matrix cores."""
+    return "valu" if name.startswith("sweep_") and d <= 24 else "mfma"
+
 WORKLOADS = {
     # id: (target kind, D, K per GPU, samples per component at 1 GPU)
     "ns": ("stm", 20, 100, 100),       # north star: K=100, D=20, N=10k
@@ -61,6 +68,13 @@ WORKLOADS = {
     # dimension sweep at the C3 shape (crossover of the register-resident and the blocked kernels, GMMVI_BLOCKED_ABOVE)
     "d32": ("gmm", 32, 100, 100), "d40": ("gmm", 40, 100, 100), "d63": ("gmm", 63, 100, 100),
     "tiny": ("stm", 4, 4, 16),         # host-overhead probe (kernels are empty; time = launch path)
+    # BASELINE configs[3]'s example AS IT IS RUN (examples/6_samtron_planar4.py:19-26): 100 initial components, a component
+    # added EVERY iteration, deletions from iteration 11 on, weight stepsize 5 -- K changes every iteration: what the packing,
+    # ring growth and eligibility checks of an adaptive run cost (timed behind the warm-up iterations; value = mean N K / t)
+    "c4_adaptive": ("planar", 10, 100, 100, "Stein", 0.0,
+                    {"del_iters": 10, "add_iters": 1, "max_components": 1000,
+                     "thresholds_for_add_heuristic": [5000., 1000., 500., 200., 100., 50.],
+                     "min_weight_for_del_heuristic": 1e-6, "num_database_samples": 100000, "num_prior_samples": 0}),
 }
 # Strong-scaling workloads: the BASELINE configurations that NAME a GPU count, as stated -- K is the TOTAL number of
 # components, split evenly over the ranks (K % gpus == 0), the samples per component do not change with the rank count.
@@ -82,6 +96,10 @@ def kernel_flops(name, n, k, d):
         "sweep_grad": p * (2 * d * d + 8 * d),            # + backward substitution + responsibility-weighted gradient
         "sweep_target": p * (2 * d * d + 8 * d),          # the target evaluation (mixture targets: log value + gradient)
         "sweep_dual": p * (2 * d * d + 8 * d),            # model log q + gradient + background in one pass over the components
+        # sample reuse (the reference's default selector): the background mixture over the window's snapshot components (log
+        # values only) and the model sweep with the gradient are separate launches of the single-call iteration
+        "sweep_background": p * (d * d + 4 * d),
+        "sweep_model": p * (2 * d * d + 8 * d),
         "stein_partial": p * (4 * d * d + 6 * d),         # y per sample (2D^2) + rank-1 accumulate (2D^2)
         # MORE: lower triangle of the (F+1)x(F+1) Gram matrix of [phi; reward], F = D(D+1)/2 + D + 1 (2 flop per MAC)
         "more_gram": p * ((d * (d + 1) // 2 + d + 2) * (d * (d + 1) // 2 + d + 3) + d * d),
@@ -109,6 +127,7 @@ def spec(workload, n_gpus, seed=0):
     extra = WORKLOADS[workload][4:]
     estimator = extra[0] if len(extra) > 0 else "Stein"
     reuse = float(extra[1]) if len(extra) > 1 else 0.0
+    adaptive = extra[2] if len(extra) > 2 else None
     if workload in STRONG_WORKLOADS:
         if k_per_gpu % n_gpus:
             raise SystemExit(f"bench.py: workload {workload} splits K = {k_per_gpu} components evenly; --gpus {n_gpus} does not divide it")
@@ -116,23 +135,32 @@ def spec(workload, n_gpus, seed=0):
     else:
         k_total = k_per_gpu * n_gpus
         s = int(np.ceil(s1 / n_gpus))
-    rng = np.random.default_rng(seed)
-    if kind == "stm":
-        ot = otargets.make_stm_target(d, rng)
-        prior_scale, initial_cov = 100.0, 300.0                    # stm20.yml:9-14
-    elif kind == "gmm":
-        ot = otargets.make_gmm_target(d, rng)
-        prior_scale, initial_cov = 31.63, 1000.0                   # gmm20.yml:7-12
-    elif kind == "gauss300":
-        ot = otargets.make_gmm_target_with_scale(d, 1, 1.0, rng)
-        prior_scale, initial_cov = 100.0, 300.0                    # stm300.yml:9-14
-    else:
-        ot = otargets.PlanarRobotTarget(d, 4)
-        prior_scale, initial_cov = [1.0] + [0.2] * (d - 1), [0.0625] + [0.0025] * (d - 1)   # planar_robot_4.yml
+    # the target's parameters come from the PRODUCT's own constructors (the reference's laws on the global NumPy RNG,
+    # gmmvi_amd/experiments/target_distributions/{student_t_mixture,gmm}.py: host arrays, no GPU); the oracle target is built
+    # from those arrays and serves the CPU baseline and the matched-ELBO scorer only
+    from gmmvi_amd.experiments.target_distributions import student_t_mixture as p_stm, gmm as p_gmm
+    state = np.random.get_state()
+    np.random.seed(seed)
+    try:
+        if kind == "stm":
+            ot = otargets.StudentTMixtureTarget(*p_stm.make_target_parameters(d, False), alpha=2)
+            prior_scale, initial_cov = 100.0, 300.0                    # stm20.yml:9-14
+        elif kind == "gmm":
+            ot = otargets.GmmTarget(*p_gmm.make_target_parameters(d))
+            prior_scale, initial_cov = 31.63, 1000.0                   # gmm20.yml:7-12
+        elif kind == "gauss300":
+            ot = otargets.GmmTarget(*p_gmm.make_target_with_scale_parameters(d, 1, 1.0))
+            prior_scale, initial_cov = 100.0, 300.0                    # stm300.yml:9-14
+        else:
+            ot = otargets.PlanarRobotTarget(d, 4)                      # (no random parameters: planar_robot.py:137-138)
+            prior_scale, initial_cov = [1.0] + [0.2] * (d - 1), [0.0625] + [0.0025] * (d - 1)   # planar_robot_4.yml
+    finally:
+        np.random.set_state(state)
     init_rng = np.random.default_rng(seed + 1)
     means = (np.asarray(prior_scale) * init_rng.standard_normal((k_total, d))).astype(np.float32)
     covs = np.broadcast_to((np.asarray(initial_cov) * np.eye(d)).astype(np.float32), (k_total, d, d))
-    cfg = samtron_config(s, initial_stepsize=0.1, estimator=estimator, reuse_ratio=reuse)
+    cfg = samtron_config(s, initial_stepsize=0.1, estimator=estimator, reuse_ratio=reuse, adaptive=adaptive,
+                         wstep=5.0 if adaptive else 1.0)                  # examples/6...:24 (the rule caps it at max_stepsize)
     cfg["model_initialization"].update(prior_mean=0.0, initial_cov=initial_cov)
     return dict(kind=kind, d=d, k_total=k_total, s=s, n_total=k_total * s, cfg=cfg, oracle_target=ot,
                 means=means, covs=np.ascontiguousarray(covs), seed=seed + 2)
@@ -178,7 +206,10 @@ def make_oracle(w, dtype=np.float64):
                               desired_samples_per_component=w["s"],
                               ratio_reused_samples_to_desired=cfg["sample_selector_config"]["ratio_reused_samples_to_desired"],
                               component_stepsize_config=cfg["component_stepsize_adapter_config"],
-                              weight_stepsize_config=cfg["weight_stepsize_adapter_config"])
+                              weight_stepsize_config=cfg["weight_stepsize_adapter_config"],
+                              adaptive=(dict(cfg["num_component_adapter_config"], prior_mean=0.0,
+                                             initial_cov=cfg["model_initialization"]["initial_cov"])
+                                        if cfg["num_component_adapter_type"] == "adaptive" else None))
 
 
 def time_cpu_baseline(w, seconds, warmup=3, max_iters=20, min_iters=3):
@@ -361,19 +392,38 @@ def main():
             exchange.barrier()
             ctx.sync()
 
+    adaptive_k = w["cfg"]["num_component_adapter_type"] == "adaptive" and n_gpus == 1
+    pairs_done = [0.0]
+
+    def timed(steps):
+        barrier()
+        pairs_done[0] = 0.0
+        t_start = time.perf_counter()
+        for _ in range(steps):
+            if adaptive_k:               # K changes between iterations: (samples, components) pairs of this one
+                pairs_done[0] += float(algo.model.num_components) ** 2 * w["s"]
+            algo.train_iter()
+        if hasattr(algo, "flush"):
+            algo.flush()             # sharded path: the last weight step rides with the next exchange; close it in the timed region
+        barrier()
+        dt = time.perf_counter() - t_start
+        return exchange.max_scalar(dt) if exchange is not None else dt
+
     for _ in range(args.warmup):
         algo.train_iter()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        algo.train_iter()
-    if hasattr(algo, "flush"):
-        algo.flush()                 # sharded path: the last weight step rides with the next exchange; close it in the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if exchange is not None:
-        elapsed = exchange.max_scalar(elapsed)
+    elapsed = timed(args.steps)
     ms_per_step = 1e3 * elapsed / args.steps
+    pairs_per_step = pairs_done[0] / args.steps if adaptive_k else float(w["n_total"]) * w["k_total"]
+    k_span = (None if not adaptive_k else
+              f"K {w['k_total']} at the start, {int(algo.model.num_components)} after {args.warmup + args.steps} iterations")
+    # the same figure at the two ends of a run: over the FIRST iterations of a fresh process (what a short --steps measures: the
+    # sample database is still growing, caches are cold) and in the steady state behind them
+    first_n = args.warmup + args.steps
+    steady_steps = 200
+    if first_n < 225:
+        for _ in range(225 - first_n):   # bring the run to the same age before the steady-state window whatever --steps was
+            algo.train_iter()
+    steady_ms = 1e3 * timed(steady_steps) / steady_steps
 
     # ---- roofline leg: the same steps again with per-kernel HIP events on the compute stream ---------------------
     ctx.check(ctx.lib.gmmvi_profile_enable(ctx.handle, 1))
@@ -408,8 +458,12 @@ def main():
         t = kernels[nme]["avg_us"] * 1e-6
         kernel_roofline[nme] = {"avg_us": kernels[nme]["avg_us"], "launches_per_step": kernels[nme]["launches_per_step"],
                                 "share_of_step": kernels[nme]["share_of_step"],
+                                "bound": kernel_bound(nme, w["d"]), "peak": pk,
                                 "flops_alg_per_launch": launch_flops(nme), "frac": launch_flops(nme) / t / 1e12 / pk,
-                                "frac_executed": launch_flops(nme, kernel_flops_executed) / t / 1e12 / pk}
+                                "frac_executed": launch_flops(nme, kernel_flops_executed) / t / 1e12 / pk,
+                                # every kernel also against the plain f32 peak (the blocked_* kernels run on the bf16 matrix
+                                # cores through split operands and are priced against that route's own ceiling above)
+                                "frac_of_f32_peak": launch_flops(nme) / t / 1e12 / PEAK_FP32_TFLOPS}
     roof_peak = kernel_peak(roof_name)
     d, n_tot, k_tot = w["d"], w["n_total"], w["k_total"]
     f_alg_iter = float(n_tot) * k_tot * (8 * d * d + 12 * d)                   # SURVEY.md 8d (probes reported apart)
@@ -428,20 +482,24 @@ def main():
         if traffic is not None:
             break
     result = {
-        "metric": "samples_components_per_sec", "value": n_tot * k_tot / (elapsed / args.steps),
+        "metric": "samples_components_per_sec", "value": pairs_per_step / (elapsed / args.steps),
         "unit": "samples*components/s", "train_iter_per_sec": args.steps / elapsed,
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "ms_per_step_first": {"iterations": f"{args.warmup + 1}..{args.warmup + args.steps} of a fresh process", "ms": ms_per_step},
+        "ms_per_step_steady": {"iterations": f"{max(first_n, 225) + 1}..{max(first_n, 225) + steady_steps}", "ms": steady_ms},
         "higher_is_better": True, "scaling": "strong" if args.workload in STRONG_WORKLOADS else "weak", "vs_baseline": None, "dtype": "f64" if roof_name == "more_gram" else "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {w['kind']} target D={d}, K={k_tot} components "
                                f"({k_local}/GPU), {w['s']} samples/component, N={n_tot} samples/iter, SAMTRON "
-                               f"({w['cfg']['ng_estimator_type']}, fixed K, reuse ratio "
+                               f"({w['cfg']['ng_estimator_type']}, {'adaptive' if w['cfg']['num_component_adapter_type'] == 'adaptive' else 'fixed'} K, reuse ratio "
                                f"{w['cfg']['sample_selector_config']['ratio_reused_samples_to_desired']:g}, KL trust regions, "
                                f"improvement-based stepsizes)",
-                   "K": k_tot, "D": d, "N": n_tot, "parallelism": f"component-shard x{n_gpus}"},
-        "roofline": {"kernel": roof_name, "bound": "mfma", "achieved": achieved, "peak": roof_peak,
+                   "K": k_tot, "D": d, "N": n_tot, "parallelism": f"component-shard x{n_gpus}",
+                   **({"adaptive": k_span + "; value = mean N K of the timed iterations / time"} if k_span else {})},
+        "roofline": {"kernel": roof_name, "bound": kernel_bound(roof_name, d), "achieved": achieved, "peak": roof_peak,
                      "unit": "TFLOP/s", "frac": achieved / roof_peak, "traffic": traffic,
                      "avg_us": kernels[roof_name]["avg_us"], "flops_per_launch": fl,
                      "flops_executed_per_launch": launch_flops(roof_name, kernel_flops_executed),
+                     "frac_of_f32_peak": achieved / PEAK_FP32_TFLOPS,
                      "selection": "the launch with the largest share of the step time among the FLOP-carrying kernels"
                                   + ("" if roof_name == dominant else f" (dominant_kernel {dominant} is a latency chain without a "
                                      "per-pair FLOP figure)") + "; kernel_roofline prices every FLOP-carrying kernel the same way",

@@ -557,10 +557,11 @@ __device__ __forceinline__ void bgemm_ws_tile(const BG& g, const unsigned char* 
                           extA < (1ll << 29);
         if (fast) {
             // byte offsets of the pieces from the operand's place at (batch, k = kb); pieces outside the row range read piece 0
-            unsigned a_bo[2], p_bo[2], r_bo[2];
+            unsigned a_bo[2], a_b0[2], p_bo[2], r_bo[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 a_bo[u] = a_ok[u] ? 4u * (unsigned)(AK ? a_k[u] * g.lda + m0 + a_r[u] : (m0 + a_r[u]) * g.lda + a_k[u]) : 0u;
+                a_b0[u] = a_ok[u] ? 4u * (unsigned)(AK ? m0 + a_r[u] : (m0 + a_r[u]) * g.lda) : 0u;    // the same piece at k = kb
                 // prologue vector: along k (PRO 1, 3, 4) or along the rows (PRO 2); PRO 4: second vector along the rows
                 p_bo[u] = PRO == 2 ? 4u * (unsigned)(a_ok[u] ? m0 + a_r[u] : 0) : 4u * (unsigned)a_k[u];
                 r_bo[u] = 4u * (unsigned)(a_ok[u] ? m0 + a_r[u] : 0);
@@ -602,11 +603,12 @@ __device__ __forceinline__ void bgemm_ws_tile(const BG& g, const unsigned char* 
                         set_batch((long long)bz * (g.inner > 0 ? g.inner : 1) + ld_bi);
                     }
                 }
-                // a piece whose k lies behind ke reads the step-0 place of the same piece (valid memory), masked at the hand-over
+                // a piece whose k lies behind ke reads the piece of its row at k = kb (inside the operand whatever the length of
+                // the tile's k range: kb < ke), masked at the hand-over
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const unsigned ko = a_k[u] < klim[R] ? kofs : 0u;
-                    ra[R][u] = *reinterpret_cast<const float4*>(Ab + (a_bo[u] + ko * a_kstep));
+                    const unsigned at = a_k[u] < klim[R] ? a_bo[u] + kofs * a_kstep : a_b0[u];
+                    ra[R][u] = *reinterpret_cast<const float4*>(Ab + at);
                 }
 #pragma unroll
                 for (int u = 0; u < NCB; ++u) rb[R][u] = *reinterpret_cast<const i32x4*>(Bi + b_go[u]);
@@ -1429,12 +1431,11 @@ static int blk_threads_mm(int D) { return D <= 320 ? 64 * ((D + 31) / 32) : blk_
 
 // the factorisation kernels stage up to ~70 KB of LDS at D = 512: raise the dynamic limit once
 static int blk_lds_attr(gmmvi_ctx* ctx) {
-    static bool done = false;
-    if (done) return GMMVI_OK;
+    if (ctx->func_attr_done & 4u) return GMMVI_OK;          // per device: remembered per context
     const int lim = 156 * 1024;            // (the kernels also hold a few static words)
     GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_cholesky_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    done = true;
+    ctx->func_attr_done |= 4u;
     return GMMVI_OK;
 }
 
@@ -2495,25 +2496,21 @@ int gmmvi_blocked_update_kl(gmmvi_ctx* ctx, int K, int D, float* means, float* c
     }
     {
         const size_t lds_cols = ((size_t)3 * D + (size_t)2 * D * 64) * sizeof(float);
-        const bool in_lds = lds_cols <= 160 * 1024;
-        if (in_lds) {
-            static bool attr_done = false;
-            if (!attr_done) {
-                GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                         160 * 1024));
-                attr_done = true;
-            }
+        const bool in_lds = lds_cols <= 156 * 1024;           // (the kernel's static LDS words need room beside it)
+        if (in_lds && !(ctx->func_attr_done & 1u)) {           // the attribute is per DEVICE: remembered per context
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     156 * 1024));
+            ctx->func_attr_done |= 1u;
         }
         hipLaunchKernelGGL(blk_search_kernel, dim3(K), dim3(64), in_lds ? lds_cols : (size_t)3 * D * sizeof(float), ctx->stream, D,
                            td, te, wt, stepsizes, last_eta, temperature, in_lds ? nullptr : scratch, state);
     }
     GMMVI_LAUNCH_CHECK(ctx);
     {
-        static bool attr_done = false;
-        if (!attr_done) {
+        if (!(ctx->func_attr_done & 2u)) {                     // per device: remembered per context
             GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_upd_final_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-            attr_done = true;
+            ctx->func_attr_done |= 2u;
         }
         const size_t a = blk_trsm_lds_floats(D), b = blk_chol_lds_floats(D);
         hipLaunchKernelGGL(blk_upd_final_kernel, dim3(K), dim3(blk_threads_mm(D + 1)), (a > b ? a : b) * sizeof(float), ctx->stream, D,
@@ -2570,11 +2567,10 @@ int gmmvi_blocked_update_plain(gmmvi_ctx* ctx, int mode, int K, int D, float* me
                        means, stepsizes, num_updates, Sig, T2, Qp, vec);
     GMMVI_LAUNCH_CHECK(ctx);
     {
-        static bool attr_done = false;
-        if (!attr_done) {
+        if (!(ctx->func_attr_done & 2u)) {                     // per device: remembered per context
             GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blk_upd_final_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-            attr_done = true;
+            ctx->func_attr_done |= 2u;
         }
         const size_t a = blk_trsm_lds_floats(D), b = blk_chol_lds_floats(D);
         hipLaunchKernelGGL(blk_upd_final_kernel, dim3(K), dim3(blk_threads_mm(D + 1)), (a > b ? a : b) * sizeof(float), ctx->stream, D,

@@ -69,6 +69,7 @@ struct gmmvi_ctx {
     void* comm = nullptr;        // ncclComm_t
     int n_ranks = 1, rank = 0;
     int num_cus = 256;
+    unsigned func_attr_done = 0; // bits: per-device kernel attributes (dynamic LDS above 64 KB) already set for this context's device
     // optional per-kernel HIP-event timing (bench.py roofline leg): events are recorded on ctx->stream
     bool prof = false;
     const char* prof_tag = nullptr;   // set by a caller that knows which sweep of the iteration a density launch is (fused.hip)

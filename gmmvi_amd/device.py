@@ -24,8 +24,10 @@ class Context:
         if device is None:
             device = int(os.environ.get("GMMVI_DEVICE", os.environ.get("LOCAL_RANK", "0")))
             n = lib.gmmvi_device_count()
-            if n > 0:
-                device %= n
+            if n > 0 and device >= n:
+                # never wrap: two ranks on one device would only fail later, inside RCCL, with "duplicate device"
+                raise _lib.GmmviError(f"rank-local device index {device} (GMMVI_DEVICE / LOCAL_RANK) but this process sees only "
+                                      f"{n} GPU(s): start one rank per visible GPU")
         h = C.c_void_p()
         rc = lib.gmmvi_ctx_create(C.byref(h), int(device))
         if rc != 0:

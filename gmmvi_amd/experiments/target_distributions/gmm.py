@@ -81,8 +81,8 @@ class GMM_LNPDF(LNPDF):
         return {"num_detected_modes": num_detected}
 
 
-def make_target(num_dimensions):
-    """gmm.py:123-145 (global NumPy RNG, as the reference)."""
+def make_target_parameters(num_dimensions):
+    """The parameter law of gmm.py:123-145 (global NumPy RNG, as the reference): host arrays only."""
     num_true_components = 10
     weights = np.ones(num_true_components) / num_true_components
     means = np.empty((num_true_components, num_dimensions))
@@ -91,11 +91,16 @@ def make_target(num_dimensions):
         means[i] = 100 * (np.random.random(num_dimensions) - 0.5)
         a = 0.1 * np.random.normal(0, num_dimensions, (num_dimensions, num_dimensions))
         covs[i] = a.T @ a + np.eye(num_dimensions)
-    return GMM_LNPDF(weights, means, covs)
+    return weights, means, covs
 
 
-def make_target_with_scale(num_dimensions, num_components, scale):
-    """gmm.py:148-162."""
+def make_target(num_dimensions):
+    """gmm.py:123-145."""
+    return GMM_LNPDF(*make_target_parameters(num_dimensions))
+
+
+def make_target_with_scale_parameters(num_dimensions, num_components, scale):
+    """The parameter law of gmm.py:148-162: host arrays only."""
     weights = np.ones(num_components) / num_components
     means = np.empty((num_components, num_dimensions))
     covs = np.empty((num_components, num_dimensions, num_dimensions))
@@ -103,4 +108,9 @@ def make_target_with_scale(num_dimensions, num_components, scale):
         means[i] = 100 * (np.random.random(num_dimensions) - 0.5)
         a = np.random.normal(0, np.sqrt(scale), (num_dimensions, num_dimensions))
         covs[i] = a.T @ a + np.eye(num_dimensions)
-    return GMM_LNPDF(weights, means, covs)
+    return weights, means, covs
+
+
+def make_target_with_scale(num_dimensions, num_components, scale):
+    """gmm.py:148-162."""
+    return GMM_LNPDF(*make_target_with_scale_parameters(num_dimensions, num_components, scale))

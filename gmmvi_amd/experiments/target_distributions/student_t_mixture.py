@@ -36,10 +36,8 @@ class StudentTMixture_LNPDF(GMM_LNPDF):
         return (self.target_means[comp] + np.einsum('nij,nj->ni', chols[comp], eps) / np.sqrt(g)[:, None]).astype(np.float32)
 
 
-def make_target(num_dimensions, harder_setting, use_matlab_target=False):
-    """student_t_mixture.py:138-194 (the MATLAB known-answer data of the reference is not shipped, :171-193)."""
-    if use_matlab_target:
-        raise ValueError("the MATLAB target data is not shipped with the reference (student_t_mixture.py:171-193)")
+def make_target_parameters(num_dimensions, harder_setting):
+    """The parameter law of student_t_mixture.py:153-169 (global NumPy RNG, as the reference): host arrays only."""
     s, num_components = (25, 20) if harder_setting else (20, 10)
     weights = np.ones(num_components) / num_components
     means = np.empty((num_components, num_dimensions))
@@ -48,4 +46,11 @@ def make_target(num_dimensions, harder_setting, use_matlab_target=False):
         means[i] = np.random.uniform(0, 1, num_dimensions) * (2 * s) - s
         a = 0.1 * num_dimensions * np.random.normal(0, 1, (num_dimensions, num_dimensions))
         covs[i] = np.linalg.inv(a.T @ a + np.eye(num_dimensions))
-    return StudentTMixture_LNPDF(weights, means, covs)
+    return weights, means, covs
+
+
+def make_target(num_dimensions, harder_setting, use_matlab_target=False):
+    """student_t_mixture.py:138-194 (the MATLAB known-answer data of the reference is not shipped, :171-193)."""
+    if use_matlab_target:
+        raise ValueError("the MATLAB target data is not shipped with the reference (student_t_mixture.py:171-193)")
+    return StudentTMixture_LNPDF(*make_target_parameters(num_dimensions, harder_setting))

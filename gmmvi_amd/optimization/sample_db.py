@@ -26,10 +26,21 @@ class _Growable:
         stop = self.n if stop is None else stop
         return self.buf.rows(start, stop)
 
+    # the first allocation holds FIRST_APPENDS appends of the first one's size (at most FIRST_BYTES): a run of a few hundred
+    # iterations then never re-allocates -- a doubling is a hipMalloc (host-synchronous) plus a copy of everything so far, and a
+    # short timed window that happens to contain one reads several percent slower (bench.py: 20 steps against 200)
+    FIRST_APPENDS, FIRST_BYTES = 256, 1 << 30
+
     def reserve(self, m):
         if self.n + m > self.buf.shape[0]:
             cap = max(2 * self.buf.shape[0], self.n + m, 1024)
+            if self.buf.shape[0] == 0:
+                row_bytes = int(np.prod(self.inner, dtype=np.int64)) * np.dtype(self.dtype).itemsize
+                cap = max(cap, min(self.FIRST_APPENDS * m, self.FIRST_BYTES // max(1, row_bytes)))
             new = self.ctx.empty((cap,) + self.inner, self.dtype)
+            if self.buf.shape[0] == 0 and new.size and np.dtype(self.dtype).itemsize == 4:
+                # touch the pages now (one fill on the stream) instead of while the appends walk through them
+                self.ctx.check(self.ctx.lib.gmmvi_fill_f32(self.ctx.handle, new.ptr, 0.0, new.size))
             if self.n:
                 new.rows(0, self.n).copy_from(self.buf.rows(0, self.n))
             self.buf = new

@@ -17,7 +17,10 @@ pytestmark = pytest.mark.gpu
 # (3, 201, 150) and (2, 161, 600): wide enough for the split-operand route of the contractions (>= 160 columns) with rows that are
 # NOT multiples of 16 bytes -- its element-wise staging route; (4, 300, 200) / (2, 512, 140): its aligned route; the others run
 # the f32 matrix-core route for the triangular launches (csrc/blocked.hip: bgemm_use_split)
-DIMS = [(3, 72, 300), (2, 130, 257), (4, 300, 200), (1, 65, 10), (2, 512, 140), (3, 201, 150), (2, 161, 600)]
+# (2, 324, 200) / (2, 332, 130): a second column tile whose k range is SHORTER than one 16-wide staging step (324 - 320 = 4):
+# pieces of the fast staging route that lie behind the end of the range must read inside the operand
+DIMS = [(3, 72, 300), (2, 130, 257), (4, 300, 200), (1, 65, 10), (2, 512, 140), (3, 201, 150), (2, 161, 600), (2, 324, 200),
+        (2, 332, 130)]
 
 
 @pytest.fixture(scope="module")
