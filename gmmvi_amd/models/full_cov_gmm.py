@@ -37,6 +37,12 @@ class FullCovGMM(GMM):
         chol = np.asarray(chol)
         return 0.5 * self.num_dimensions * (np.log(2 * np.pi) + 1) + np.sum(np.log(np.diag(chol)))
 
+    def component_entropies(self):
+        """gmm.py:249-261 for all components at once (one row-wise reduction instead of a Python loop over K: 0.8 ms per call at
+        K = 170, called by every add of the adaptive configurations)."""
+        diag = np.ascontiguousarray(np.diagonal(self.chol_cov.numpy(), axis1=1, axis2=2))
+        return (0.5 * self.num_dimensions * (np.log(2 * np.pi) + 1) + np.sum(np.log(diag), axis=1)).astype(np.float32)
+
     def component_log_densities(self, samples):
         """full_cov_gmm.py:56-62 -> [K, N]."""
         ld, _, _ = hip_ops.mixture_eval(self.ctx, self.packed, self.log_weights, self._x(samples), self.num_dimensions,

@@ -11,6 +11,9 @@ NAMES = [  # (substring of the kernel instance name, bench.py kernel name); firs
     # sweep = model log-value instance, target = the other family / the per-wave matrix-core instance at D = 50)
     ("mixture_eval_kernel<20, 1, true", "sweep_target"), ("mixture_eval_kernel<10, 1, true", "sweep_target"),
     ("mixture_eval_mfma_ws_kernel<50, 0, true", "sweep_dual"), ("mixture_eval_mfma_kernel<50, 0, true", "sweep_target"), ("mixture_eval_mfma_kernel<50, 0, false", "sweep_post"),
+    ("mixture_eval_pk_kernel<20, 0, true", "sweep_dual"), ("mixture_eval_pk_kernel<20, 0, false", "sweep_post"),
+    ("mixture_eval_pk_kernel<10, 0, true", "sweep_dual"), ("mixture_eval_pk_kernel<10, 0, false", "sweep_post"),
+    ("elr_riders_kernel", "expected_log_ratios"),
     ("mixture_eval_kernel<20, 0, true", "sweep_dual"), ("mixture_eval_kernel<20, 0, false", "sweep_post"),
     ("mixture_eval_kernel<10, 0, true", "sweep_dual"), ("mixture_eval_kernel<10, 0, false", "sweep_post"),
     ("update_kl_fast_kernel", "update_kl"), ("combine_partials_kernel", "mixture_combine"),
