@@ -494,6 +494,11 @@ def main():
                                f"{w['cfg']['sample_selector_config']['ratio_reused_samples_to_desired']:g}, KL trust regions, "
                                f"improvement-based stepsizes)",
                    "K": k_tot, "D": d, "N": n_tot, "parallelism": f"component-shard x{n_gpus}",
+                   # which code path issued the iterations: the launches are the same on the first two
+                   "path": ("single C call per iteration (gmmvi_train_iter_samtron)" if getattr(getattr(algo, "_fast_path", None), "eligible", lambda: False)()
+                            else "four C calls per iteration with an all-gather between them (gmmvi_train_iter_sharded_phase)"
+                            if getattr(algo, "_fast", None) is not None
+                            else "module-by-module plug-in calls"),
                    **({"adaptive": k_span + "; value = mean N K of the timed iterations / time"} if k_span else {})},
         "roofline": {"kernel": roof_name, "bound": kernel_bound(roof_name, d), "achieved": achieved, "peak": roof_peak,
                      "unit": "TFLOP/s", "frac": achieved / roof_peak, "traffic": traffic,

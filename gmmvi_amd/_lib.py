@@ -98,6 +98,8 @@ _PROTOS = {
     "gmmvi_component_stepsize_improvement": (_i, [_p, _i, _p, _p, _p, _f, _f, _f, _f]),
     "gmmvi_weight_stepsize_improvement": (_i, [_p, _i, _p, _p, _p, _f, _f, _f, _f]),
     "gmmvi_train_iter_samtron": (_i, [_p, _p]),
+    "gmmvi_sharded_scratch_floats": (_sz, [_i, _i, _i]),
+    "gmmvi_train_iter_sharded_phase": (_i, [_p, _p, _i]),
     "gmmvi_comm_unique_id": (_i, [C.c_char_p]),
     "gmmvi_comm_init": (_i, [_p, C.c_char_p, _i, _i]),
     "gmmvi_comm_destroy": (_i, [_p]),

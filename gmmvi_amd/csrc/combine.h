@@ -52,12 +52,16 @@ __device__ __forceinline__ void combine_element_n(const CombineJob& j, long e) {
     if (e >= (long)j.N * width) return;
     const int n = (int)(e / width), i = (int)(e - (long)n * width);
     const int Rr = R > 0 ? R : j.R;
+    // distance between the parts of consecutive chunks / ranks: N values (N * D gradient entries) unless the parts sit inside a
+    // gathered exchange buffer (fused.hip: sharded iteration)
+    const int ps = j.part_stride > 0 ? (int)j.part_stride : j.N;
+    const size_t gs = j.part_stride > 0 ? (size_t)j.part_stride : (size_t)j.N * j.D;
     float lp;
-    if constexpr (R > 0) lp = combine_log_values_n<R>(j.lp_parts, j.N, n); else lp = combine_log_values(j.lp_parts, Rr, j.N, n);
+    if constexpr (R > 0) lp = combine_log_values_n<R>(j.lp_parts, ps, n); else lp = combine_log_values(j.lp_parts, Rr, ps, n);
     if (j.lp_out && i == 0) j.lp_out[n] = lp;
     if (j.lp2_out && j.lp2_parts && i == (width > 1 ? 1 : 0)) {
-        if constexpr (R > 0) j.lp2_out[n] = combine_log_values_n<R>(j.lp2_parts, j.N, n);
-        else j.lp2_out[n] = combine_log_values(j.lp2_parts, Rr, j.N, n);
+        if constexpr (R > 0) j.lp2_out[n] = combine_log_values_n<R>(j.lp2_parts, ps, n);
+        else j.lp2_out[n] = combine_log_values(j.lp2_parts, Rr, ps, n);
     }
     if (with_grad) {
         float g = 0.f;
@@ -65,14 +69,14 @@ __device__ __forceinline__ void combine_element_n(const CombineJob& j, long e) {
             float lv[R], gv[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                lv[r] = j.lp_parts[(size_t)r * j.N + n];
-                gv[r] = j.grad_parts[((size_t)r * j.N + n) * j.D + i];
+                lv[r] = j.lp_parts[(size_t)r * ps + n];
+                gv[r] = j.grad_parts[(size_t)r * gs + (size_t)n * j.D + i];
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) g = fmaf(__expf(lv[r] - lp), gv[r], g);
         } else {
             for (int r = 0; r < Rr; ++r)
-                g = fmaf(__expf(j.lp_parts[(size_t)r * j.N + n] - lp), j.grad_parts[((size_t)r * j.N + n) * j.D + i], g);
+                g = fmaf(__expf(j.lp_parts[(size_t)r * ps + n] - lp), j.grad_parts[(size_t)r * gs + (size_t)n * j.D + i], g);
         }
         j.grad_out[(size_t)n * j.D + i] = g;
     }

@@ -19,11 +19,11 @@ __global__ __launch_bounds__(256) void combine_partials_kernel(CombineJob j) {
 // C++ linkage (common.h): gmmvi_combine_partials plus an optional second set of log-value partials (dual mixture sweep)
 int gmmvi_combine_partials_internal(gmmvi_ctx* ctx, int R, int N, int D, const float* lp_parts_dev,
                                     const float* grad_parts_dev, float* lp_out_dev, float* grad_out_dev,
-                                    const float* lp2_parts_dev, float* lp2_out_dev) {
-    GMMVI_ARG_CHECK(ctx, R >= 1 && N >= 0 && D >= 1 && lp_parts_dev);
+                                    const float* lp2_parts_dev, float* lp2_out_dev, long part_stride) {
+    GMMVI_ARG_CHECK(ctx, R >= 1 && N >= 0 && D >= 1 && lp_parts_dev && part_stride >= 0);
     if (N == 0) return GMMVI_OK;
     CombineJob j;
-    j.R = R; j.N = N; j.D = D;
+    j.R = R; j.N = N; j.D = D; j.part_stride = part_stride;
     j.lp_parts = lp_parts_dev; j.grad_parts = grad_parts_dev; j.lp2_parts = lp2_parts_dev;
     j.lp_out = lp_out_dev; j.grad_out = grad_out_dev; j.lp2_out = lp2_parts_dev ? lp2_out_dev : nullptr;
     const long elems = (long)N * ((grad_out_dev && grad_parts_dev) ? D : 1);

@@ -13,6 +13,7 @@
 // launch carry it (density.hip defers, the target / expected-log-ratio launches take it)
 struct CombineJob {
     int R = 0, N = 0, D = 0;
+    long part_stride = 0;                 // floats between the parts of consecutive chunks (0: N log values, N * D gradient entries)
     int first_block = 0, blocks = 0;      // set by the carrying launcher
     const float* lp_parts = nullptr;
     const float* grad_parts = nullptr;
@@ -130,7 +131,7 @@ int gmmvi_sample_components_prep(gmmvi_ctx* ctx, int K, int D, const float* mean
 // comm.hip: gmmvi_combine_partials plus an optional second set of log-value partials
 int gmmvi_combine_partials_internal(gmmvi_ctx* ctx, int R, int N, int D, const float* lp_parts_dev,
                                     const float* grad_parts_dev, float* lp_out_dev, float* grad_out_dev,
-                                    const float* lp2_parts_dev, float* lp2_out_dev);
+                                    const float* lp2_parts_dev, float* lp2_out_dev, long part_stride = 0);
 // comm.hip: deferred merges.  reserve: room for the partials (no merge may be pending); flush: launch a pending merge on its
 // own; take: hand a pending merge to a launch of `threads` threads per workgroup whose own workgroups end at `first_block`
 int gmmvi_defer_reserve(gmmvi_ctx* ctx, size_t nbytes);

@@ -202,3 +202,163 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
     }
     return GMMVI_OK;
 }
+
+
+// ---- component shards: the iteration in four phases with an all-gather between them (include/gmmvi_hip.h) ---------------
+namespace {
+struct ShardArena { float *ld, *lq, *bg, *qgrad, *H, *g, *E; int32_t* success; };
+}
+extern "C" size_t gmmvi_sharded_scratch_floats(int K, int D, int N) {
+    if (K < 1 || D < 1 || N < 1) return 0;
+    return (size_t)K * N + 2 * (size_t)N + (size_t)N * D + (size_t)K * D * D + (size_t)K * D + 2 * (size_t)K + 64;
+}
+static void shard_arena(float* base, int K, int D, int N, ShardArena& a) {
+    a.ld = base; base += (size_t)K * N;
+    a.lq = base; base += N;
+    a.bg = base; base += N;
+    a.qgrad = base; base += (size_t)N * D;
+    a.H = base; base += (size_t)K * D * D;
+    a.g = base; base += (size_t)K * D;
+    a.E = base; base += K;
+    a.success = (int32_t*)base;
+}
+
+static int sharded_phase_body(gmmvi_ctx* ctx, const gmmvi_sharded_plan* p, int phase) {
+    const int R = p->n_ranks, K = p->K, D = p->D, N = p->N;
+    const int Nl = N / R, Kt = K * R;
+    const size_t s1 = (size_t)Nl * (2 * D + 1) + 2 * (size_t)K, s2 = (size_t)N * (D + 2), s3 = (size_t)N;
+    float* my1 = p->e1 + (size_t)p->rank * s1;         // x_loc | tlp_loc | tgrad_loc | E_loc | reward_loc
+    float* x_loc = my1;
+    float* tlp_loc = my1 + (size_t)Nl * D;
+    float* tgrad_loc = tlp_loc + Nl;
+    float* E_loc = tgrad_loc + (size_t)Nl * D;
+    float* reward_loc = E_loc + K;
+    float* my2 = p->e2 + (size_t)p->rank * s2;         // bg_part | lq_part | qgrad_part
+    float* my3 = p->e3 + (size_t)p->rank * s3;
+    float* logw_loc = p->logw_all + (size_t)p->rank * K;
+    ShardArena a;
+    shard_arena(p->scratch, K, D, N, a);
+    const int max_pc = p->max_per_component > 0 ? p->max_per_component : (Nl + K - 1) / K;
+    if (phase == 1) {
+        // ---- the local draw and its target evaluation, written where the first exchange picks them up -----------------------
+        if (!p->presampled)
+            GMMVI_TRY(gmmvi_sample_components_bounded(ctx, K, D, p->means, p->chols, p->offsets, Nl, max_pc, p->seed, p->first_index, 0,
+                                                      nullptr, x_loc, nullptr));
+        if (p->target_kind == 1) {
+            GMMVI_TRY(gmmvi_target_planar(ctx, D, p->planar_prior_std, p->planar_goals_count, p->planar_goals,
+                                          p->planar_likelihood_std, x_loc, Nl, tlp_loc, tgrad_loc));
+        } else {
+            ctx->prof_tag = "sweep_target";
+            int rc_t = gmmvi_mixture_eval(ctx, p->target_family, p->target_nu, p->target_K, D, p->target_packed, p->target_logw,
+                                          x_loc, Nl, nullptr, tlp_loc, tgrad_loc);
+            ctx->prof_tag = nullptr;
+            GMMVI_TRY(rc_t);
+        }
+        return GMMVI_OK;
+    }
+    if (phase == 2) {
+        // ---- de-interleave the first exchange (one rank: the parts ARE the gathered arrays when the caller aliased them) ------
+        const bool aliased = R == 1 && p->x_all == x_loc && p->tlp_all == tlp_loc && p->tgrad_all == tgrad_loc &&
+                             p->E_all == E_loc && p->reward_all == reward_loc;
+        if (!aliased) {
+            const size_t words[5] = {(size_t)Nl * D, (size_t)Nl, (size_t)Nl * D, (size_t)K, (size_t)K};
+            void* const dst[5] = {p->x_all, p->tlp_all, p->tgrad_all, p->E_all, p->reward_all};
+            GMMVI_TRY(gmmvi_unpack_gathered(ctx, p->e1, R, s1, 5, words, dst));
+        }
+        // ---- the previous iteration's weight step, replicated (weight_updater.py:56-100, gmm_wrapper.py:150-160) --------------
+        if (p->has_pending) {
+            GMMVI_HIP_CHECK(ctx, hipMemcpyAsync(p->reward_col_pending, p->reward_all, (size_t)Kt * sizeof(float),
+                                                hipMemcpyDeviceToDevice, ctx->stream));
+            if (Kt > 1)
+                GMMVI_TRY(gmmvi_update_weights_internal(ctx, 0, Kt, p->logw_all, p->E_all, p->wstate, p->temperature, nullptr, nullptr));
+        }
+        // ---- stepsize rules: components local, weights over all components (iter_prep.h); they ride in the dual sweep when that
+        // launch has room, else their own small launch
+        {
+            PrepArgs q{};
+            q.K = K; q.cs_mode = p->component_stepsize_mode; q.stepsizes = p->stepsizes;
+            q.reward_prev = p->reward_prev; q.reward_last = p->reward_last;
+            q.cs_min = p->cs_min; q.cs_max = p->cs_max; q.cs_inc = p->cs_inc; q.cs_dec = p->cs_dec;
+            q.ws_mode = p->weight_stepsize_mode; q.logw = p->logw_all; q.wstate = p->wstate;
+            q.ws_min = p->ws_min; q.ws_max = p->ws_max; q.ws_inc = p->ws_inc; q.ws_dec = p->ws_dec;
+            q.ws_K = Kt; q.ws_reward_last = p->reward_last_all;
+            ctx->riders.prep = q;
+            ctx->riders.prep_blocks = 1;
+            GMMVI_TRY(gmmvi_flush_pending_riders(ctx));
+        }
+        // ---- dual sweep over the local components on all samples; its partials are this rank's part of the second exchange ----
+        float* bg_out = R > 1 ? my2 : a.bg;
+        float* lq_out = R > 1 ? my2 + N : a.lq;
+        float* qg_out = R > 1 ? my2 + 2 * (size_t)N : a.qgrad;
+        ctx->prof_tag = "sweep_dual";
+        int rc_dual = gmmvi_mixture_eval_dual(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed, logw_loc, p->bg_logw, p->x_all, N, a.ld,
+                                              lq_out, qg_out, bg_out);
+        ctx->prof_tag = nullptr;
+        return rc_dual;
+    }
+    if (phase == 3) {
+        if (R > 1) {
+            // merge of the ranks' partials: log q and its gradient, the background as the second set of log values
+            GMMVI_PROF(ctx, "mixture_combine");
+            GMMVI_TRY(gmmvi_combine_partials_internal(ctx, R, N, D, p->e2 + N, p->e2 + 2 * (size_t)N, a.lq, a.qgrad, p->e2, a.bg,
+                                                      (long)s2));
+        }
+        SteinSlab slab{nullptr, nullptr, 0};
+        GMMVI_TRY(gmmvi_stein_partials(ctx, K, D, p->packed, p->x_all, N, a.ld, a.qgrad, a.bg, p->tgrad_all, p->stein_flags, &slab));
+        GMMVI_TRY(gmmvi_update_components_kl_from_slab(ctx, K, D, slab, N, p->stein_flags, p->packed, a.H, a.g, p->means, p->chols,
+                                                       p->stepsizes, p->temperature, p->l2_init, p->last_eta, p->l2, p->num_updates,
+                                                       p->success_out ? p->success_out : a.success, p->packed_new));
+        // post-update sweep: one rank leaves the merge of its chunk partials to the expected-log-ratio kernel (phase 4); with
+        // more ranks the merged local log q is what travels
+        ctx->defer_combine = R == 1;
+        ctx->prof_tag = "sweep_post";
+        int rc_post = gmmvi_mixture_eval(ctx, GMMVI_GAUSS, 0.f, K, D, p->packed_new, logw_loc, p->x_all, N, a.ld,
+                                         R > 1 ? my3 : a.lq, nullptr);
+        ctx->defer_combine = false;
+        ctx->prof_tag = nullptr;
+        return rc_post;
+    }
+    // ---- phase 4: expected log-ratios / rewards of the local components; with more ranks the gathered log q partials are merged
+    // while they are read (the kernel's chunk-partial form: [R][N])
+    if (R > 1) {
+        GMMVI_TRY(gmmvi_flush_pending_combine(ctx));
+        ctx->pending.R = R; ctx->pending.N = N; ctx->pending.D = D;
+        ctx->pending.lp_parts = p->e3; ctx->pending.lp_out = a.lq;
+    }
+    if (p->presample_next) {
+        // the next iteration's local draw from the updated components, into this rank's part of the first exchange buffer: nothing
+        // reads that part any more (x was de-interleaved in phase 2; one rank with aliased views: the sweeps and the Stein estimate
+        // are done, this launch reads log values only)
+        SampleJob& sj = ctx->riders.sample;
+        sj.K = K; sj.D = D; sj.uniform_count = (long)K * max_pc == Nl ? max_pc : 0;
+        sj.means = p->means; sj.chols = p->chols; sj.offsets = p->offsets;
+        sj.seed = p->seed; sj.first_index = p->first_index + (uint64_t)N;
+        sj.X = x_loc; sj.mapping = nullptr; sj.mapping_base = 0;
+        ctx->riders.sample_blocks = K * ((max_pc + 255) / 256);
+    }
+    GMMVI_TRY(gmmvi_expected_log_ratios(ctx, K, N, a.ld, a.bg, p->tlp_all, a.lq, p->temperature, logw_loc,
+                                        (p->stein_flags & GMMVI_SELF_NORMALIZED) ? 1 : 0, E_loc, reward_loc, nullptr));
+    GMMVI_TRY(gmmvi_flush_pending_riders(ctx));
+    return GMMVI_OK;
+}
+
+extern "C" int gmmvi_train_iter_sharded_phase(gmmvi_ctx* ctx, const gmmvi_sharded_plan* p, int phase) {
+    GMMVI_ARG_CHECK(ctx, ctx != nullptr && p != nullptr && phase >= 1 && phase <= 4);
+    GMMVI_ARG_CHECK(ctx, p->n_ranks >= 1 && p->rank >= 0 && p->rank < p->n_ranks && p->K >= 1 && p->D >= 1 && p->D < GMMVI_MAX_DIM &&
+                             p->N >= p->n_ranks && p->N % p->n_ranks == 0);
+    GMMVI_ARG_CHECK(ctx, p->means && p->chols && p->packed && p->packed_new && p->stepsizes && p->last_eta && p->l2 && p->num_updates &&
+                             p->logw_all && p->bg_logw && p->offsets && p->e1 && p->e2 && p->e3 && p->x_all && p->tlp_all &&
+                             p->tgrad_all && p->E_all && p->reward_all && p->wstate && p->reward_prev && p->reward_last &&
+                             p->reward_last_all && p->scratch);
+    GMMVI_ARG_CHECK(ctx, !p->has_pending || p->reward_col_pending != nullptr);
+    int rc = GMMVI_OK;
+    if (phase != 4) rc = gmmvi_flush_pending_combine(ctx);     // (phase 4 consumes the merge phase 3 left for it)
+    if (rc == GMMVI_OK) rc = sharded_phase_body(ctx, p, phase);
+    if (rc != GMMVI_OK) {
+        ctx->pending = CombineJob();
+        ctx->riders.prep_blocks = ctx->riders.sample_blocks = 0;
+        ctx->defer_combine = false;
+        ctx->prof_tag = nullptr;
+    }
+    return rc;
+}

@@ -14,6 +14,9 @@ struct PrepArgs {
     int K; int cs_mode; float* stepsizes; const float* reward_prev; const float* reward_last;
     float cs_min, cs_max, cs_inc, cs_dec;
     int ws_mode; const float* logw; float* wstate; float ws_min, ws_max, ws_inc, ws_dec;
+    // component shards (fused.hip: sharded iteration): the weight-stepsize rule runs over ALL ws_K components with its own
+    // reward column (0 / NULL: K and reward_last, the unsharded case)
+    int ws_K; const float* ws_reward_last;
 };
 
 // block 0 of n_blocks: the O(K) stepsize rules (wave 0 also runs the weight-stepsize reduction); blocks >= 1: copies.
@@ -25,7 +28,8 @@ __device__ __forceinline__ void iter_prep_block(const PrepArgs& a, int block, in
                 a.stepsizes[k] = component_stepsize_rule(a.stepsizes[k], a.reward_prev[k], a.reward_last[k], a.cs_min,
                                                          a.cs_max, a.cs_inc, a.cs_dec);
         if (a.ws_mode == 1 && threadIdx.x < 64)
-            weight_stepsize_wave(a.K, a.logw, a.reward_last, a.wstate, a.ws_min, a.ws_max, a.ws_inc, a.ws_dec, threadIdx.x);
+            weight_stepsize_wave(a.ws_K > 0 ? a.ws_K : a.K, a.logw, a.ws_reward_last ? a.ws_reward_last : a.reward_last, a.wstate,
+                                 a.ws_min, a.ws_max, a.ws_inc, a.ws_dec, threadIdx.x);
         if (n_blocks > 1) return;                      // a single block does the copies as well
     }
     const int copy_blocks = n_blocks > 1 ? n_blocks - 1 : 1;

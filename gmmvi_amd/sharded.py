@@ -32,6 +32,32 @@ import numpy as np
 FLOAT32_MIN = float(np.finfo(np.float32).min)
 
 
+import ctypes as _C
+
+_f, _i, _p = _C.c_float, _C.c_int32, _C.c_void_p
+
+
+class ShardedPlan(_C.Structure):
+    """struct gmmvi_sharded_plan (include/gmmvi_hip.h)."""
+    _fields_ = [
+        ("n_ranks", _i), ("rank", _i), ("K", _i), ("D", _i), ("N", _i),
+        ("target_kind", _i), ("target_family", _i), ("target_K", _i), ("target_nu", _f),
+        ("target_packed", _p), ("target_logw", _p), ("planar_prior_std", _p), ("planar_goals", _p),
+        ("planar_goals_count", _i), ("planar_likelihood_std", _f),
+        ("means", _p), ("chols", _p), ("packed", _p), ("packed_new", _p),
+        ("stepsizes", _p), ("last_eta", _p), ("l2", _p), ("num_updates", _p), ("success_out", _p),
+        ("logw_all", _p), ("bg_logw", _p), ("offsets", _p), ("max_per_component", _i),
+        ("seed", _C.c_uint64), ("first_index", _C.c_uint64),
+        ("e1", _p), ("e2", _p), ("e3", _p),
+        ("x_all", _p), ("tlp_all", _p), ("tgrad_all", _p), ("E_all", _p), ("reward_all", _p),
+        ("has_pending", _i), ("reward_col_pending", _p), ("reward_prev", _p), ("reward_last", _p), ("reward_last_all", _p),
+        ("wstate", _p), ("temperature", _f), ("l2_init", _f),
+        ("component_stepsize_mode", _i), ("cs_min", _f), ("cs_max", _f), ("cs_inc", _f), ("cs_dec", _f),
+        ("weight_stepsize_mode", _i), ("ws_min", _f), ("ws_max", _f), ("ws_inc", _f), ("ws_dec", _f),
+        ("stein_flags", _i), ("presample_next", _i), ("presampled", _i), ("scratch", _p),
+    ]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # GPU back end
 # ---------------------------------------------------------------------------------------------------------------------
@@ -162,6 +188,10 @@ class RcclExchange:
         self.ctx.check(self.ctx.lib.gmmvi_allgather_f32(self.ctx.handle, arr.ptr, out.ptr, arr.size))
         return out
 
+    def allgather_inplace(self, buf, count):
+        """``buf`` holds n_ranks parts of ``count`` floats; this rank's part is filled: gather the others in place."""
+        self.ctx.check(self.ctx.lib.gmmvi_allgather_f32(self.ctx.handle, buf.ptr + 4 * count * self.rank, buf.ptr, count))
+
     def barrier(self):
         self._scalar.set(np.zeros(1, np.float32))
         self.ctx.check(self.ctx.lib.gmmvi_allreduce_f32(self.ctx.handle, self._scalar.ptr, 1, 0))
@@ -179,6 +209,9 @@ class LocalExchange:
 
     def allgather(self, arr):
         return arr
+
+    def allgather_inplace(self, buf, count):
+        pass
 
     def barrier(self):
         pass
@@ -224,6 +257,9 @@ class ShardedGMMVI:
         self.num_updates = 0
         self.last_success = None
         self.packed = None                         # packed blocks of the local components (kept up to date by update_kl)
+        self._fast = None
+        if isinstance(ops, HipOps) and os.environ.get("GMMVI_FAST_PATH", "1") != "0":
+            self._setup_phased(cfg)
 
     @staticmethod
     def _check_scope(cfg):
@@ -282,7 +318,110 @@ class ShardedGMMVI:
             e, reward = e_loc, reward_loc
         self._apply_weight_step(e, reward)
 
+    # ---- the iteration as four C calls with an all-gather between them (gmmvi_train_iter_sharded_phase) --------------------------
+    def _setup_phased(self, cfg):
+        """Buffers and the plan of the phased C iteration: the SAME launches as the single-GPU single-call iteration (packed
+        sweeps with carried merges, Stein slab whitened inside the update kernel, the next draw as riders), the exchanges issued
+        from here.  Built-in targets and register-path dimensions only; anything else keeps the module-by-module path below."""
+        from . import _lib, hip_ops
+        ctx, tgt = self.ops.ctx, self.ops.target
+        if not hasattr(tgt, "_fast_path_target") or self.d > _lib.blocked_above() or self.d >= _lib.MAX_DIM:
+            return
+        if not hasattr(self.exchange, "allgather_inplace"):
+            return
+        snis = bool(cfg["ng_estimator_config"].get("use_self_normalized_importance_weights", True))
+        if bool(cfg["weight_updater_config"].get("use_self_normalized_importance_weights", True)) != snis:
+            return
+        if cfg.get("weight_updater_type", "trust-region") != "trust-region":
+            return
+        R, K, D, N, Nl, Kt = self.R, self.Kl, self.d, self.N, self.Nl, self.K
+        s1, s2 = Nl * (2 * D + 1) + 2 * K, N * (D + 2)
+        f = type("PhasedState", (), {})()
+        f.s1, f.s2 = s1, s2
+        f.e1, f.e2, f.e3 = ctx.zeros((R * s1,)), ctx.empty((R * s2,)), ctx.empty((R * N,))
+        part = f.e1.rows(self.rank * s1, (self.rank + 1) * s1)
+        f.E_loc, f.reward_loc = part.rows(Nl * (2 * D + 1), Nl * (2 * D + 1) + K), part.rows(Nl * (2 * D + 1) + K, s1)
+        if R == 1:                                     # the parts ARE the gathered arrays
+            f.x_all, f.tlp_all = part.rows(0, N * D), part.rows(N * D, N * D + N)
+            f.tgrad_all = part.rows(N * D + N, N * (2 * D + 1))
+            f.E_all, f.reward_all = f.E_loc, f.reward_loc
+        else:
+            f.x_all, f.tlp_all, f.tgrad_all = ctx.empty((N * D,)), ctx.empty((N,)), ctx.empty((N * D,))
+            f.E_all, f.reward_all = ctx.empty((Kt,)), ctx.empty((Kt,))
+        f.scratch = ctx.empty((int(ctx.lib.gmmvi_sharded_scratch_floats(K, D, N)),))
+        stride = int(hip_ops.packed_stride(D))
+        f.packed_next = ctx.empty((K, stride))
+        f.success = ctx.empty((K,), np.int32)
+        offsets = np.concatenate([[0], np.cumsum(self.counts_loc)]).astype(np.int32)
+        f.offsets = ctx.asarray(offsets, np.int32)
+        t = tgt._fast_path_target()
+        f.target_keepalive = t
+        p = ShardedPlan()
+        p.n_ranks, p.rank, p.K, p.D, p.N = R, self.rank, K, D, N
+        p.target_kind = t["kind"]
+        p.target_family, p.target_K, p.target_nu = t.get("family", 0), t.get("K", 0), t.get("nu", 0.0)
+        p.target_packed, p.target_logw = t.get("packed"), t.get("logw")
+        p.planar_prior_std, p.planar_goals = t.get("prior_std"), t.get("goals")
+        p.planar_goals_count, p.planar_likelihood_std = t.get("G", 0), t.get("lik_std", 0.0)
+        p.e1, p.e2, p.e3 = f.e1.ptr, f.e2.ptr, f.e3.ptr
+        p.x_all, p.tlp_all, p.tgrad_all = f.x_all.ptr, f.tlp_all.ptr, f.tgrad_all.ptr
+        p.E_all, p.reward_all = f.E_all.ptr, f.reward_all.ptr
+        p.bg_logw, p.offsets, p.max_per_component = self.logc_loc.ptr, f.offsets.ptr, int(self.counts_loc.max())
+        p.seed = int(self.seed) & 0xFFFFFFFFFFFFFFFF
+        p.wstate = self.wstate.ptr
+        p.temperature, p.l2_init = self.temperature, 1e-12
+        p.component_stepsize_mode = 1
+        p.cs_min, p.cs_max = self.cs["min_stepsize"], self.cs["max_stepsize"]
+        p.cs_inc, p.cs_dec = self.cs["stepsize_inc_factor"], self.cs["stepsize_dec_factor"]
+        p.weight_stepsize_mode = 1
+        p.ws_min, p.ws_max = self.ws["min_stepsize"], self.ws["max_stepsize"]
+        p.ws_inc, p.ws_dec = self.ws["stepsize_inc_factor"], self.ws["stepsize_dec_factor"]
+        p.stein_flags = _lib.SELF_NORMALIZED if snis else 0
+        p.scratch = f.scratch.ptr
+        f.plan, f.presampled = p, False
+        f.presample = os.environ.get("GMMVI_PRESAMPLE", "1") != "0"
+        self._fast = f
+
+    def _train_iter_phased(self):
+        f, ex, ctx = self._fast, self.exchange, self.ops.ctx
+        p = f.plan
+        K, Kt, H = self.Kl, self.K, self.H
+        if self.packed is None:
+            self.packed = self.ops.pack(self.means, self.chols)
+        p.means, p.chols, p.logw_all = self.means.ptr, self.chols.ptr, self._logw.ptr
+        p.packed, p.packed_new = self.packed.ptr, f.packed_next.ptr
+        p.stepsizes, p.last_eta, p.l2 = self.stepsizes.ptr, self.last_eta.ptr, self.l2.ptr
+        p.num_updates, p.success_out = self.num_received_updates.ptr, f.success.ptr
+        p.first_index = self.num_samples_written + self.rank * self.Nl
+        pending = self._pending is not None
+        p.has_pending = int(pending)
+        ring = self.reward_ring.ptr
+        if pending:                                    # the gathered rewards become the next column of the (replicated) history
+            p.reward_col_pending = ring + 4 * Kt * (self.t_reward % H)
+            self.t_reward += 1
+        last, prev = (self.t_reward - 1) % H, (self.t_reward - 2) % H
+        p.reward_last_all = ring + 4 * Kt * last
+        p.reward_last = ring + 4 * (Kt * last + self.lo)
+        p.reward_prev = ring + 4 * (Kt * prev + self.lo)
+        p.presampled, p.presample_next = int(f.presampled), int(f.presample)
+        call = lambda phase: ctx.check(ctx.lib.gmmvi_train_iter_sharded_phase(ctx.handle, _C.byref(p), phase))
+        call(1)
+        ex.allgather_inplace(f.e1, f.s1)
+        call(2)
+        ex.allgather_inplace(f.e2, f.s2)
+        call(3)
+        ex.allgather_inplace(f.e3, self.N)
+        call(4)
+        self.packed, f.packed_next = f.packed_next, self.packed
+        self.last_success = f.success
+        self._pending = (f.E_loc, f.reward_loc)        # travel with the next iteration's first exchange (or flush())
+        f.presampled = f.presample
+        self.num_samples_written += self.N
+        self.num_updates += 1
+
     def train_iter(self):
+        if self._fast is not None:
+            return self._train_iter_phased()
         o, ex, d, R, N, Nl = self.ops, self.exchange, self.d, self.R, self.N, self.Nl
         # ---- sampling + target (local components); exchange E1: [x | log p~ | grad log p~ (| pending E, reward)] in ONE
         # all-gather; neither sampling nor the target reads the mixture weights, so the previous weight step may still be open

@@ -327,6 +327,65 @@ typedef struct gmmvi_samtron_plan {
 } gmmvi_samtron_plan;
 int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan* plan);
 
+/* The same iteration for COMPONENT SHARDS (the reference has no multi-GPU code): rank r owns K components, their
+ * samples and their updates; every component needs all N samples of the iteration, so the iteration has three exchange points.
+ * It is issued as FOUR calls with one all-gather between consecutive calls (gmmvi_allgather_f32 in place on the exchange
+ * buffers; the caller may substitute any exchange, e.g. through the host in tests) -- the launches inside a phase are those of
+ * gmmvi_train_iter_samtron (packed density sweeps with carried merges, Stein slab whitened inside the update kernel):
+ *   phase 1  draw the local samples and evaluate the target on them, straight into this rank's part of e1
+ *   -- all-gather e1 --  [x | log p~ | grad log p~ | E | reward] of every rank
+ *   phase 2  de-interleave e1; apply the PREVIOUS iteration's weight step from the gathered (E, reward) (replicated on every
+ *            rank: nothing reads the new weights or the new reward column earlier); stepsize rules; dual density sweep over
+ *            the local components on all N samples into this rank's part of e2
+ *   -- all-gather e2 --  [background partial | log q partial | gradient partial] of every rank
+ *   phase 3  combine the ranks' partials; Stein estimate and KL-constrained update of the local components; post-update
+ *            sweep, its log q partial into this rank's part of e3
+ *   -- all-gather e3 --
+ *   phase 4  expected log-ratios and rewards of the local components into this rank's part of e1 (they travel with the next
+ *            iteration's first exchange)
+ * With n_ranks == 1 the gathers are no-ops and the gathered views may alias the parts. */
+typedef struct gmmvi_sharded_plan {
+    int32_t n_ranks, rank;
+    int32_t K, D, N;                      /* LOCAL components, dimension, samples of ALL ranks (N % n_ranks == 0) */
+    int32_t target_kind, target_family, target_K;
+    float target_nu;
+    const float* target_packed; const float* target_logw;
+    const float* planar_prior_std; const float* planar_goals;
+    int32_t planar_goals_count; float planar_likelihood_std;
+    /* local model state (in/out) */
+    float* means; float* chols; const float* packed; float* packed_new;
+    float* stepsizes; float* last_eta; float* l2; float* num_updates; int32_t* success_out;
+    float* logw_all;                      /* [K * n_ranks] replicated log weights */
+    const float* bg_logw;                 /* [K] log(count_k / N) of the local components */
+    const int32_t* offsets;               /* [K+1] prefix sums of the local per-component sample counts */
+    int32_t max_per_component;
+    uint64_t seed, first_index;           /* Philox key / global index of this rank's first new sample */
+    /* exchange buffers [n_ranks * stride] floats; this rank's part at rank * stride */
+    float* e1;                            /* stride (N / n_ranks) * (2 D + 1) + 2 K */
+    float* e2;                            /* stride N * (D + 2) */
+    float* e3;                            /* stride N */
+    /* gathered arrays written by phase 2 */
+    float* x_all; float* tlp_all; float* tgrad_all;      /* [N,D], [N], [N,D] */
+    float* E_all; float* reward_all;      /* [K * n_ranks] */
+    int32_t has_pending;                  /* e1 carries the previous iteration's (E, reward): phase 2 applies that weight step */
+    float* reward_col_pending;            /* [K * n_ranks] reward-history column that receives the gathered rewards */
+    const float* reward_prev; const float* reward_last;  /* [K] local slices of the two newest columns AFTER the pending step */
+    const float* reward_last_all;         /* [K * n_ranks] the newest column (weight stepsize rule) */
+    float* wstate;                        /* [2] weight stepsize, previous ELBO proxy */
+    float temperature, l2_init;
+    int32_t component_stepsize_mode; float cs_min, cs_max, cs_inc, cs_dec;
+    int32_t weight_stepsize_mode; float ws_min, ws_max, ws_inc, ws_dec;
+    int32_t stein_flags;
+    /* as in gmmvi_samtron_plan: phase 4 draws the NEXT iteration's local samples (Philox indices first_index + N ..) into this
+     * rank's part of e1 as riders of the expected-log-ratio launch; phase 1 of a call with presampled != 0 skips its draw */
+    int32_t presample_next, presampled;
+    /* scratch that lives across the four phases (component log densities, merged mixture arrays): caller-owned so that
+     * several plans can take turns on one context; at least gmmvi_sharded_scratch_floats(K, D, N) floats */
+    float* scratch;
+} gmmvi_sharded_plan;
+size_t gmmvi_sharded_scratch_floats(int K, int D, int N);
+int gmmvi_train_iter_sharded_phase(gmmvi_ctx* ctx, const gmmvi_sharded_plan* plan, int phase /* 1..4 */);
+
 /* ---- multi-GPU exchange (component shards) ----------------------------------------------------- */
 /* RCCL communicator over the ranks of one node; unique_id is the 128-byte ncclUniqueId produced by rank 0. */
 int gmmvi_comm_unique_id(char* out_id_128);

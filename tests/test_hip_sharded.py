@@ -79,6 +79,14 @@ class _ThreadExchange:
         shape = (self.n_ranks * arr.shape[0],) + tuple(arr.shape[1:])
         return self.ctx.asarray(out.reshape(shape))
 
+    def allgather_inplace(self, buf, count):
+        """The in-place form the phased C iteration uses (gmmvi_train_iter_sharded_phase): own part -> host, all parts back."""
+        self.slots[self.rank] = buf.rows(self.rank * count, (self.rank + 1) * count).numpy()
+        self._rendezvous()
+        out = np.concatenate(self.slots)
+        self._rendezvous()
+        buf.set(out)
+
     def barrier_(self):
         self._rendezvous()
 
@@ -86,8 +94,13 @@ class _ThreadExchange:
         return v
 
 
-@pytest.mark.parametrize("kind,d,k,s,iters", [("stm", 6, 8, 40, 5), ("gmm", 72, 4, 48, 3)])     # D = 72: blocked kernels
+@pytest.mark.parametrize("kind,d,k,s,iters", [("stm", 6, 8, 40, 5), ("gmm", 72, 4, 48, 3), ("stm", 20, 32, 64, 4),
+                                              ("planar", 10, 8, 50, 4)])
 def test_two_virtual_ranks_match_single_rank(kind, d, k, s, iters):
+    """D = 6 / 20 / 10: the phased C iteration (gmmvi_train_iter_sharded_phase: the single-call iteration's launches with the
+    three exchanges between its phases; 16 local components at D = 20, N = 2048: component-chunked sweeps, their partials merged
+    before they travel); D = 72: blocked
+    kernels, module-by-module path."""
     import threading
     from gmmvi_amd.device import get_context
     from gmmvi_amd.sharded import ShardedGMMVI, HipOps, LocalExchange
