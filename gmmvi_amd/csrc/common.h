@@ -217,7 +217,7 @@ struct Pack {
     static constexpr int NF = FRAGS ? fwd_base(MT) : 0, NB = FRAGS ? bwd_base(MT) : 0;
     static constexpr int FWD = FRAGS ? ((CONST + 1 + 63) / 64) * 64 : ((CONST + 1 + 3) / 4) * 4;
     static constexpr int BWD = FWD + 64 * NF;
-    // blocks without fragments (scalar-fed sweeps) end in the SWEEP STREAM: the floats a component pass of the packed
+    // every block ends in the SWEEP STREAM: the floats a component pass of the packed
     // two-samples-per-lane sweep reads, in the order it reads them (density.hip, subst_pk.h), each part 16-byte aligned:
     //   SWH  mu[DP], log-normaliser
     //   SWF  forward substitution by columns, the reciprocal of the diagonal entry in front of its column:
@@ -228,7 +228,7 @@ struct Pack {
     static constexpr int SWH = BWD + 64 * NB;
     static constexpr int SWF = SWH + ((DP + 1 + 3) / 4) * 4;
     static constexpr int SWB = SWF + ((TD + 3) / 4) * 4;
-    static constexpr int STRIDE = FRAGS ? BWD + 64 * NB : SWB + ((TD + 3) / 4) * 4;
+    static constexpr int STRIDE = SWB + ((TD + 3) / 4) * 4;
     __host__ __device__ static constexpr int swf_col(int j) { return j * DP - j * (j - 1) / 2; }
     __host__ __device__ static constexpr int swb_row(int i) { return i * (i + 1) / 2; }
     __host__ __device__ static constexpr int rowofs(int i) { return i * (i - 1) / 2; }
@@ -249,13 +249,10 @@ inline __host__ __device__ PackDims gmmvi_pack_dims(int dp) {
     d.fwd = frags ? ((2 * dp + 2 * T + 1 + 63) / 64) * 64 : ((2 * dp + 2 * T + 1 + 3) / 4) * 4;
     d.bwd = d.fwd + 64 * d.nf_total;
     d.stride = d.bwd + 64 * d.nb_total;
-    d.swh = d.swf = d.swb = -1;
-    if (!frags) {
-        d.swh = d.stride;
-        d.swf = d.swh + ((dp + 1 + 3) / 4) * 4;
-        d.swb = d.swf + ((T + dp + 3) / 4) * 4;
-        d.stride = d.swb + ((T + dp + 3) / 4) * 4;
-    }
+    d.swh = d.stride;
+    d.swf = d.swh + ((dp + 1 + 3) / 4) * 4;
+    d.swb = d.swf + ((T + dp + 3) / 4) * 4;
+    d.stride = d.swb + ((T + dp + 3) / 4) * 4;
     return d;
 }
 inline size_t gmmvi_packed_stride_dp(int dp) { return (size_t)gmmvi_pack_dims(dp).stride; }

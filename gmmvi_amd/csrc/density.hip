@@ -50,9 +50,9 @@ __global__ __launch_bounds__(64) void pack_kernel(int family, float nu, int K, i
             c = lgammaf(0.5f * (nu + D)) - lgammaf(0.5f * nu) - 0.5f * D * logf(nu * 3.14159265358979f) - s;
         out[P::CONST] = c;
         for (int i = P::CONST + 1; i < P::FWD; ++i) out[i] = 0.f;
-        if constexpr (!P::FRAGS) out[P::SWH + DP] = c;
+        out[P::SWH + DP] = c;
     }
-    if constexpr (!P::FRAGS) gmmvi_write_sweep_stream(out, DP, D, L, D, means + (size_t)k * D, t, 64);
+    gmmvi_write_sweep_stream(out, DP, D, L, D, means + (size_t)k * D, t, 64);
     // L^-1: lane t solves L x = e_t (column t) by forward substitution; the dense inverse is staged in LDS, from where the
     // matrix-core fragments of the block (common.h) and the optional explicit inverse (sample_db.py:121) are written
     __shared__ float Li[DP * DP];
@@ -391,7 +391,9 @@ __global__ __launch_bounds__(DP >= GMMVI_ME_WIDE_DP ? 512 : GMMVI_ME_THREADS, GM
 //    flat merge of 128 samples would take, so that two 8-wave workgroups share a CU.
 // Chunk partials (gridDim.y > 1) leave as in the kernel above: log values and gradients normalised per chunk.
 template <int DP, int FAMILY, bool GRAD>
-__global__ __launch_bounds__(1024) void mixture_eval_pk_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
+// (padded D <= 24: up to 16 waves at <= 128 registers; wider dimensions: 8 waves, 256 registers -- the gradient instance keeps
+// 4 DP registers of per-dimension state)
+__global__ __launch_bounds__(DP > 24 ? 512 : 1024) void mixture_eval_pk_kernel(float nu, int K_total, int D, const float* __restrict__ packed,
                                                                const float* __restrict__ logw, const float* __restrict__ X, int N,
                                                                float* __restrict__ ld_out, float* __restrict__ lp_out,
                                                                float* __restrict__ grad_out, const float* __restrict__ logw2,
@@ -1400,13 +1402,17 @@ static int launch_mixture_eval_pk(gmmvi_ctx* ctx, int family, float nu, int K, i
     const int ky16 = chunks_for(cus), ky8 = chunks_for(2 * cus);
     bool wide = fill(ky16, cus) + 0.05 >= fill(ky8, 2 * cus);
     int ky = wide ? ky16 : ky8;
+    // wider dimensions: 8 waves per workgroup; with the gradient ~220 registers and ~136 KB of LDS at D = 50 (one workgroup per
+    // CU), without it 120 registers and 34 KB (two)
+    if (DP > 24) ky = want_grad ? ky16 : ky8;
     if (env_ky > 0) ky = env_ky;
     if (ky > K) ky = K;
     if (ky < 1) ky = 1;
     const int kchunk = (K + ky - 1) / ky;
     ky = (K + kchunk - 1) / kchunk;
-    int nw = wide ? 16 : 8;
+    int nw = wide && DP <= 24 ? 16 : 8;
     if (env_nw > 0) nw = env_nw;
+    if (DP > 24 && nw > 8) nw = 8;
     if (nw > kchunk) nw = kchunk;
     if (nw > 16) nw = 16;
     const int nv = (want_grad ? DP : 0) + 2;
@@ -1442,10 +1448,16 @@ static int launch_mixture_eval_pk(gmmvi_ctx* ctx, int family, float nu, int K, i
         hipLaunchKernelGGL((mixture_eval_pk_kernel<DP, FAM, G>), grid, block, shmem, ctx->stream, nu, K, D, packed, \
                            logw, X, N, ld, lp_k, grad_k, logw2, lp2_k, carried, riders);                                         \
     } while (0)
-        if (family == GMMVI_GAUSS) {
-            if (want_grad) GMMVI_LAUNCH_MEPK(GMMVI_GAUSS, true); else GMMVI_LAUNCH_MEPK(GMMVI_GAUSS, false);
+        // (the gradient instances exist up to padded D = 40: at 50 they need 223 registers and lose to the matrix-core kernel)
+        if constexpr (DP <= 40) {
+            if (family == GMMVI_GAUSS) {
+                if (want_grad) GMMVI_LAUNCH_MEPK(GMMVI_GAUSS, true); else GMMVI_LAUNCH_MEPK(GMMVI_GAUSS, false);
+            } else {
+                if (want_grad) GMMVI_LAUNCH_MEPK(GMMVI_STUDENT_T, true); else GMMVI_LAUNCH_MEPK(GMMVI_STUDENT_T, false);
+            }
         } else {
-            if (want_grad) GMMVI_LAUNCH_MEPK(GMMVI_STUDENT_T, true); else GMMVI_LAUNCH_MEPK(GMMVI_STUDENT_T, false);
+            if (want_grad) return gmmvi_fail(ctx, GMMVI_ERR_ARG, "mixture_eval_pk: no gradient instance for this dimension");
+            if (family == GMMVI_GAUSS) GMMVI_LAUNCH_MEPK(GMMVI_GAUSS, false); else GMMVI_LAUNCH_MEPK(GMMVI_STUDENT_T, false);
         }
 #undef GMMVI_LAUNCH_MEPK
     }
@@ -1468,14 +1480,23 @@ static int launch_mixture_eval(gmmvi_ctx* ctx, int family, float nu, int K, int 
                                const float* logw, const float* X, int N, float* ld, float* lp, float* grad,
                                const float* logw2 = nullptr, float* lp2 = nullptr) {
     using PK = Pack<DP>;
-    if constexpr (!PK::FRAGS) {
+    {
         // enough (128-sample tile, component) passes to give every SIMD a few: the packed kernel; otherwise the one-sample
-        // kernel, whose 64-sample tiles spread a small problem over more CUs (GMMVI_ME_PK: 0 never, 1 always)
+        // kernel, whose 64-sample tiles spread a small problem over more CUs (GMMVI_ME_PK: 0 never, 1 always).
+        // Padded D >= 32 (GMMVI_ME_PK_WIDE, experiments): the triangular substitution on the packed vector unit does D^2 / 2
+        // multiply-adds per pair and side where the matrix-core kernels multiply whole 16 x 4 fragments of the explicit inverse
         static const int env_pk = getenv("GMMVI_ME_PK") ? atoi(getenv("GMMVI_ME_PK")) : -1;
         static const long env_pk_min = getenv("GMMVI_ME_PK_MIN") ? atol(getenv("GMMVI_ME_PK_MIN")) : 4096;
+        static const int env_pk_wide = getenv("GMMVI_ME_PK_WIDE") ? atoi(getenv("GMMVI_ME_PK_WIDE")) : 1;
         const long passes = (long)((N + 127) / 128) * K;
-        if (env_pk != 0 && (env_pk == 1 || passes >= env_pk_min))
-            return launch_mixture_eval_pk<DP>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
+        // measured inside the iteration at K = 100, N = 10^4 (profiles/r04_notes.md): without the gradient the packed kernel wins
+        // at D = 40 / 50 (post-update sweep 41.9 -> 33.0 / 53.1 -> 45.7 us; D = 32: 25.8 / 26.1), with the gradient at D = 32 / 40
+        // (dual sweep 57.5 -> 52.3 / 79.9 -> 74.4) but not at D = 50 (99 -> 115: 223 registers = two waves per SIMD)
+        const bool shape_ok = !PK::FRAGS || (env_pk_wide && (grad == nullptr || DP <= 40));
+        if constexpr (DP <= 50) {
+            if (shape_ok && env_pk != 0 && (env_pk == 1 || passes >= env_pk_min))
+                return launch_mixture_eval_pk<DP>(ctx, family, nu, K, D, packed, logw, X, N, ld, lp, grad, logw2, lp2);
+        }
     }
     if constexpr (PK::FRAGS) {
         // enough samples for the workgroup-shared form (eight waves on one component at a time): the block goes to LDS once per

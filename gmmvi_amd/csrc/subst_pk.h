@@ -72,7 +72,6 @@ __host__ __device__ constexpr int pk_bcol(int e) { return e - pk_brow(e) * (pk_b
 template <int DP>
 struct PkPass {
     using PK = Pack<DP>;
-    static_assert(!PK::FRAGS, "the sweep stream exists in blocks without fragments only");
     static constexpr int TD = PK::TD;
     static constexpr int HN = (DP + 1 + 3) / 4 * 4;
     using Fwd = SpStream<PK::SWF, TD>;

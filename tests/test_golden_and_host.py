@@ -68,7 +68,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     # padded D <= 24: [mu | 1/diag | triangle by rows | by columns | log-normaliser] + the sweep stream [mu, log-normaliser |
     # columns with their reciprocal diagonal entry | rows with theirs], every part a whole number of 16-byte words
     assert built_lib.gmmvi_packed_stride(20) == ((2 * 20 + 20 * 19 + 1 + 3) // 4) * 4 + 24 + 2 * ((210 + 3) // 4 * 4)
-    assert built_lib.gmmvi_packed_stride(40) == 1664 + 64 * (4 + 8 + 10) + 64 * (10 + 6 + 2)       # L^-1 fragments, no sweep stream
+    assert built_lib.gmmvi_packed_stride(40) == 1664 + 64 * (4 + 8 + 10) + 64 * (10 + 6 + 2) + 44 + 2 * 820   # + L^-1 fragments
     assert built_lib.gmmvi_packed_stride(65) == 68 + 65 * 65          # blocked path: [mu, const, pad to 4 | L^-1]
     assert built_lib.gmmvi_packed_stride(300) == 304 + 300 * 300
     assert built_lib.gmmvi_packed_stride(513) == 0
