@@ -67,6 +67,8 @@ _PROTOS = {
     "gmmvi_segment_lse_f32": (_i, [_p, _i, _p, _p, _p, _i, _p, _sz, _i]),
     "gmmvi_copy_2d_f32": (_i, [_p, _p, _sz, _p, _sz, _i, _i]),
     "gmmvi_copy_batch": (_i, [_p, _i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_sz)]),
+    "gmmvi_normalize_logw": (_i, [_p, _p, _i, _p]),
+    "gmmvi_add_heuristic_argmax": (_i, [_p, _p, _p, _i, C.c_double, _p]),
     "gmmvi_unpack_gathered": (_i, [_p, _p, _i, _sz, _i, C.POINTER(_sz), C.POINTER(_p)]),
     "gmmvi_fill_strided_f32": (_i, [_p, _p, _sz, _sz, _f]),
     "gmmvi_remove_column_f32": (_i, [_p, _p, _i, _sz, _i, _i]),

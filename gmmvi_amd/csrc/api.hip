@@ -303,6 +303,76 @@ __global__ void exp_f32_kernel(float* dst, const float* src, size_t n) {
     for (; i < n; i += stride) dst[i] = expf(src[i]);
 }
 
+// GMM.replace_weights (models/gmm.py:173-181): out = lw - logsumexp(lw), the log-sum-exp in fp64 as the host form of it
+// (optimization on the adaptive path: adding / removing a component no longer reads the weights back).  One workgroup.
+__global__ __launch_bounds__(256) void normalize_logw_kernel(const float* __restrict__ in, int n, float* __restrict__ out) {
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    double m = -1.0e300;
+    for (int i = t; i < n; i += 256) m = fmax(m, (double)in[i]);
+    red[t] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] = fmax(red[t], red[t + o]); __syncthreads(); }
+    m = red[0];
+    __syncthreads();
+    double s = 0.0;
+    for (int i = t; i < n; i += 256) s += exp((double)in[i] - m);
+    red[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+    const double lse = log(red[0]) + m;
+    for (int i = t; i < n; i += 256) out[i] = (float)((double)in[i] - lse);
+}
+
+int gmmvi_normalize_logw(gmmvi_ctx* ctx, const float* logw_in_dev, int n, float* logw_out_dev) {
+    GMMVI_ARG_CHECK(ctx, n >= 1 && logw_in_dev && logw_out_dev);
+    hipLaunchKernelGGL(normalize_logw_kernel, dim3(1), dim3(256), 0, ctx->stream, logw_in_dev, n, logw_out_dev);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
+// VipsComponentAdaptation.add_at_best_location (component_adaptation.py:192-226): the candidate with the largest
+//   reward_n = log p~(x_n) - max(max_m log q(x_m) - threshold, log q(x_n)),
+// first index on ties (argmax), evaluated in fp64 as the host form; index_out[0] = that candidate.  One workgroup.
+__global__ __launch_bounds__(1024) void add_heuristic_argmax_kernel(const float* __restrict__ model_ld, const float* __restrict__ tlp,
+                                                                    int n, double threshold, int32_t* __restrict__ index_out) {
+    __shared__ double rv[1024];
+    __shared__ int ri[1024];
+    const int t = threadIdx.x;
+    double m = -1.0e300;
+    for (int i = t; i < n; i += 1024) m = fmax(m, (double)model_ld[i]);
+    rv[t] = m;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if (t < o) rv[t] = fmax(rv[t], rv[t + o]); __syncthreads(); }
+    const double floor_ld = rv[0] - threshold;
+    __syncthreads();
+    double best = -1.0e300;
+    int bi = 0x7fffffff;
+    for (int i = t; i < n; i += 1024) {
+        const double r = (double)tlp[i] - fmax(floor_ld, (double)model_ld[i]);
+        if (bi == 0x7fffffff || r > best) { best = r; bi = i; }    // ascending i per thread: the first maximum stays
+    }
+    rv[t] = best; ri[t] = bi;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (t < o) {
+            const double b2 = rv[t + o]; const int i2 = ri[t + o];
+            if (i2 != 0x7fffffff && (ri[t] == 0x7fffffff || b2 > rv[t] || (b2 == rv[t] && i2 < ri[t]))) { rv[t] = b2; ri[t] = i2; }
+        }
+        __syncthreads();
+    }
+    if (t == 0) index_out[0] = ri[0] == 0x7fffffff ? 0 : ri[0];
+}
+
+int gmmvi_add_heuristic_argmax(gmmvi_ctx* ctx, const float* model_ld_dev, const float* target_lnpdfs_dev, int n, double threshold,
+                               int32_t* index_out_dev) {
+    GMMVI_ARG_CHECK(ctx, n >= 1 && model_ld_dev && target_lnpdfs_dev && index_out_dev);
+    hipLaunchKernelGGL(add_heuristic_argmax_kernel, dim3(1), dim3(1024), 0, ctx->stream, model_ld_dev, target_lnpdfs_dev, n,
+                       threshold, index_out_dev);
+    GMMVI_LAUNCH_CHECK(ctx);
+    return GMMVI_OK;
+}
+
 int gmmvi_exp_f32(gmmvi_ctx* ctx, float* dst_dev, const float* src_dev, size_t count) {
     if (count == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, dst_dev && src_dev);

@@ -8,6 +8,7 @@ still available for callers of the dense entry points.
 import numpy as np
 
 from .. import hip_ops
+from ..device import DeviceArray
 from .gmm import GMM
 
 
@@ -136,9 +137,10 @@ class DiagonalGMM(GMM):
         cov = np.asarray(initial_cov, np.float32).reshape(d)
         if not np.all(cov > 0):
             raise ValueError("add_component: covariance entries must be positive")
-        self.means = self.ctx.asarray(np.concatenate([self.means.numpy(),
-                                                      np.asarray(initial_mean, np.float32).reshape(1, d)]))
-        self.chol_cov = self.ctx.asarray(np.concatenate([self.chol_cov.numpy(), np.sqrt(cov)[None]]))
+        if not isinstance(initial_mean, DeviceArray):
+            initial_mean = self.ctx.asarray(np.asarray(initial_mean, np.float32).reshape(1, d))
+        self.means = self._append_rows(self.means, initial_mean.reshape((1, d)))
+        self.chol_cov = self._append_rows(self.chol_cov, self.ctx.asarray(np.sqrt(cov)[None]))
         self._invalidate()
-        self.replace_weights(np.concatenate([self.log_weights.numpy().astype(np.float64),
-                                             [np.log(np.float64(initial_weight))]]))
+        new_lw = self.ctx.asarray(np.array([np.log(np.float64(initial_weight))], np.float32))
+        self.log_weights = self._renormalised(self._append_rows(self.log_weights, new_lw))

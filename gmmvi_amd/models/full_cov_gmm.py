@@ -2,6 +2,7 @@
 import numpy as np
 
 from .. import hip_ops
+from ..device import DeviceArray
 from .gmm import GMM
 
 
@@ -61,15 +62,23 @@ class FullCovGMM(GMM):
         return -0.5 * diffs * diffs / var[:, None] - 0.5 * np.log(var)[:, None] - 0.5 * np.log(2 * np.pi)
 
     def add_component(self, initial_weight, initial_mean, initial_cov):
-        """full_cov_gmm.py:64-68."""
+        """full_cov_gmm.py:64-68.  Device-side appends (nothing is read back); ``initial_mean`` may be a DeviceArray [1, D]."""
         d = self.num_dimensions
-        cov = self.ctx.asarray(np.asarray(initial_cov, np.float32).reshape(1, d, d))
-        chol, ok = hip_ops.cholesky(self.ctx, cov)
-        if not ok.numpy().all():
-            raise ValueError("add_component: covariance is not positive definite")
-        self.means = self.ctx.asarray(np.concatenate([self.means.numpy(),
-                                                      np.asarray(initial_mean, np.float32).reshape(1, d)]))
-        self.chol_cov = self.ctx.asarray(np.concatenate([self.chol_cov.numpy(), chol.numpy()]))
+        cov = np.asarray(initial_cov, np.float32).reshape(d, d)
+        if np.count_nonzero(cov - np.diag(np.diagonal(cov))) == 0:
+            # a diagonal covariance (what the add heuristic passes, component_adaptation.py:220-223): its factor is the square
+            # root of the diagonal -- exactly what the Cholesky kernel returns, without the launch and the status read-back
+            if not np.all(np.diagonal(cov) > 0):
+                raise ValueError("add_component: covariance is not positive definite")
+            chol = self.ctx.asarray(np.diag(np.sqrt(np.diagonal(cov))).reshape(1, d, d))
+        else:
+            chol, ok = hip_ops.cholesky(self.ctx, self.ctx.asarray(cov.reshape(1, d, d)))
+            if not ok.numpy().all():
+                raise ValueError("add_component: covariance is not positive definite")
+        if not isinstance(initial_mean, DeviceArray):
+            initial_mean = self.ctx.asarray(np.asarray(initial_mean, np.float32).reshape(1, d))
+        self.means = self._append_rows(self.means, initial_mean.reshape((1, d)))
+        self.chol_cov = self._append_rows(self.chol_cov, chol)
         self._invalidate()
-        self.replace_weights(np.concatenate([self.log_weights.numpy().astype(np.float64),
-                                             [np.log(np.float64(initial_weight))]]))
+        new_lw = self.ctx.asarray(np.array([np.log(np.float64(initial_weight))], np.float32))
+        self.log_weights = self._renormalised(self._append_rows(self.log_weights, new_lw))

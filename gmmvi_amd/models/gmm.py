@@ -172,10 +172,24 @@ class GMM:
         self.chol_cov = self.ctx.asarray(new_chols)
         self._invalidate()
 
+    def _renormalised(self, log_weights_dev):
+        """gmm.py:173-181 on the device (fp64 log-sum-exp): no read-back of the weights."""
+        out = self.ctx.empty(log_weights_dev.shape)
+        self.ctx.check(self.ctx.lib.gmmvi_normalize_logw(self.ctx.handle, log_weights_dev.ptr, int(log_weights_dev.shape[0]), out.ptr))
+        return out
+
+    def _append_rows(self, arr, new_row):
+        """[K, ...] device array with one more row (device-side copy, nothing read back)."""
+        inner = tuple(arr.shape[1:])
+        new_row = self.ctx.asarray(new_row) if not isinstance(new_row, DeviceArray) else new_row
+        return hip_ops.concat(self.ctx, [arr, new_row]).reshape((arr.shape[0] + 1,) + inner)
+
     def remove_component(self, idx):
-        """gmm.py:388-398."""
+        """gmm.py:388-398 (device-side gathers: nothing is read back)."""
         idx = int(idx)
-        self.replace_weights(np.delete(self.log_weights.numpy(), idx))
-        self.means = self.ctx.asarray(np.delete(self.means.numpy(), idx, axis=0))
-        self.chol_cov = self.ctx.asarray(np.delete(self.chol_cov.numpy(), idx, axis=0))
+        keep = np.delete(np.arange(self.num_components, dtype=np.int32), idx)
+        keep_dev = self.ctx.asarray(keep, np.int32)
+        self.log_weights = self._renormalised(hip_ops.gather_rows(self.ctx, self.log_weights, keep_dev))
+        self.means = hip_ops.gather_rows(self.ctx, self.means, keep_dev)
+        self.chol_cov = hip_ops.gather_rows(self.ctx, self.chol_cov, keep_dev)
         self._invalidate()

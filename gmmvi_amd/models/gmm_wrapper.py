@@ -141,11 +141,13 @@ class GmmWrapper:
         self.model.add_component(initial_weight, initial_mean, initial_cov)
         self.max_component_id += 1
         self.unique_component_ids = np.append(self.unique_component_ids, np.int32(self.max_component_id))
-        app = lambda dev, v: ctx.asarray(np.append(dev.numpy(), np.float32(v)))
-        self.l2_regularizers = app(self.l2_regularizers, self.initial_regularizer)
-        self.last_log_etas = app(self.last_log_etas, self.initial_last_eta)
-        self.num_received_updates = app(self.num_received_updates, 0.0)
-        self.stepsizes = app(self.stepsizes, self.initial_stepsize)
+        # the four per-component vectors get their new entry on the device (one small upload, four copies: nothing read back)
+        tail = ctx.asarray(np.array([self.initial_regularizer, self.initial_last_eta, 0.0, self.initial_stepsize], np.float32))
+        app = lambda dev, j: hip_ops.concat(ctx, [dev, tail.rows(j, j + 1)])
+        self.l2_regularizers = app(self.l2_regularizers, 0)
+        self.last_log_etas = app(self.last_log_etas, 1)
+        self.num_received_updates = app(self.num_received_updates, 2)
+        self.stepsizes = app(self.stepsizes, 3)
         h = self.max_reward_history_length
         # the new component's history column: rewards float32.min (:121-122), weights initial_weight (:123-124)
         ctx.check(ctx.lib.gmmvi_fill_strided_f32(ctx.handle, self._reward_ring.ptr + 4 * k_old, self._kcap, h,
@@ -164,7 +166,8 @@ class GmmWrapper:
         k_old = self.model.num_components
         self.model.remove_component(idx)
         self.unique_component_ids = np.delete(self.unique_component_ids, idx)
-        rm = lambda dev: ctx.asarray(np.delete(dev.numpy(), idx))
+        keep = ctx.asarray(np.delete(np.arange(k_old, dtype=np.int32), idx), np.int32)
+        rm = lambda dev: hip_ops.gather_rows(ctx, dev, keep)
         self.l2_regularizers = rm(self.l2_regularizers)
         self.last_log_etas = rm(self.last_log_etas)
         self.num_received_updates = rm(self.num_received_updates)

@@ -81,23 +81,26 @@ class VipsComponentAdaptation(ComponentAdaptation):
                 self.add_new_component()
 
     def add_at_best_location(self, samples, target_lnpdfs):
-        """:192-226."""
+        """:192-226.  The candidate search runs on the device (gmmvi_add_heuristic_argmax: the same fp64 arithmetic, first
+        maximum): neither the 10^5 candidate densities nor the chosen sample are read back."""
         m = self.model
+        ctx = m.ctx
         it = self.num_calls_to_add_heuristic % len(self.thresholds_for_addHeuristic)
-        model_log_densities = m.log_density(samples).numpy().astype(np.float64)
-        target_lnpdfs = np.asarray(target_lnpdfs.numpy() if hasattr(target_lnpdfs, "numpy") else target_lnpdfs,
-                                   np.float64)
+        samples = ctx.asarray(samples) if not hasattr(samples, "ptr") else samples
+        target_lnpdfs = ctx.asarray(np.asarray(target_lnpdfs, np.float32)) if not hasattr(target_lnpdfs, "ptr") else target_lnpdfs
+        model_log_densities = m.log_density(samples)
         init_weight = 1e-29
         a = self.rng.random()                                                                        # :208
         if self.prior_var is not None:
             des_entropy = m.get_average_entropy() * a + self._prior_entropy() * (1 - a)
         else:
             des_entropy = m.get_average_entropy()
-        max_logdensity = np.max(model_log_densities)
-        rewards = target_lnpdfs - np.maximum(max_logdensity - self.thresholds_for_addHeuristic[it],
-                                             model_log_densities)
-        best = int(np.argmax(rewards))
-        new_mean = samples.rows(best, best + 1).numpy()[0] if hasattr(samples, "rows") else np.asarray(samples)[best]
+        best = ctx.empty((1,), np.int32)
+        ctx.check(ctx.lib.gmmvi_add_heuristic_argmax(ctx.handle, model_log_densities.ptr, target_lnpdfs.ptr,
+                                                     int(model_log_densities.shape[0]),
+                                                     float(self.thresholds_for_addHeuristic[it]), best.ptr))
+        from ... import hip_ops
+        new_mean = hip_ops.gather_rows(ctx, samples, best)                                           # [1, D] on the device
         d = m.num_dimensions
         h_unscaled = 0.5 * d * (np.log(2.0 * np.pi) + 1)
         c = np.exp((2 * (des_entropy - h_unscaled)) / d)
@@ -122,7 +125,8 @@ class VipsComponentAdaptation(ComponentAdaptation):
             ctx = self.model.ctx
             plp = self.target_lnpdf.log_density(ctx.asarray(prior_samples))
             samples = ctx.asarray(np.concatenate([samples.numpy(), prior_samples]))
-            target_lnpdfs = np.concatenate([target_lnpdfs.numpy(), np.asarray(plp.numpy() if hasattr(plp, "numpy") else plp)])
+            target_lnpdfs = ctx.asarray(np.concatenate([target_lnpdfs.numpy(),
+                                                        np.asarray(plp.numpy() if hasattr(plp, "numpy") else plp)]).astype(np.float32))
         self.add_at_best_location(samples, target_lnpdfs)
 
     def deletion_criteria(self):

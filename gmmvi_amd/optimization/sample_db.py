@@ -277,7 +277,12 @@ class SampleDB:
         n = self._samples.n
         # N distinct rows in random order == shuffle(range(n))[:N], without the O(n) permutation of a 10^7-row DB
         idx = rng.choice(n, size=min(int(N), n), replace=False).astype(np.int32)
-        didx = self.ctx.asarray(idx, np.int32)
+        # the index list goes up in pieces that fit the pinned staging ring (gmmvi_upload: no wait for the stream); one 400 KB
+        # copy would be synchronous and park the host until the iteration's kernels have drained
+        didx = self.ctx.empty((idx.shape[0],), np.int32)
+        piece = 16000
+        for lo in range(0, idx.shape[0], piece):
+            didx.rows(lo, min(lo + piece, idx.shape[0])).set(idx[lo:lo + piece])
         return hip_ops.gather_rows(self.ctx, self.samples, didx), hip_ops.gather_rows(self.ctx, self.target_lnpdfs, didx)
 
     # ---- background density ------------------------------------------------------------------------------------------

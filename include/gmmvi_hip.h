@@ -85,6 +85,12 @@ int gmmvi_copy_batch(gmmvi_ctx* ctx, int n, void* const* dst_dev, const void* co
  * consecutive segments (seg_words[j] words each); dst[j] receives segment j of all ranks back to back,
  * dst[j][r * seg_words[j] + i] = src[r * chunk_words + seg_offset_j + i].  One launch; lets the sharded iteration send
  * several arrays in ONE collective (sharded.py E1-E3). */
+/* GMM.replace_weights (models/gmm.py:173-181) on the device: out = lw - logsumexp(lw), the sum in fp64. */
+int gmmvi_normalize_logw(gmmvi_ctx* ctx, const float* logw_in_dev, int n, float* logw_out_dev);
+/* VipsComponentAdaptation.add_at_best_location (component_adaptation.py:192-226): index_out[0] = argmax_n of
+ * log p~(x_n) - max(max_m log q(x_m) - threshold, log q(x_n)) over n candidates (first index on ties, fp64). */
+int gmmvi_add_heuristic_argmax(gmmvi_ctx* ctx, const float* model_ld_dev, const float* target_lnpdfs_dev, int n, double threshold,
+                               int32_t* index_out_dev);
 int gmmvi_unpack_gathered(gmmvi_ctx* ctx, const void* src_dev, int n_ranks, size_t chunk_words, int n_seg,
                           const size_t* seg_words, void* const* dst_dev);
 /* dst[i * stride] = value, i < count: a new component's column of the [H, Kcap] reward / weight history rings
