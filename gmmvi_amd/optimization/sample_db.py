@@ -29,7 +29,7 @@ class _Growable:
     # the first allocation holds FIRST_APPENDS appends of the first one's size (at most FIRST_BYTES): a run of a few hundred
     # iterations then never re-allocates -- a doubling is a hipMalloc (host-synchronous) plus a copy of everything so far, and a
     # short timed window that happens to contain one reads several percent slower (bench.py: 20 steps against 200)
-    FIRST_APPENDS, FIRST_BYTES = 256, 1 << 30
+    FIRST_APPENDS, FIRST_BYTES = 256, 4 << 30
 
     def reserve(self, m):
         if self.n + m > self.buf.shape[0]:
