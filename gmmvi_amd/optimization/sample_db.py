@@ -76,7 +76,10 @@ class _HostGrowable:
     def append(self, arr):
         m = arr.shape[0]
         if self.n + m > self.buf.shape[0]:
-            new = np.zeros(max(2 * self.buf.shape[0], self.n + m), self.buf.dtype)
+            # room for 256 appends of the first one's size at the first growth (as the device buffers), doubling afterwards: a
+            # doubling copies everything so far on the host (1.3 ms at 2.6 M entries: one slow iteration)
+            first = self.buf.shape[0] <= 1024 and self.n == 0
+            new = np.empty(max(2 * self.buf.shape[0], self.n + m, 256 * m if first else 0), self.buf.dtype)
             new[:self.n] = self.buf[:self.n]
             self.buf = new
         self.buf[self.n:self.n + m] = arr

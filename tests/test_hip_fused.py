@@ -144,3 +144,50 @@ def test_fast_path_steps_aside():
     fast.ng_based_updater.want_info = True
     assert not fast._fast_path.eligible()
     fast.train_iter()                                            # and the modular path still runs
+
+
+
+def test_early_draw_is_dropped_when_something_changes_in_between():
+    """The single-call iteration draws the NEXT iteration's samples behind its component update (csrc/riders.h).  That draw
+    must only be used if nothing touched the components, the sample counts or the database since: here the components are
+    replaced, an iteration runs on the module-by-module path, and the desired samples per component change between
+    single-call iterations -- the trajectories must stay bit-equal to a twin that never draws early."""
+    cfg = samtron_config(48)
+    o = make_oracle("stm", 6, 5, 48, 29, cfg)
+    early = make_device("stm", 6, 5, 48, 29, cfg, o)
+    plain = make_device("stm", 6, 5, 48, 29, cfg, o)
+    plain._fast_path.presample = False
+    for g in (early, plain):
+        g._fast_path.explicit_estimate = True
+
+    def both(fn):
+        fn(early); fn(plain)
+
+    def check(tag):
+        for name in ("means", "chol_cov", "log_weights", "stepsizes"):
+            np.testing.assert_array_equal(getattr(early.model, name).numpy(), getattr(plain.model, name).numpy(), err_msg=f"{tag}: {name}")
+        np.testing.assert_array_equal(early.sample_db.samples.numpy(), plain.sample_db.samples.numpy(), err_msg=tag)
+
+    for _ in range(3):
+        both(lambda g: g.train_iter())
+    assert early._fast_path._presample_token is not None and plain._fast_path._presample_token is None
+    check("three single-call iterations")
+    # (1) the components are replaced: the samples drawn early came from the old ones
+    both(lambda g: g.model.replace_components(g.model.means.numpy() + 0.25, g.model.chol_cov.numpy()))
+    both(lambda g: g.train_iter())
+    check("after replace_components")
+    # (2) an iteration on the module-by-module path in between
+    def modular_iteration(g):
+        g._fast_path.enabled = False
+        g.train_iter()
+        g._fast_path.enabled = True
+    both(modular_iteration)
+    both(lambda g: g.train_iter())
+    check("after a module-by-module iteration")
+    # (3) another number of samples per component
+    def fewer(g):
+        g.sample_selector.desired_samples_per_component = 40
+    both(fewer)
+    both(lambda g: g.train_iter())
+    both(lambda g: g.train_iter())
+    check("after changing the samples per component")
