@@ -136,6 +136,22 @@ def get_context():
     return _CTX
 
 
+_F32, _I32 = np.dtype(np.float32), np.dtype(np.int32)
+_DTYPES = {np.float32: _F32, np.int32: _I32, _F32: _F32, _I32: _I32}
+
+
+def _as_shape(shape):
+    """Tuple of Python ints (NumPy integers would leak into pointer arithmetic)."""
+    if type(shape) is tuple:
+        for v in shape:
+            if type(v) is not int:
+                return tuple(int(v) for v in shape)
+        return shape
+    if isinstance(shape, (int, np.integer)):
+        return (int(shape),)
+    return tuple(int(v) for v in shape)
+
+
 class DeviceArray:
     """Dense row-major fp32 / int32 array in HBM."""
     __slots__ = ("ctx", "ptr", "shape", "dtype", "_owner", "_base", "_cap", "__weakref__")
@@ -144,23 +160,26 @@ class DeviceArray:
     def __init__(self):
         raise TypeError("use Context.empty / Context.asarray")
 
+    # (these run a few dozen times per iteration on the module-by-module and the sample-reuse paths: the common cases -- a tuple
+    # of Python ints, np.float32 / np.int32 -- skip the normalisation)
     @classmethod
     def _alloc(cls, ctx, shape, dtype):
         self = object.__new__(cls)
-        shape = (int(shape),) if isinstance(shape, (int, np.integer)) else tuple(int(s) for s in shape)
-        dtype = np.dtype(dtype)
-        if dtype not in (np.dtype(np.float32), np.dtype(np.int32)):
-            raise TypeError(f"DeviceArray supports float32 and int32, not {dtype}")
-        nbytes = math.prod(shape) * 4
-        ptr, cap = ctx._alloc_bytes(nbytes)
-        self.ctx, self.ptr, self.shape, self.dtype, self._owner, self._base = ctx, ptr, shape, dtype, True, None
+        shape = _as_shape(shape)
+        dt = _DTYPES.get(dtype)
+        if dt is None:
+            dt = np.dtype(dtype)
+            if dt != _F32 and dt != _I32:
+                raise TypeError(f"DeviceArray supports float32 and int32, not {dt}")
+        ptr, cap = ctx._alloc_bytes(math.prod(shape) * 4)
+        self.ctx, self.ptr, self.shape, self.dtype, self._owner, self._base = ctx, ptr, shape, dt, True, None
         self._cap = cap
         return self
 
     @classmethod
     def _view(cls, base, ptr, shape):
         self = object.__new__(cls)
-        self.ctx, self.ptr, self.shape, self.dtype = base.ctx, ptr, tuple(int(s) for s in shape), base.dtype
+        self.ctx, self.ptr, self.shape, self.dtype = base.ctx, ptr, _as_shape(shape), base.dtype
         self._owner, self._base, self._cap = False, base, 0
         return self
 
@@ -235,8 +254,8 @@ class DeviceArray:
 
     def reshape(self, *shape):
         shape = shape[0] if len(shape) == 1 and not isinstance(shape[0], (int, np.integer)) else shape
-        shape = tuple(int(s) for s in shape)
-        if shape.count(-1) == 1:
+        shape = _as_shape(shape)
+        if -1 in shape and shape.count(-1) == 1:
             known = math.prod(s for s in shape if s != -1)
             shape = tuple(self.size // max(known, 1) if s == -1 else s for s in shape)
         if math.prod(shape) != self.size:
