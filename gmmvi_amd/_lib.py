@@ -76,6 +76,10 @@ _PROTOS = {
     "gmmvi_event_create": (_i, [_p, C.POINTER(_p)]),
     "gmmvi_event_destroy": (_i, [_p, _p]),
     "gmmvi_event_record": (_i, [_p, _p]),
+    "gmmvi_event_synchronize": (_i, [_p, _p]),
+    "gmmvi_host_alloc": (_i, [_p, _sz, C.POINTER(_p)]),
+    "gmmvi_host_free": (_i, [_p, _p]),
+    "gmmvi_download_async": (_i, [_p, _p, _p, _sz]),
     "gmmvi_event_elapsed_ms": (_i, [_p, _p, _p, C.POINTER(_f)]),
     "gmmvi_profile_enable": (_i, [_p, _i]),
     "gmmvi_profile_report": (_i, [_p, C.c_char_p, _sz]),

@@ -127,6 +127,26 @@ int gmmvi_download(gmmvi_ctx* ctx, void* dst_host, const void* src_dev, size_t n
     return GMMVI_OK;
 }
 
+// a device -> host copy that does NOT wait: dst must be pinned host memory (gmmvi_host_alloc); the data is there once an event
+// recorded behind it has been reached (gmmvi_event_synchronize)
+int gmmvi_download_async(gmmvi_ctx* ctx, void* dst_pinned_host, const void* src_dev, size_t nbytes) {
+    if (nbytes == 0) return GMMVI_OK;
+    GMMVI_ARG_CHECK(ctx, dst_pinned_host && src_dev);
+    GMMVI_HIP_CHECK(ctx, hipMemcpyAsync(dst_pinned_host, src_dev, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    return GMMVI_OK;
+}
+
+int gmmvi_host_alloc(gmmvi_ctx* ctx, size_t nbytes, void** out_host) {
+    GMMVI_ARG_CHECK(ctx, out_host != nullptr && nbytes > 0);
+    GMMVI_HIP_CHECK(ctx, hipHostMalloc(out_host, nbytes, hipHostMallocDefault));
+    return GMMVI_OK;
+}
+
+int gmmvi_host_free(gmmvi_ctx* ctx, void* host) {
+    if (host) GMMVI_HIP_CHECK(ctx, hipHostFree(host));
+    return GMMVI_OK;
+}
+
 int gmmvi_copy(gmmvi_ctx* ctx, void* dst_dev, const void* src_dev, size_t nbytes) {
     if (nbytes == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, dst_dev && src_dev);
@@ -472,6 +492,12 @@ int gmmvi_event_destroy(gmmvi_ctx* ctx, void* event) {
 
 int gmmvi_event_record(gmmvi_ctx* ctx, void* event) {
     GMMVI_HIP_CHECK(ctx, hipEventRecord((hipEvent_t)event, ctx->stream));
+    return GMMVI_OK;
+}
+
+int gmmvi_event_synchronize(gmmvi_ctx* ctx, void* event) {
+    GMMVI_ARG_CHECK(ctx, event != nullptr);
+    GMMVI_HIP_CHECK(ctx, hipEventSynchronize((hipEvent_t)event));
     return GMMVI_OK;
 }
 

@@ -60,7 +60,7 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
     GMMVI_ARG_CHECK(ctx, p->means && p->chols && p->logw && p->packed && p->packed_new && p->stepsizes && p->last_eta &&
                              p->l2 && p->num_updates && p->offsets && p->bg_logw && p->db_samples && p->db_tlp &&
                              p->db_tgrad && p->db_mapping && p->reward_next && p->wstate);
-    GMMVI_ARG_CHECK(ctx, p->n_old >= 0 && p->max_per_component >= 0);
+    GMMVI_ARG_CHECK(ctx, p->n_old >= 0 && p->max_per_component >= 0 && p->phase >= 0 && p->phase <= 2);
     GMMVI_ARG_CHECK(ctx, p->n_old == 0 || (p->bg_packed != nullptr && p->bg_K >= 1 && p->bg_old != nullptr && p->bg_logw_new != nullptr));
     const int n_old = p->n_old;
     const int Na = n_old + N;                          // active samples: the reused ones followed by the new ones
@@ -81,10 +81,12 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
     float* bg_a = base; base += Na;                    // reused samples: the two halves of the background density
     float* bg_b = base; base += Na;
 
+    const int phase = p->phase;        // 0: everything; 1: through the component update; 2: the weight update
     float* x = p->db_samples;          // the new samples are written straight into the database
     float* xa = x - (size_t)n_old * D; // the active samples: the n_old database rows in front of them and the new ones
     const float* tlp_a = p->db_tlp - n_old;
     const float* tgrad_a = p->db_tgrad - (size_t)n_old * D;
+    if (phase != 2) {
     // ---- sample selection: draw, evaluate the target, append to the DB (sample_selector.py:160-219) --------------------
     // the element-wise bookkeeping (model snapshot into the DB, the two stepsize rules) rides in extra blocks of the
     // sampling launch, and the sampling blocks write the DB mapping (component index + base) directly
@@ -173,6 +175,8 @@ static int train_iter_samtron_body(gmmvi_ctx* ctx, const gmmvi_samtron_plan* p) 
     GMMVI_TRY(gmmvi_update_components_kl_from_slab(ctx, K, D, slab, Na, p->stein_flags, p->packed, a.H, a.g, p->means, p->chols,
                                                    p->stepsizes, p->temperature, p->l2_init, p->last_eta, p->l2, p->num_updates,
                                                    p->success_out ? p->success_out : a.success, p->packed_new));
+    }
+    if (phase == 1) return GMMVI_OK;
     // ---- weight update (gmmvi.py:172-173) ---------------------------------------------------------------------------------
     // (the merge of this sweep's log-density partials happens inside the expected-log-ratio kernel)
     ctx->defer_combine = true;

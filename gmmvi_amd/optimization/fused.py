@@ -48,7 +48,7 @@ class SamtronPlan(C.Structure):
         ("temperature", _f), ("l2_init", _f),
         ("component_stepsize_mode", _i), ("cs_min", _f), ("cs_max", _f), ("cs_inc", _f), ("cs_dec", _f),
         ("weight_stepsize_mode", _i), ("ws_min", _f), ("ws_max", _f), ("ws_inc", _f), ("ws_dec", _f),
-        ("weight_update_mode", _i), ("stein_flags", _i), ("presample_next", _i), ("presampled", _i),
+        ("weight_update_mode", _i), ("stein_flags", _i), ("presample_next", _i), ("presampled", _i), ("phase", _i),
     ]
 
 
@@ -65,6 +65,13 @@ class SamtronFastPath:
         # components, the counts or the database in between: fixed number of components, reuse ratio 0
         self.presample = os.environ.get("GMMVI_PRESAMPLE", "1") != "0"
         self._presample_token = None
+        # sample reuse: the effective sample sizes of the NEXT iteration's window need the updated components but not the weights;
+        # they are queued between the component update and the weight update (the iteration as two C calls) and read back
+        # asynchronously, so the next iteration does not start with a wait for the device
+        self.prefetch_counts = os.environ.get("GMMVI_PREFETCH_COUNTS", "1") != "0"
+        self._prefetch = None
+        self._pinned = None              # (pinned host pointer, floats, NumPy view)
+        self._event = None
         lib = _lib.load()
         lib.gmmvi_train_iter_samtron.restype = C.c_int
         lib.gmmvi_train_iter_samtron.argtypes = [C.c_void_p, C.POINTER(SamtronPlan)]
@@ -90,6 +97,12 @@ class SamtronFastPath:
         return bool(ok)
 
     def eligible(self):
+        ok = self._eligible()
+        if not ok and self._prefetch is not None:
+            self.drop_prefetch()
+        return ok
+
+    def _eligible(self):
         if not self.enabled:
             return False
         if self._static_ok is None:
@@ -108,6 +121,48 @@ class SamtronFastPath:
             return False                                   # the modular path thins the DB out first (sample_db.py:111-112)
         return sel.desired_samples_per_component >= 1
 
+    # ---- effective sample sizes of a reuse window, fetched ahead -----------------------------------------------------------
+    def _state_token(self):
+        """What the prefetched effective sample sizes depend on: the database as it is, the components, the selector."""
+        g = self.g
+        sel, db, model = g.sample_selector, g.sample_db, g.model.model
+        return (db._samples.n, db._means.n, db._epoch, int(db._num_samples_written), db._samples.buf.ptr, model.num_components,
+                id(model._packed), model.means.ptr, model.chol_cov.ptr, sel.desired_samples_per_component,
+                sel.reused_samples_per_component)
+
+    def drop_prefetch(self):
+        """The next iteration will not use what was fetched ahead (another path runs it, or something changed): the database's
+        window caches go back to where they were."""
+        pf, self._prefetch = self._prefetch, None
+        if pf is not None:
+            db = self.g.sample_db
+            db._bg_cache, db._pd = pf["db_caches"]
+
+    def _pinned_floats(self, n):
+        ctx = self.g.model.model.ctx
+        if self._pinned is None or self._pinned[1] < n:
+            if self._pinned is not None:
+                ctx.sync()
+                ctx.check(ctx.lib.gmmvi_host_free(ctx.handle, self._pinned[0]))
+            cap = max(256, 2 * n)
+            ptr = C.c_void_p()
+            ctx.check(ctx.lib.gmmvi_host_alloc(ctx.handle, 4 * cap, C.byref(ptr)))
+            self._pinned = (ptr.value, cap, np.ctypeslib.as_array((C.c_float * cap).from_address(ptr.value)))
+        if self._event is None:
+            self._event = ctx.event()
+        return self._pinned
+
+    def _issue_counts(self):
+        """The selector's launches for the effective sample sizes of the newest reuse window (sample_selector.py:140-202):
+        background density of the window, component log densities of the current model on it, effective sample sizes.
+        -> (ess [K] on the device, window background density, its mixture, window length)."""
+        g = self.g
+        sel, db, model = g.sample_selector, g.sample_db, g.model.model
+        n_reuse = sel.reused_samples_per_component * model.num_components
+        bg_old, xs_old, _, _, _ = db.get_newest_samples(n_reuse)
+        ld_old = model.component_log_densities(xs_old)
+        return sel.get_effective_samples(ld_old, bg_old), bg_old, db._bg_cache["mix"], int(xs_old.shape[0])
+
     def _new_sample_counts(self):
         """Per-component numbers of new samples and the window of reused ones (sample_selector.py:160-219).
         -> (counts [K] int64, n_old).  Reuse ratio 0: every component draws its full share, nothing is read back."""
@@ -117,14 +172,69 @@ class SamtronFastPath:
         n_reuse = sel.reused_samples_per_component * k
         if n_reuse == 0 or db._samples.n == 0:
             return np.full(k, s, np.int64), 0
+        pf = self._prefetch
+        if pf is not None:
+            if pf["token"] == self._state_token():
+                # fetched ahead by the previous iteration, behind its component update: normally long since there
+                self._prefetch = None
+                ctx = model.ctx
+                # the window's mixture (its snapshot blocks, its log weights) does not depend on the counts either: its device
+                # work is queued before the wait
+                mix = pf["bg_mix"]() if callable(pf["bg_mix"]) else pf["bg_mix"]
+                mix.packed, mix.logw_dev
+                pf["bg_mix"] = mix
+                ctx.check(ctx.lib.gmmvi_event_synchronize(ctx.handle, self._event))
+                n_eff = np.floor(self._pinned[2][:k]).astype(np.int64)
+                self._bg_old, self._bg_mix = pf["bg_old"], pf["bg_mix"]
+                return np.maximum(1, s - n_eff), pf["n_old"]
+            self.drop_prefetch()
         # exactly the selector's launches: background density of the newest n_reuse samples, component log-densities of the
         # current model on them, effective sample sizes; the [K] result is read back (host synchronisation)
-        bg_old, xs_old, _, _, _ = db.get_newest_samples(n_reuse)
-        ld_old = model.component_log_densities(xs_old)
-        n_eff = np.floor(sel.get_effective_samples(ld_old, bg_old).numpy()).astype(np.int64)
+        ess, bg_old, bg_mix, n_old = self._issue_counts()
+        n_eff = np.floor(ess.numpy()).astype(np.int64)
         self._bg_old = bg_old            # the window's background density so far: the call extends it instead of redoing it
-        self._bg_mix = db._bg_cache["mix"]     # ... and the mixture it belongs to
-        return np.maximum(1, s - n_eff), int(xs_old.shape[0])
+        self._bg_mix = bg_mix            # ... and the mixture it belongs to
+        return np.maximum(1, s - n_eff), n_old
+
+    def _fill_static(self, p, packed_cur, packed_new, success):
+        """The plan fields that do not depend on the iteration's sample counts."""
+        g = self.g
+        m = g.model
+        model = m.model
+        sel = g.sample_selector
+        tgt = sel.target_distribution._fast_path_target()
+        p.target_kind = tgt["kind"]
+        p.target_family, p.target_K, p.target_nu = tgt.get("family", 0), tgt.get("K", 0), tgt.get("nu", 0.0)
+        p.target_packed, p.target_logw = tgt.get("packed"), tgt.get("logw")
+        p.planar_prior_std, p.planar_goals = tgt.get("prior_std"), tgt.get("goals")
+        p.planar_goals_count, p.planar_likelihood_std = tgt.get("G", 0), tgt.get("lik_std", 0.0)
+        p.means, p.chols, p.logw = model.means.ptr, model.chol_cov.ptr, model.log_weights.ptr
+        p.packed, p.packed_new = packed_cur.ptr, packed_new.ptr
+        p.stepsizes, p.last_eta, p.l2 = m.stepsizes.ptr, m.last_log_etas.ptr, m.l2_regularizers.ptr
+        p.num_updates, p.success_out = m.num_received_updates.ptr, success.ptr
+        p.seed = int(model.seed) & 0xFFFFFFFFFFFFFFFF
+        p.reward_prev, p.reward_last = m.reward_slot(1).ptr, m.reward_slot(0).ptr
+        p.reward_next = m.next_reward_slot().ptr
+        p.weight_slot = m.next_weight_slot().ptr
+        ws, cs, wu = g.weight_stepsize_adapter, g.component_stepsize_adapter, g.weight_updater
+        p.wstate = ws._state.ptr
+        p.temperature, p.l2_init = float(g.temperature), float(m.initial_regularizer)
+        if type(cs) is ImprovementBasedComponentStepsizeAdaptation:
+            p.component_stepsize_mode = 1
+            p.cs_min, p.cs_max = cs.min_stepsize, cs.max_stepsize
+            p.cs_inc, p.cs_dec = cs.stepsize_inc_factor, cs.stepsize_dec_factor
+        else:
+            p.component_stepsize_mode = 0
+        if type(ws) is ImprovementBasedWeightStepsizeAdaptation:
+            p.weight_stepsize_mode = 1
+            p.ws_min, p.ws_max = ws.min_stepsize, ws.max_stepsize
+            p.ws_inc, p.ws_dec = ws.stepsize_inc_factor, ws.stepsize_dec_factor
+        else:
+            p.weight_stepsize_mode = 0
+        p.weight_update_mode = 0 if type(wu) is TrustRegionBasedWeightUpdater else 1
+        p.stein_flags = _lib.SELF_NORMALIZED if g.ng_estimator._use_self_normalized_importance_weights else 0
+        if self.explicit_estimate:
+            p.stein_flags |= _lib.EXPLICIT_ESTIMATE
 
     # ---- one iteration -----------------------------------------------------------------------------------------------------
     def step(self):
@@ -135,6 +245,14 @@ class SamtronFastPath:
         sel, db = g.sample_selector, g.sample_db
         k, d = model.num_components, model.num_dimensions
         p = self.plan
+
+        # everything that does not depend on this iteration's sample counts comes first: with counts fetched ahead the device
+        # may still be on its way to them, and this is host time it hides
+        stride = db._packed.inner[0]
+        packed_cur = model.packed
+        packed_new = ctx.empty((k, stride))
+        success = ctx.empty((k,), np.int32)
+        self._fill_static(p, packed_cur, packed_new, success)
 
         counts, n_old = self._new_sample_counts()
         n = int(counts.sum())
@@ -156,10 +274,6 @@ class SamtronFastPath:
                            (db._mapping_dev, 2 * n if presample_next else n), (db._means, k), (db._chols, k), (db._packed, k)):
             grow.reserve(rows)
         s0, c0 = db._samples.n, db._means.n
-        stride = db._packed.inner[0]
-        packed_cur = model.packed
-        packed_new = ctx.empty((k, stride))
-        success = ctx.empty((k,), np.int32)
 
         # background mixture of the active window (sample_db.py:216-227): with nothing reused its components are the
         # model's own and share the model's sweep; otherwise the snapshots of the window's sampling components (the new
@@ -184,19 +298,9 @@ class SamtronFastPath:
             p.bg_log_share_old, p.bg_log_share_new = db.log_shares(n_old, n)
         p.max_per_component = int(counts.max())
 
-        tgt = sel.target_distribution._fast_path_target()
         p.K, p.D, p.N = k, d, n
-        p.target_kind = tgt["kind"]
-        p.target_family, p.target_K, p.target_nu = tgt.get("family", 0), tgt.get("K", 0), tgt.get("nu", 0.0)
-        p.target_packed, p.target_logw = tgt.get("packed"), tgt.get("logw")
-        p.planar_prior_std, p.planar_goals = tgt.get("prior_std"), tgt.get("goals")
-        p.planar_goals_count, p.planar_likelihood_std = tgt.get("G", 0), tgt.get("lik_std", 0.0)
-        p.means, p.chols, p.logw = model.means.ptr, model.chol_cov.ptr, model.log_weights.ptr
-        p.packed, p.packed_new = packed_cur.ptr, packed_new.ptr
-        p.stepsizes, p.last_eta, p.l2 = m.stepsizes.ptr, m.last_log_etas.ptr, m.l2_regularizers.ptr
-        p.num_updates, p.success_out = m.num_received_updates.ptr, success.ptr
         p.offsets, p.bg_logw = offsets_dev.ptr, bg_logw.ptr
-        p.seed, p.first_index = int(model.seed) & 0xFFFFFFFFFFFFFFFF, int(db._num_samples_written)
+        p.first_index = int(db._num_samples_written)
         p.db_samples = db._samples.buf.ptr + s0 * d * 4
         p.db_tlp = db._target_lnpdfs.buf.ptr + s0 * 4
         p.db_tgrad = db._target_grads.buf.ptr + s0 * d * 4
@@ -204,28 +308,6 @@ class SamtronFastPath:
         p.db_means = db._means.buf.ptr + c0 * d * 4
         p.db_chols = db._chols.buf.ptr + c0 * d * d * 4
         p.db_packed = db._packed.buf.ptr + c0 * stride * 4
-        p.reward_prev, p.reward_last = m.reward_slot(1).ptr, m.reward_slot(0).ptr
-        p.reward_next = m.next_reward_slot().ptr
-        p.weight_slot = m.next_weight_slot().ptr
-        ws, cs, wu = g.weight_stepsize_adapter, g.component_stepsize_adapter, g.weight_updater
-        p.wstate = ws._state.ptr
-        p.temperature, p.l2_init = float(g.temperature), float(m.initial_regularizer)
-        if type(cs) is ImprovementBasedComponentStepsizeAdaptation:
-            p.component_stepsize_mode = 1
-            p.cs_min, p.cs_max = cs.min_stepsize, cs.max_stepsize
-            p.cs_inc, p.cs_dec = cs.stepsize_inc_factor, cs.stepsize_dec_factor
-        else:
-            p.component_stepsize_mode = 0
-        if type(ws) is ImprovementBasedWeightStepsizeAdaptation:
-            p.weight_stepsize_mode = 1
-            p.ws_min, p.ws_max = ws.min_stepsize, ws.max_stepsize
-            p.ws_inc, p.ws_dec = ws.stepsize_inc_factor, ws.stepsize_dec_factor
-        else:
-            p.weight_stepsize_mode = 0
-        p.weight_update_mode = 0 if type(wu) is TrustRegionBasedWeightUpdater else 1
-        p.stein_flags = _lib.SELF_NORMALIZED if g.ng_estimator._use_self_normalized_importance_weights else 0
-        if self.explicit_estimate:
-            p.stein_flags |= _lib.EXPLICIT_ESTIMATE
 
         # this iteration's samples may already be there: drawn by the previous call behind its component update
         here = (db._samples.buf.ptr, db._mapping_dev.buf.ptr, s0, c0, n, k, key, int(db._num_samples_written),
@@ -234,6 +316,8 @@ class SamtronFastPath:
         p.presampled = int(tok is not None and n_old == 0 and tok[0] == here and tok[1] is model._packed)
         p.presample_next = int(presample_next)
 
+        prefetch_next = self.prefetch_counts and sel.reused_samples_per_component > 0
+        p.phase = 1 if prefetch_next else 0
         try:
             ctx.check(self._fn(ctx.handle, C.byref(p)))
         except Exception:
@@ -250,14 +334,29 @@ class SamtronFastPath:
         db._num_samples_written += n
         if n_old > 0:
             db._bg_cache = None          # the window's density was extended inside the call (SampleDB.get_newest_samples does the same)
+        model._packed = packed_new
+        model._eval_cache = None
+        if prefetch_next:
+            # between the component update and the weight update: the next iteration's effective sample sizes (they need the
+            # appended samples and the updated components, both there; not the weights), read back without waiting
+            caches = (db._bg_cache, db._pd)
+            ess, bg_old_next, bg_mix_next, n_old_next = self._issue_counts()
+            pinned = self._pinned_floats(k)
+            ctx.check(ctx.lib.gmmvi_download_async(ctx.handle, pinned[0], ess.ptr, 4 * k))
+            ctx.record(self._event)
+            p.phase = 2
+            ctx.check(self._fn(ctx.handle, C.byref(p)))
+            p.phase = 0
+            self._prefetch = {"ess": ess, "bg_old": bg_old_next, "bg_mix": bg_mix_next, "n_old": n_old_next,
+                              "db_caches": caches, "token": None}
         m.commit_rewards()
         if k > 1:
             m._t_weight += 1
-        model._packed = packed_new
-        model._eval_cache = None
         if presample_next:
             self._presample_token = ((db._samples.buf.ptr, db._mapping_dev.buf.ptr, s0 + n, c0 + k, n, k, key,
                                       int(db._num_samples_written), int(model.seed), model.means.ptr, model.chol_cov.ptr,
                                       offsets_dev.ptr), packed_new)
         g.ng_based_updater.last_success = success
         g.num_updates.assign_add(1)
+        if self._prefetch is not None:
+            self._prefetch["token"] = self._state_token()

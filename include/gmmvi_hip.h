@@ -124,6 +124,13 @@ int gmmvi_event_create(gmmvi_ctx* ctx, void** out_event);
 int gmmvi_event_destroy(gmmvi_ctx* ctx, void* event);
 int gmmvi_event_record(gmmvi_ctx* ctx, void* event);
 int gmmvi_event_elapsed_ms(gmmvi_ctx* ctx, void* start, void* stop, float* out_ms);       /* synchronises on stop */
+int gmmvi_event_synchronize(gmmvi_ctx* ctx, void* event);                                   /* waits until the stream has reached it */
+/* A read-back that does not wait: dst is pinned host memory from gmmvi_host_alloc; valid once an event recorded behind the copy
+ * has been reached (the effective sample sizes of the NEXT iteration's reuse window are fetched this way while the current
+ * iteration's last launches still run: optimization/fused.py). */
+int gmmvi_host_alloc(gmmvi_ctx* ctx, size_t nbytes, void** out_pinned_host);
+int gmmvi_host_free(gmmvi_ctx* ctx, void* pinned_host);
+int gmmvi_download_async(gmmvi_ctx* ctx, void* dst_pinned_host, const void* src_dev, size_t nbytes);
 
 /* Per-kernel timing for bench.py's roofline leg: while enabled, every kernel-launching entry point brackets its
  * launches with HIP events on the context's stream.  gmmvi_profile_report synchronises, writes one line per kernel
@@ -330,6 +337,11 @@ typedef struct gmmvi_samtron_plan {
      * presampled != 0: db_samples / db_mapping already hold this iteration's draw (made by the previous call with
      *   presample_next, nothing touched the components, the offsets or the database since): no sampling launch. */
     int32_t presample_next, presampled;
+    /* 0: the whole iteration.  1 / 2: the iteration in two calls -- 1 ends behind the component update, 2 is the weight
+     * update (post-update sweep, expected log-ratios, weight step).  Between the two the caller may queue work that needs the
+     * updated components but not the weights: with sample reuse the effective sample sizes of the NEXT iteration's window
+     * (sample_selector.py:140-202), read back asynchronously, so that the next iteration starts without waiting for them. */
+    int32_t phase;
 } gmmvi_samtron_plan;
 int gmmvi_train_iter_samtron(gmmvi_ctx* ctx, const gmmvi_samtron_plan* plan);
 
