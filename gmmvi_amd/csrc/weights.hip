@@ -272,6 +272,10 @@ __global__ __launch_bounds__(64) void update_weights_kernel(int mode, int K, flo
             weights_search_reg<2>(K, beta, bound, lw, E, nl, kl, eta, updated);
         } else if (K <= 256) {
             weights_search_reg<4>(K, beta, bound, lw, E, nl, kl, eta, updated);
+        } else if (K <= 512) {                                                              // (adaptive runs grow there: the LDS form
+            weights_search_reg<8>(K, beta, bound, lw, E, nl, kl, eta, updated);             //  below took 45 us at K = 290)
+        } else if (K <= 1024) {
+            weights_search_reg<16>(K, beta, bound, lw, E, nl, kl, eta, updated);
         } else {
             float lb = -45.f, ub = 45.f;                                                  // :276-277
             float log_eta = 0.5f * (ub + lb);

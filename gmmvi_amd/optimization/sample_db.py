@@ -278,8 +278,10 @@ class SampleDB:
         """sample_db.py:137-152 (tf.random.shuffle -> NumPy Generator permutation)."""
         rng = np.random.default_rng() if rng is None else rng
         n = self._samples.n
-        # N distinct rows in random order == shuffle(range(n))[:N], without the O(n) permutation of a 10^7-row DB
-        idx = rng.choice(n, size=min(int(N), n), replace=False).astype(np.int32)
+        # a uniformly random N-subset of the rows, as shuffle(range(n))[:N] is; the order of the subset is left unshuffled: NumPy
+        # then draws it in O(N) instead of O(n) (1.6 ms against 8.6 ms at n = 3e6; the database holds up to 1e7 rows), and the
+        # consumer -- the arg-max of the add heuristic -- does not depend on the order
+        idx = rng.choice(n, size=min(int(N), n), replace=False, shuffle=False).astype(np.int32)
         # the index list goes up in pieces that fit the pinned staging ring (gmmvi_upload: no wait for the stream); one 400 KB
         # copy would be synchronous and park the host until the iteration's kernels have drained
         didx = self.ctx.empty((idx.shape[0],), np.int32)

@@ -71,7 +71,10 @@ class SampleDB:
     def get_random_sample(self, n, rng):
         """sample_db.py:137-152 (tf.random.shuffle replaced by a NumPy Generator permutation)."""
         total = self.samples.shape[0]
-        idx = rng.choice(total, size=min(int(n), total), replace=False)     # == shuffle(range(total))[:n] in law
+        # a uniformly random n-subset, as shuffle(range(total))[:n] is; its ORDER is not shuffled (NumPy then draws it in O(n)
+        # instead of O(total): 1.6 ms against 8.6 ms at total = 3e6) -- the consumer, an arg-max over the candidates, does not
+        # depend on the order
+        idx = rng.choice(total, size=min(int(n), total), replace=False, shuffle=False)
         return self.samples[idx], self.target_lnpdfs[idx]
 
     def gaussian_log_pdf(self, mean, chol, inv_chol, x):

@@ -507,7 +507,7 @@ def test_expected_log_ratios(ctx, rng, k, n):
         np.testing.assert_allclose(e.numpy(), ref, rtol=2e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("k", [2, 6, 100, 257])
+@pytest.mark.parametrize("k", [2, 6, 100, 257, 512, 700, 1024, 1300])     # register forms up to 1024, the LDS loop behind
 def test_update_weights(ctx, rng, k):
     lw = np.log(rng.dirichlet(np.ones(k)))
     lw = (lw - logsumexp(lw)).astype(np.float32).astype(np.float64)
