@@ -7,6 +7,7 @@
 // inverse the reference also keeps for its sample database, optimization/sample_db.py:121), models/gmm.py:183-216,274-300,
 // :361-386, gmmvi_modules/ng_estimator.py:146-263, gmmvi_modules/ng_based_component_updater.py:244-524.
 #include "blocked.h"
+#include "bf16_split.h"
 #include "wave_reduce.h"
 #include <cfloat>
 #include <cstdlib>
@@ -82,20 +83,7 @@ __device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<u
 // ds_read_b64_tr_b16, which hands lane i of a 16-lane group column i of a 4 x 16 block -- the MFMA operand order.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    const f32x2_t f = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
-}
-// (a, b) -> three packed bf16 pairs, a in the low half
-__device__ __forceinline__ void split_pair(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-    p1 = cvt_pk_bf16(a, b);
-    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
-    p2 = cvt_pk_bf16(ra, rb);
-    p3 = cvt_pk_bf16(ra - __uint_as_float(p2 << 16), rb - __uint_as_float(p2 & 0xffff0000u));
-}
+// (bf16x2_t, f32x2_t, cvt_pk_bf16, split_pair: bf16_split.h)
 constexpr int split_rowsp(int rows) {                  // row stride (elements) of a k-major bf16 image
     int r = rows;
     while (r % 128 != 32 && r % 128 != 96) r += 4;

@@ -11,6 +11,7 @@
 #include "blocked.h"
 #include "wave_reduce.h"
 #include "stein_finalize.h"
+#include "stein_tile.h"
 #include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -44,15 +45,6 @@ static int launch_stein_finalize(gmmvi_ctx* ctx, int K, int D, int R, int N, int
     return GMMVI_OK;
 }
 
-// A wave-private LDS image: ordering its writes against the same wave's later reads only needs the wave's own LDS queue
-// drained (and the compiler kept from moving the accesses).  A workgroup-scope fence would also wait for every outstanding
-// GLOBAL access -- the prefetched rows of the next chunk -- ~1 us each time.
-#define WAVE_LDS_SYNC()                                        \
-    do {                                                       \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
-        __builtin_amdgcn_wave_barrier();                       \
-    } while (0)
-
 // =====================================================================================================================
 // Moment form (all D <= 63): the estimate is LINEAR in y = Sigma_k^-1 (x - mu_k), so nothing has to be whitened per sample:
 //     A_k = sum_n e_kn [g_n; 1] [x_n - mu_k; 1]^T            (one dense contraction over the samples)
@@ -80,35 +72,6 @@ static int launch_stein_finalize(gmmvi_ctx* ctx, int K, int D, int R, int N, int
 // The four waves are merged through LDS in fixed order (common maximum); one partial per (component, range) goes to the
 // slab that stein_finalize sums -- K x R x (D+1)^2 floats with R ~ CUs / stacks ranges instead of one per 256 samples.
 // =====================================================================================================================
-constexpr int SM_RS = 72;          // LDS row stride (floats) of the transposed images: 64 samples + 8
-constexpr int SM_NBMAX = 5;        // most components stacked in one tile row
-
-// Tiling of the padded dimension DP (covers D in (previous DP, DP]): MT row tiles for the D + 1 rows of [g; 1], NB components
-// stacked along NT column tiles -- the (NT, NB) with the fewest padded columns among NT <= NTMAX (accumulators: 4 MT NT
-// registers), ties to the smaller tile.
-template <int DP>
-struct SteinTile {
-    static constexpr int D1 = DP + 1 < 64 ? DP + 1 : 64;           // D <= 63
-    static constexpr int MT = (D1 + 15) / 16;
-    static constexpr int NTMAX = MT <= 2 ? 6 : (MT == 3 ? 6 : 7);
-    static constexpr int pick_nt() {
-        int best = 1;
-        long best_num = 0, best_den = 1;                        // efficiency best_num / best_den
-        for (int nt = 1; nt <= NTMAX; ++nt) {
-            int nb = (16 * nt) / D1;
-            if (nb > SM_NBMAX) nb = SM_NBMAX;
-            if (nb < 1) continue;
-            const long num = (long)nb * D1, den = 16L * nt;
-            if (num * best_den > best_num * den) { best = nt; best_num = num; best_den = den; }
-        }
-        return best;
-    }
-    static constexpr int NT = pick_nt();
-    static constexpr int NB = (16 * NT) / D1 < SM_NBMAX ? (16 * NT) / D1 : SM_NBMAX;
-    static constexpr int PREV = DP == 2 ? 0 : DP == 4 ? 2 : DP == 8 ? 4 : DP == 10 ? 8 : DP == 12 ? 10 : DP == 16 ? 12 : DP == 20 ? 16
-                                : DP == 24 ? 20 : DP == 32 ? 24 : DP == 40 ? 32 : DP == 50 ? 40 : 50;     // D > PREV
-};
-
 // A lane's row of a row-major [*, D] array into registers, VW floats per load (VW > 1: D == DP, rows VW*4-byte aligned); the
 // loads of a lane walk the same cache lines, only the first goes past the L1.  No per-lane predication: rows beyond the
 // range are CLAMPED to a valid row by the caller (finite data, weight 0).
@@ -173,7 +136,8 @@ void stein_moment_kernel(int K, int D_rt, int N, int wave_range, int stacks, int
     const int rows_g = D1 + 1, rows_x = D1;
     constexpr int rows_e = NB + 1;
     const int wave_floats = (rows_g + rows_x + rows_e) * SM_RS;
-    float* Tg = sm + (size_t)wave * wave_floats;
+    const int wave_stride = max(wave_floats, 16 * MT * (16 * NT + 1));      // (the region also takes the wave's result tile)
+    float* Tg = sm + (size_t)wave * wave_stride;
     float* Tx = Tg + rows_g * SM_RS;
     float* Te = Tx + rows_x * SM_RS;
     for (int e = lane; e < SM_RS; e += 64) { Tg[D1 * SM_RS + e] = 0.f; Te[NB * SM_RS + e] = 0.f; Tx[D * SM_RS + e] = 1.f; }
@@ -220,16 +184,26 @@ void stein_moment_kernel(int K, int D_rt, int N, int wave_range, int stacks, int
         }
     };
 
+    float a[NB], xr[DP], tr[DP], qr[DP];
+    auto fetch = [&](int n0) {
+        const size_t row = (size_t)min(n0 + lane, N - 1) * D;
+        log_weights(n0, a);
+        sm_load_row<DP, VW>(X + row, D, xr);
+        sm_load_row<DP, VW>(TG + row, D, tr);
+        sm_load_row<DP, VW>(QG + row, D, qr);
+    };
+    if (MT >= 4 && w_begin < w_end) fetch(w_begin);            // many row tiles: the first chunk's rows travel while pass 1 runs
+
     // ---- pass 1: the maximum of the log weights over this wave's samples, per component: the weights of pass 2 are referred
     // to it from the start, the accumulators never have to be rescaled ------------------------------------------------
     float M[NB];
 #pragma unroll
     for (int c = 0; c < NB; ++c) M[c] = -3.0e38f;
     for (int n0 = w_begin; n0 < w_end; n0 += 64) {
-        float a[NB];
-        log_weights(n0, a);
+        float a1[NB];
+        log_weights(n0, a1);
 #pragma unroll
-        for (int c = 0; c < NB; ++c) M[c] = fmaxf(M[c], a[c]);
+        for (int c = 0; c < NB; ++c) M[c] = fmaxf(M[c], a1[c]);
     }
 #pragma unroll
     for (int c = 0; c < NB; ++c) M[c] = wave_max(M[c]);
@@ -244,15 +218,7 @@ void stein_moment_kernel(int K, int D_rt, int N, int wave_range, int stacks, int
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[mt][nt][r] = 0.f;
-    float a[NB], xr[DP], tr[DP], qr[DP];
-    auto fetch = [&](int n0) {
-        const size_t row = (size_t)min(n0 + lane, N - 1) * D;
-        log_weights(n0, a);
-        sm_load_row<DP, VW>(X + row, D, xr);
-        sm_load_row<DP, VW>(TG + row, D, tr);
-        sm_load_row<DP, VW>(QG + row, D, qr);
-    };
-    if (w_begin < w_end) fetch(w_begin);
+    if (MT < 4 && w_begin < w_end) fetch(w_begin);
     for (int n0 = w_begin; n0 < w_end; n0 += 64) {
         const int n_here = min(64, w_end - n0);
         sm_store_rows<DP, EXACT>(Tx + lane, D, xr);
@@ -288,46 +254,84 @@ void stein_moment_kernel(int K, int D_rt, int N, int wave_range, int stacks, int
         WAVE_LDS_SYNC();
     }
 
-    // ---- merge the four waves (common maximum per component, fixed order), one partial per (component, range) ---------
-    if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < NB; ++c) sm_m[wave][c] = M[c];
-    }
-    __syncthreads();                                   // also: every wave is done with its images
-    float Mall[NB], fsc[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) {
-        Mall[c] = fmaxf(fmaxf(sm_m[0][c], sm_m[1][c]), fmaxf(sm_m[2][c], sm_m[3][c]));
-        fsc[c] = __expf(M[c] - Mall[c]);
-    }
-    constexpr int CW = 16 * NT + 1;
-    float* C = sm;                                     // [16 MT][CW]
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                float fs = 1.f;
-#pragma unroll
-                for (int c = 0; c < NB; ++c) fs = (cidx[nt] == c) ? fsc[c] : fs;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float* dst = C + (16 * mt + 4 * q + r) * CW + 16 * nt + c16;
-                        const float v = acc[mt][nt][r] * fs;
-                        *dst = (w == 0) ? v : *dst + v;
-                    }
-            }
+    if constexpr (MT >= 4) {
+        // ---- merge the four waves (common maximum per component, fixed order), one partial per (component, range): every wave
+        // parks its tile in its OWN image region (nobody else reads or writes it: no barrier in front), one barrier, then the
+        // store loop adds the four tiles, each scaled to the common maximum ---------------------------------------------------
+        constexpr int CW = 16 * NT + 1;
+        float* C = sm + (size_t)wave * wave_stride;        // [16 MT][CW]
+    #pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+    #pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+    #pragma unroll
+                for (int r = 0; r < 4; ++r) C[(16 * mt + 4 * q + r) * CW + 16 * nt + c16] = acc[mt][nt][r];
+        if (lane == 0) {
+    #pragma unroll
+            for (int c = 0; c < NB; ++c) sm_m[wave][c] = M[c];
         }
         __syncthreads();
+        const int DD = D1 * D1;
+    #pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            if (c < nb) {                                   // uniform
+                const float m0 = sm_m[0][c], m1 = sm_m[1][c], m2 = sm_m[2][c], m3 = sm_m[3][c];
+                const float Mall = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+                const float f0 = __expf(m0 - Mall), f1 = __expf(m1 - Mall), f2 = __expf(m2 - Mall), f3 = __expf(m3 - Mall);
+                float* dst = part + ((size_t)(k0 + c) * R + range_id) * DD;
+                for (int el = tid; el < DD; el += 256) {
+                    const int i = el / D1, j = el - i * D1;
+                    const float* src = sm + i * CW + c * D1 + j;
+                    // (explicit fused multiply-adds: every instance of the kernel rounds the same way)
+                    dst[el] = fmaf(src[3 * wave_stride], f3, fmaf(src[2 * wave_stride], f2, fmaf(src[wave_stride], f1, src[0] * f0)));
+                }
+                if (tid == 0) part_m[(size_t)(k0 + c) * R + range_id] = Mall;
+            }
+        }
+    } else {
+        // (up to three row tiles the tiles are small and the four rounds below cost less than the scaled four-way sum: D = 20
+        // 24.4 against 25.0 us, D = 40 72.6 against 75.4; D = 50: 89.5 against 80.3)
+        // ---- merge the four waves (common maximum per component, fixed order), one partial per (component, range) ---------
+        if (lane == 0) {
+    #pragma unroll
+            for (int c = 0; c < NB; ++c) sm_m[wave][c] = M[c];
+        }
+        __syncthreads();                                   // also: every wave is done with its images
+        float Mall[NB], fsc[NB];
+    #pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            Mall[c] = fmaxf(fmaxf(sm_m[0][c], sm_m[1][c]), fmaxf(sm_m[2][c], sm_m[3][c]));
+            fsc[c] = __expf(M[c] - Mall[c]);
+        }
+        constexpr int CW = 16 * NT + 1;
+        float* C = sm;                                     // [16 MT][CW]
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+    #pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float fs = 1.f;
+    #pragma unroll
+                    for (int c = 0; c < NB; ++c) fs = (cidx[nt] == c) ? fsc[c] : fs;
+    #pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float* dst = C + (16 * mt + 4 * q + r) * CW + 16 * nt + c16;
+                            const float v = acc[mt][nt][r] * fs;
+                            *dst = (w == 0) ? v : *dst + v;
+                        }
+                }
+            }
+            __syncthreads();
+        }
+        const int DD = D1 * D1;
+        for (int el = tid; el < nb * DD; el += 256) {
+            const int comp = el / DD, rem = el - comp * DD;
+            const int i = rem / D1, j = rem - i * D1;
+            part[((size_t)(k0 + comp) * R + range_id) * DD + rem] = C[i * CW + comp * D1 + j];
+        }
+        if (tid < nb) part_m[(size_t)(k0 + tid) * R + range_id] = Mall[tid];
     }
-    const int DD = D1 * D1;
-    for (int el = tid; el < nb * DD; el += 256) {
-        const int comp = el / DD, rem = el - comp * DD;
-        const int i = rem / D1, j = rem - i * D1;
-        part[((size_t)(k0 + comp) * R + range_id) * DD + rem] = C[i * CW + comp * D1 + j];
-    }
-    if (tid < nb) part_m[(size_t)(k0 + tid) * R + range_id] = Mall[tid];
 }
 
 template <int DP, int VW>
@@ -354,18 +358,18 @@ static int launch_stein_moment(gmmvi_ctx* ctx, int K, int D, const float* packed
     if (rc != GMMVI_OK) return rc;
     float* part = (float*)ctx->ws;
     float* part_m = part + part_floats;
-    size_t floats = (size_t)4 * (2 * D1 + ST::NB + 2) * SM_RS;
-    if (floats < (size_t)16 * ST::MT * (16 * ST::NT + 1)) floats = (size_t)16 * ST::MT * (16 * ST::NT + 1);
-    const size_t shmem = floats * sizeof(float);
-    static size_t attr = 64 * 1024;
-    if (shmem > attr) {
-        GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_moment_kernel<DP, VW>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr = shmem;
-    }
+    const int per_xcd = (stacks * R + 7) / 8;
     {
+        size_t floats = (size_t)(2 * D1 + ST::NB + 2) * SM_RS;                 // a wave's images ...
+        if (floats < (size_t)16 * ST::MT * (16 * ST::NT + 1)) floats = (size_t)16 * ST::MT * (16 * ST::NT + 1);     // ... or its result tile
+        const size_t shmem = 4 * floats * sizeof(float);
+        static size_t attr = 64 * 1024;
+        if (shmem > attr) {
+            GMMVI_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stein_moment_kernel<DP, VW>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            attr = shmem;
+        }
         GMMVI_PROF(ctx, "stein_partial");
-        const int per_xcd = (stacks * R + 7) / 8;
         hipLaunchKernelGGL((stein_moment_kernel<DP, VW>), dim3(8 * per_xcd), dim3(256), shmem, ctx->stream, K, D, N, wave_range,
                            stacks, R, packed, X, tgrad, qgrad, ld, bg, mapping, map_offset,
                            (flags & GMMVI_OWN_SAMPLES_ONLY) ? 1 : 0, part, part_m);

@@ -143,6 +143,11 @@ LONG_CASES = {
     # 200 samples per component, reuse ratio 0, initial stepsize 0.1, weight stepsize 1
     "c1": dict(kind="stm", d=20, k=45, s=200, seed=5, iters=260, every=10, adaptive=EXAMPLE5_ADAPTIVE,
                init=(100.0, 300.0)),
+    # the same run at the length the example states (examples/5_samtron_20D_student-T.py:30: 1501 iterations): the converged tail,
+    # where the stepsizes saturate and the deletion rule sees flat reward histories.  Its first 260 iterations ARE long_c1; behind
+    # them K / ids are compared in lock-step as long as they agree and statistically afterwards (test_hip_long_horizon.py)
+    "c1_full": dict(kind="stm", d=20, k=45, s=200, seed=5, iters=1501, every=50, adaptive=EXAMPLE5_ADAPTIVE,
+                    init=(100.0, 300.0), chaotic=True, lockstep=260),
     # BASELINE configs[3]'s example as it is run, examples/6_samtron_planar4.py:19-26: planar-4 target, 100 initial components
     # from the planar_robot_4.yml prior, a component ADDED EVERY iteration, deletions from iteration 11 on (del_iters 10),
     # 100 samples per component, reuse ratio 0, weight stepsize 5 (clipped by the rule's max_stepsize as upstream does)
