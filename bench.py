@@ -193,6 +193,9 @@ def make_gmmvi(w, n_gpus, rank):
         model.seed = w["seed"]
         wrapper = w["GmmWrapper"](model, 0.1, 1e-12, 10000)        # setup_experiment.py:40-41 history length
         return w["GMMVI"].build_from_config(w["cfg"], w["target"], wrapper)
+    if w["cfg"]["num_component_adapter_type"] == "adaptive":     # K changes: partition by component id (sharded_adaptive.py)
+        from gmmvi_amd.sharded_adaptive import ShardedAdaptiveGMMVI
+        return ShardedAdaptiveGMMVI.build(w, n_gpus, rank)
     from gmmvi_amd.sharded import ShardedGMMVI
     return ShardedGMMVI.build(w, n_gpus, rank)
 
@@ -392,7 +395,7 @@ def main():
             exchange.barrier()
             ctx.sync()
 
-    adaptive_k = w["cfg"]["num_component_adapter_type"] == "adaptive" and n_gpus == 1
+    adaptive_k = w["cfg"]["num_component_adapter_type"] == "adaptive"
     pairs_done = [0.0]
 
     def timed(steps):
@@ -401,7 +404,7 @@ def main():
         t_start = time.perf_counter()
         for _ in range(steps):
             if adaptive_k:               # K changes between iterations: (samples, components) pairs of this one
-                pairs_done[0] += float(algo.model.num_components) ** 2 * w["s"]
+                pairs_done[0] += float(algo.model.num_components if n_gpus == 1 else algo.num_components) ** 2 * w["s"]
             algo.train_iter()
         if hasattr(algo, "flush"):
             algo.flush()             # sharded path: the last weight step rides with the next exchange; close it in the timed region
@@ -415,7 +418,8 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     pairs_per_step = pairs_done[0] / args.steps if adaptive_k else float(w["n_total"]) * w["k_total"]
     k_span = (None if not adaptive_k else
-              f"K {w['k_total']} at the start, {int(algo.model.num_components)} after {args.warmup + args.steps} iterations")
+              f"K {w['k_total']} at the start, {int(algo.model.num_components if n_gpus == 1 else algo.num_components)} after "
+              f"{args.warmup + args.steps} iterations")
     # the same figure at the two ends of a run: over the FIRST iterations of a fresh process (what a short --steps measures: the
     # sample database is still growing, caches are cold) and in the steady state behind them
     first_n = args.warmup + args.steps
@@ -498,6 +502,8 @@ def main():
                    "path": ("single C call per iteration (gmmvi_train_iter_samtron)" if getattr(getattr(algo, "_fast_path", None), "eligible", lambda: False)()
                             else "four C calls per iteration with an all-gather between them (gmmvi_train_iter_sharded_phase)"
                             if getattr(algo, "_fast", None) is not None
+                            else "module-by-module launches, components partitioned by id (gmmvi_amd/sharded_adaptive.py)"
+                            if adaptive_k and n_gpus > 1
                             else "module-by-module plug-in calls"),
                    **({"adaptive": k_span + "; value = mean N K of the timed iterations / time"} if k_span else {})},
         "roofline": {"kernel": roof_name, "bound": kernel_bound(roof_name, d), "achieved": achieved, "peak": roof_peak,

@@ -264,15 +264,15 @@ class ShardedGMMVI:
     @staticmethod
     def _check_scope(cfg):
         """The sharded iteration covers the configuration bench.py scales; anything else is refused up front instead of
-        silently running something different (adaptive K would need a host-driven re-balancing of the shards after every
-        add / delete: SURVEY.md 8e -- not built; use the single-GPU GMMVI for those configurations)."""
+        silently running something different.  An adaptive number of components has its own class,
+        ``gmmvi_amd.sharded_adaptive.ShardedAdaptiveGMMVI`` (partition by component id, replicated add / delete decisions)."""
         def refuse(what):
             raise NotImplementedError(f"ShardedGMMVI: {what} is not supported on the component-sharded path "
                                       "(supported: Stein estimator, KL trust-region updates, fixed number of components, "
                                       "reuse ratio 0, full covariances); run it on one GPU with gmmvi_amd.optimization.gmmvi.GMMVI")
         if cfg.get("num_component_adapter_type", "fixed") != "fixed":
             refuse("an adaptive number of components (num_component_adapter_type = "
-                   f"{cfg['num_component_adapter_type']!r})")
+                   f"{cfg['num_component_adapter_type']!r}: use gmmvi_amd.sharded_adaptive.ShardedAdaptiveGMMVI)")
         if float(cfg.get("sample_selector_config", {}).get("ratio_reused_samples_to_desired", 0.0)) != 0.0:
             refuse("sample reuse (ratio_reused_samples_to_desired > 0)")
         if cfg.get("ng_estimator_type", "Stein") != "Stein":

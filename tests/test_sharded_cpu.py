@@ -233,11 +233,39 @@ def test_single_rank_sharded_equals_unsharded_oracle():
     (dict(reuse_ratio=2.0), "reuse"), (dict(estimator="MORE"), "MORE"), (dict(updater="direct"), "direct"),
     (dict(diag=True), "diagonal")])
 def test_sharded_path_refuses_configurations_outside_its_scope(change, word):
-    """Adaptive K (component_adaptation.py:177-300) would need the shards re-balanced after every add / delete; it is not
-    built for the sharded path, which says so instead of running something else."""
+    """The fixed-block sharded path says what it does not cover instead of running something else (an adaptive number of
+    components -- component_adaptation.py:177-300 -- has its own class, gmmvi_amd/sharded_adaptive.py)."""
     from gmmvi_amd.sharded import ShardedGMMVI, LocalExchange
     cfg = samtron_config(S, **change)
     o = make_oracle(KIND, D, K, S, SEED, samtron_config(S))
     om = o.model.model
     with pytest.raises(NotImplementedError, match=word):
         ShardedGMMVI(OracleOps(o.target), LocalExchange(), D, K, om.means.copy(), om.chol_cov.copy(), S, SEED, cfg)
+
+
+def test_partition_tables_restore_the_global_order_through_adds_and_deletions():
+    """Host logic of the adaptive sharded path (gmmvi_amd/sharded_adaptive.py): components are owned by id (initial blocks, then
+    id mod R), deletions leave the ranks with different counts.  Concatenating every rank's local list (what an all-gather
+    delivers, padding stripped) and gathering with ``rm_of_g`` must give the global (ascending id) order at every step."""
+    from gmmvi_amd.sharded_adaptive import partition_tables
+    rng = np.random.default_rng(4)
+    for n_ranks in (2, 3, 8):
+        k0 = 2 * n_ranks + 1
+        ids = np.arange(k0)
+        owner = (np.arange(k0) * n_ranks // k0).astype(np.int32)
+        next_id = k0
+        for step in range(60):
+            if step % 3 != 2 or len(ids) <= n_ranks + 2:                                 # add (gmm_wrapper.py:106: ids grow by one)
+                ids, owner = np.append(ids, next_id), np.append(owner, np.int32(next_id % n_ranks))
+                next_id += 1
+            else:                                                                        # delete anywhere but a rank's last one
+                cand = [g for g in range(len(ids)) if np.count_nonzero(owner == owner[g]) > 1]
+                g = int(rng.choice(cand))
+                ids, owner = np.delete(ids, g), np.delete(owner, g)
+            tables = [partition_tables(owner, n_ranks, r) for r in range(n_ranks)]
+            counts, _, rm_of_g = tables[0]
+            assert counts.sum() == len(ids) and all(np.array_equal(t[2], rm_of_g) for t in tables)
+            rank_major = np.concatenate([ids[tables[r][1]] for r in range(n_ranks)])       # every rank sends its ids in local order
+            assert all(len(tables[r][1]) == counts[r] for r in range(n_ranks))
+            np.testing.assert_array_equal(rank_major[rm_of_g], ids)
+            assert np.all(np.diff(ids) > 0)
