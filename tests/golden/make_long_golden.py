@@ -5,6 +5,8 @@ ships no vectors: SURVEY.md 8c; these files are oracle output, data only -- "par
   long_c1.npz   BASELINE configs[0] = examples/5_samtron_20D_student-T.py:13-30: K = 45 adaptive (add every 60, delete after
                 100 iterations), 200 samples / component, reuse ratio 0, 260 iterations (adds at 60/120/180/240, deletions
                 from iteration 101)
+  long_c1_full.npz  the same run at the example's stated length, examples/5_samtron_20D_student-T.py:30: 1501 iterations (K 45 -> 70
+                by 25 adds, no deletion: the rule never fires on this target; checkpoints every 50 iterations; ~65 minutes)
   long_c4.npz   BASELINE configs[3]'s example as examples/6_samtron_planar4.py:19-26 runs it: planar-4 target, 100 initial
                 components, a component added EVERY iteration, deletions from iteration 11 (del_iters 10), 100 samples /
                 component, weight stepsize 5, 140 iterations; the script asserts that the oracle deleted >= 5 components;

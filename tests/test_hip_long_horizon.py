@@ -81,6 +81,7 @@ def _run_long(name, modular):
         assert g._fast_path.eligible(), "expected the single-call iteration for this configuration"
     cps = {int(i): j for j, i in enumerate(fx["checkpoint_iters"])}
     chaotic = bool(case.get("chaotic"))             # examples/6 regime: see the comment above
+    lockstep = int(case.get("lockstep", LOCKSTEP_ITERS))
     state = {"it": 0, "deleted": 0, "checked": 0}
     if case["adaptive"]:
         _check_deletion_rule(g, state)
@@ -89,7 +90,7 @@ def _run_long(name, modular):
         state["it"] = it
         g.train_iter()
         k_fx = int(fx["k_trace"][it - 1])
-        if not chaotic or it <= LOCKSTEP_ITERS:
+        if not chaotic or it <= lockstep:
             assert g.model.num_components == k_fx, f"iteration {it}: K = {g.model.num_components}, oracle {k_fx}"
             if "id_trace" in fx:                     # WHICH components were added / deleted, not only how many
                 ids = fx["id_trace"][it - 1]
@@ -107,7 +108,7 @@ def _run_long(name, modular):
             e, _ = score_elbo(o.target, g.model.log_weights.numpy(), g.model.means.numpy(), g.model.chol_cov.numpy())
             # decorrelated trajectories differ by the run-to-run spread of the algorithm itself, not by rounding: 0.15 nats
             # (the oracle's ELBO moves by 1.0 nat over the last 60 iterations of this fixture)
-            tol = 3.0 * float(fx["checkpoint_sigma"][j]) + (0.15 if chaotic and it > LOCKSTEP_ITERS else 1e-2)
+            tol = 3.0 * float(fx["checkpoint_sigma"][j]) + (0.15 if chaotic and it > lockstep else 1e-2)
             dev = abs(e - float(fx["checkpoint_elbo"][j]))
             worst = max(worst, dev / tol)
             assert dev <= tol, f"iteration {it}: ELBO {e:.4f} vs oracle {float(fx['checkpoint_elbo'][j]):.4f} (tol {tol:.4f})"
@@ -115,7 +116,7 @@ def _run_long(name, modular):
         assert state["checked"] >= case["iters"] - case["adaptive"]["del_iters"] - 1
     if chaotic:
         n_fx = int(fx["n_deleted"])
-        assert n_fx // 2 <= state["deleted"] <= 2 * n_fx, (state["deleted"], n_fx)
+        assert n_fx // 2 <= state["deleted"] <= 2 * n_fx + 2, (state["deleted"], n_fx)
         print(f"long_{name} ({'modular' if modular else 'single-call'}): worst |dELBO|/tol {worst:.3f}, deleted {state['deleted']} "
               f"(oracle {n_fx}), max |K - K_oracle| {k_dev_max}, ids in lock-step to the end: {in_lockstep}")
         if not in_lockstep:
@@ -126,8 +127,8 @@ def _run_long(name, modular):
     c_dev = np.abs(g.model.chol_cov.numpy() - fx["final_chols"]).max() / np.abs(fx["final_chols"]).max()
     print(f"long_{name} ({'modular' if modular else 'single-call'}): worst |dELBO|/tol {worst:.3f}, final weights {w_dev:.2e}, "
           f"means {m_dev:.2e}, chols {c_dev:.2e}")
-    if not chaotic:
-        assert w_dev <= 2e-3 and m_dev <= 2e-2 and c_dev <= 2e-2, (w_dev, m_dev, c_dev)
+    # (a "chaotic" case gets here only when its ids stayed in lock-step with the fixture to the end: same bounds then)
+    assert w_dev <= 2e-3 and m_dev <= 2e-2 and c_dev <= 2e-2, (w_dev, m_dev, c_dev)
 
 
 @pytest.mark.parametrize("modular", [False, True], ids=["single_call", "modular"])
@@ -153,3 +154,13 @@ def test_long_horizon_c1_example5(modular):
     """BASELINE configs[0] = examples/5_samtron_20D_student-T.py:13-30: K = 45 adaptive (component_adaptation.py:186-190:
     add every 60, delete after 100 iterations), 200 samples / component, 260 iterations."""
     _run_long("c1", modular)
+
+
+@pytest.mark.parametrize("modular", [False, True], ids=["single_call", "modular"])
+def test_long_horizon_c1_example5_full_length(modular):
+    """The same run at the length the example states, examples/5_samtron_20D_student-T.py:30: 1501 iterations -- the converged
+    tail (stepsizes saturated, flat reward histories in front of the deletion rule, 24 adds).  K and the unique ids in lock-step
+    with the fixture for the first 260 iterations (= long_c1) and for as long as they agree behind them; then |K - K_oracle| <=
+    10, ELBO at every 50th iteration within 3 sigma + 0.15 nats, the deletion rule checked exactly at every iteration on the
+    device's own histories."""
+    _run_long("c1_full", modular)
