@@ -78,6 +78,9 @@ _PROTOS = {
     "gmmvi_event_record": (_i, [_p, _p]),
     "gmmvi_event_synchronize": (_i, [_p, _p]),
     "gmmvi_host_alloc": (_i, [_p, _sz, C.POINTER(_p)]),
+    "gmmvi_vmm_reserve": (_i, [_p, _sz, C.POINTER(_p), C.POINTER(_sz)]),
+    "gmmvi_vmm_grow": (_i, [_p, _p, _sz, _sz, _sz]),
+    "gmmvi_vmm_release": (_i, [_p, _p, _sz, _sz, _sz]),
     "gmmvi_host_free": (_i, [_p, _p]),
     "gmmvi_download_async": (_i, [_p, _p, _p, _sz]),
     "gmmvi_event_elapsed_ms": (_i, [_p, _p, _p, C.POINTER(_f)]),

@@ -147,6 +147,56 @@ int gmmvi_host_free(gmmvi_ctx* ctx, void* host) {
     return GMMVI_OK;
 }
 
+// ---- grow-in-place device buffers (the sample database) ---------------------------------------------------------------------
+// A buffer that doubles by hipMalloc + copy + hipFree costs seconds once it holds gigabytes (measured at the D = 300 shard:
+// 1.5 - 3.7 s of host time per doubling of the five database arrays, 0.9 - 2.6 s of it with the GPU idle); on a 288 GB part the
+// database is meant to grow that far.  Here the ADDRESS range is reserved once and physical memory is mapped behind the used
+// part chunk by chunk (HIP virtual memory management): growing never moves a byte and never frees one.
+int gmmvi_vmm_reserve(gmmvi_ctx* ctx, size_t max_bytes, void** base_out, size_t* chunk_bytes_out) {
+    GMMVI_ARG_CHECK(ctx, base_out != nullptr && chunk_bytes_out != nullptr && max_bytes > 0);
+    int supported = 0;
+    GMMVI_HIP_CHECK(ctx, hipDeviceGetAttribute(&supported, hipDeviceAttributeVirtualMemoryManagementSupported, ctx->device));
+    if (!supported) return gmmvi_fail(ctx, GMMVI_ERR_HIP, "gmmvi_vmm_reserve: virtual memory management is not supported on this device");
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = ctx->device;
+    size_t gran = 0;
+    GMMVI_HIP_CHECK(ctx, hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    size_t chunk = (size_t)256 << 20;                        // one map call per 256 MiB of growth (tens of microseconds)
+    if (chunk % gran) chunk = (chunk / gran + 1) * gran;
+    const size_t total = (max_bytes + chunk - 1) / chunk * chunk;
+    GMMVI_HIP_CHECK(ctx, hipMemAddressReserve(base_out, total, gran, nullptr, 0));
+    *chunk_bytes_out = chunk;
+    return GMMVI_OK;
+}
+
+// physical memory behind [mapped_bytes, new_mapped_bytes) of a reserved range (both multiples of the chunk size)
+int gmmvi_vmm_grow(gmmvi_ctx* ctx, void* base, size_t chunk_bytes, size_t mapped_bytes, size_t new_mapped_bytes) {
+    GMMVI_ARG_CHECK(ctx, base != nullptr && chunk_bytes > 0 && mapped_bytes % chunk_bytes == 0 && new_mapped_bytes % chunk_bytes == 0 &&
+                         new_mapped_bytes >= mapped_bytes);
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = ctx->device;
+    hipMemAccessDesc acc = {};
+    acc.location.type = hipMemLocationTypeDevice; acc.location.id = ctx->device; acc.flags = hipMemAccessFlagsProtReadWrite;
+    for (size_t at = mapped_bytes; at < new_mapped_bytes; at += chunk_bytes) {
+        hipMemGenericAllocationHandle_t h;
+        GMMVI_HIP_CHECK(ctx, hipMemCreate(&h, chunk_bytes, &prop, 0));
+        hipError_t e = hipMemMap((char*)base + at, chunk_bytes, 0, h, 0);
+        if (e == hipSuccess) e = hipMemSetAccess((char*)base + at, chunk_bytes, &acc, 1);
+        (void)hipMemRelease(h);                              // the mapping keeps the memory alive until it is unmapped
+        GMMVI_HIP_CHECK(ctx, e);
+    }
+    return GMMVI_OK;
+}
+
+int gmmvi_vmm_release(gmmvi_ctx* ctx, void* base, size_t chunk_bytes, size_t mapped_bytes, size_t reserved_bytes) {
+    if (base == nullptr) return GMMVI_OK;
+    GMMVI_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));     // launches that still read the buffer
+    for (size_t at = 0; at < mapped_bytes; at += chunk_bytes) GMMVI_HIP_CHECK(ctx, hipMemUnmap((char*)base + at, chunk_bytes));
+    const size_t total = (reserved_bytes + chunk_bytes - 1) / chunk_bytes * chunk_bytes;
+    GMMVI_HIP_CHECK(ctx, hipMemAddressFree(base, total));
+    return GMMVI_OK;
+}
+
 int gmmvi_copy(gmmvi_ctx* ctx, void* dst_dev, const void* src_dev, size_t nbytes) {
     if (nbytes == 0) return GMMVI_OK;
     GMMVI_ARG_CHECK(ctx, dst_dev && src_dev);

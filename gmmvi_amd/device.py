@@ -183,6 +183,15 @@ class DeviceArray:
         self._owner, self._base, self._cap = False, base, 0
         return self
 
+    @classmethod
+    def _external(cls, ctx, ptr, shape, dtype, keepalive):
+        """Array over memory this class does not manage (a mapped range of optimization/sample_db.py's grow-in-place buffers);
+        ``keepalive`` owns it and stays referenced by this array and every view of it."""
+        self = object.__new__(cls)
+        self.ctx, self.ptr, self.shape, self.dtype = ctx, ptr, _as_shape(shape), np.dtype(dtype)
+        self._owner, self._base, self._cap = False, keepalive, 0
+        return self
+
     def __del__(self):
         try:
             if getattr(self, "_owner", False) and self.ptr:

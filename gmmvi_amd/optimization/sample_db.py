@@ -8,19 +8,53 @@ window ends on an append boundary the answer is read off the append log without 
 Background densities are evaluated by the same fused density kernel as the model (log-weights = log(count / N),
 sample_db.py:221-227).  Steady-state iterations issue no host<->device synchronisation.
 """
+import os
+
 import numpy as np
 
 from .. import hip_ops
 from ..device import DeviceArray, get_context
 
 
+class _MappedRange:
+    """A reserved device address range with physical memory mapped behind its first ``mapped`` bytes (gmmvi_vmm_*)."""
+
+    def __init__(self, ctx, reserve_bytes):
+        import ctypes as C
+        base, chunk = C.c_void_p(), C.c_size_t()
+        ctx.check(ctx.lib.gmmvi_vmm_reserve(ctx.handle, int(reserve_bytes), C.byref(base), C.byref(chunk)))
+        self.ctx, self.base, self.chunk, self.reserved, self.mapped = ctx, base.value, int(chunk.value), int(reserve_bytes), 0
+
+    def ensure(self, nbytes):
+        want = (int(nbytes) + self.chunk - 1) // self.chunk * self.chunk
+        if want > self.mapped:
+            if want > (self.reserved + self.chunk - 1) // self.chunk * self.chunk:
+                raise MemoryError(f"sample database: a buffer outgrew its reserved address range of {self.reserved >> 30} GiB "
+                                  "(GMMVI_DB_RESERVE_GB)")
+            self.ctx.check(self.ctx.lib.gmmvi_vmm_grow(self.ctx.handle, self.base, self.chunk, self.mapped, want))
+            self.mapped = want
+
+    def __del__(self):
+        try:
+            if self.base:
+                self.ctx.lib.gmmvi_vmm_release(self.ctx.handle, self.base, self.chunk, self.mapped, self.reserved)
+                self.base = None
+        except Exception:
+            pass
+
+
 class _Growable:
-    """Device buffer with logical length ``n`` along axis 0 and amortised O(1) append."""
+    """Device buffer with logical length ``n`` along axis 0 and amortised O(1) append.  Small buffers double (allocate, copy,
+    release); once a buffer would pass ``MAPPED_FROM`` bytes it moves -- one last copy -- into a reserved address range and
+    grows IN PLACE from then on, physical memory mapped chunk by chunk (csrc/api.hip: gmmvi_vmm_*): a doubling of a multi-gigabyte
+    buffer costs seconds (hipMalloc + copy + a hipFree that waits for the stream), and the database of a long run is meant to
+    fill a good part of the 288 GB."""
 
     def __init__(self, ctx, inner, dtype=np.float32):
         self.ctx, self.inner, self.dtype = ctx, tuple(inner), dtype
         self.buf = ctx.empty((0,) + self.inner, dtype)
         self.n = 0
+        self._range = None
 
     def view(self, start=0, stop=None):
         stop = self.n if stop is None else stop
@@ -29,21 +63,43 @@ class _Growable:
     # the first allocation holds FIRST_APPENDS appends of the first one's size (at most FIRST_BYTES): a run of a few hundred
     # iterations then never re-allocates -- a doubling is a hipMalloc (host-synchronous) plus a copy of everything so far, and a
     # short timed window that happens to contain one reads several percent slower (bench.py: 20 steps against 200)
-    FIRST_APPENDS, FIRST_BYTES = 256, 4 << 30
+    FIRST_APPENDS, FIRST_BYTES = 256, 1 << 30
+    MAPPED_FROM = 1 << 30                                     # bytes from which a buffer lives in a mapped range
+    RESERVE = int(os.environ.get("GMMVI_DB_RESERVE_GB", "64")) << 30      # address range per buffer (costs nothing until mapped)
+
+    def _row_bytes(self):
+        return int(np.prod(self.inner, dtype=np.int64)) * np.dtype(self.dtype).itemsize
+
+    def _map_rows(self, rows):
+        """Rows [0, rows) of the mapped range usable; ``buf`` re-pointed at everything that is mapped."""
+        rb = self._row_bytes()
+        self._range.ensure(rows * rb)
+        self.buf = DeviceArray._external(self.ctx, self._range.base, (self._range.mapped // rb,) + self.inner, self.dtype, self._range)
 
     def reserve(self, m):
-        if self.n + m > self.buf.shape[0]:
-            cap = max(2 * self.buf.shape[0], self.n + m, 1024)
-            if self.buf.shape[0] == 0:
-                row_bytes = int(np.prod(self.inner, dtype=np.int64)) * np.dtype(self.dtype).itemsize
-                cap = max(cap, min(self.FIRST_APPENDS * m, self.FIRST_BYTES // max(1, row_bytes)))
-            new = self.ctx.empty((cap,) + self.inner, self.dtype)
-            if self.buf.shape[0] == 0 and new.size and np.dtype(self.dtype).itemsize == 4:
-                # touch the pages now (one fill on the stream) instead of while the appends walk through them
-                self.ctx.check(self.ctx.lib.gmmvi_fill_f32(self.ctx.handle, new.ptr, 0.0, new.size))
+        if self.n + m <= self.buf.shape[0]:
+            return
+        if self._range is not None:
+            self._map_rows(self.n + m)
+            return
+        cap = max(2 * self.buf.shape[0], self.n + m, 1024)
+        row_bytes = self._row_bytes()
+        if self.buf.shape[0] == 0:
+            cap = max(cap, min(self.FIRST_APPENDS * m, self.FIRST_BYTES // max(1, row_bytes)))
+        if cap * row_bytes >= self.MAPPED_FROM and np.dtype(self.dtype).itemsize == 4:
+            old = self.buf
+            self._range = _MappedRange(self.ctx, max(self.RESERVE, 2 * (self.n + m) * row_bytes))
+            self._map_rows(self.n + m)
             if self.n:
-                new.rows(0, self.n).copy_from(self.buf.rows(0, self.n))
-            self.buf = new
+                self.buf.rows(0, self.n).copy_from(old.rows(0, self.n))
+            return
+        new = self.ctx.empty((cap,) + self.inner, self.dtype)
+        if self.buf.shape[0] == 0 and new.size and np.dtype(self.dtype).itemsize == 4:
+            # touch the pages now (one fill on the stream) instead of while the appends walk through them
+            self.ctx.check(self.ctx.lib.gmmvi_fill_f32(self.ctx.handle, new.ptr, 0.0, new.size))
+        if self.n:
+            new.rows(0, self.n).copy_from(self.buf.rows(0, self.n))
+        self.buf = new
 
     def append(self, arr):
         m = arr.shape[0]
@@ -61,6 +117,13 @@ class _Growable:
         self.n += m
 
     def assign(self, arr):
+        if self._range is not None:                            # (thinning a large database: the rows move to the front of the range)
+            self.n = 0
+            self.reserve(arr.shape[0])
+            if arr.shape[0]:
+                self.buf.rows(0, arr.shape[0]).copy_from(arr)
+            self.n = arr.shape[0]
+            return
         self.buf = arr
         self.n = arr.shape[0]
 

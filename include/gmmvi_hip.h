@@ -132,6 +132,14 @@ int gmmvi_host_alloc(gmmvi_ctx* ctx, size_t nbytes, void** out_pinned_host);
 int gmmvi_host_free(gmmvi_ctx* ctx, void* pinned_host);
 int gmmvi_download_async(gmmvi_ctx* ctx, void* dst_pinned_host, const void* src_dev, size_t nbytes);
 
+/* Grow-in-place device buffers (what optimization/sample_db.py keeps its arrays in; the reference's SampleDB concatenates
+   tensors, sample_db.py:97-135): reserve an address range once, map physical memory behind its used part in chunks of
+   *chunk_bytes_out; growing copies nothing.  gmmvi_vmm_grow: mapped_bytes / new_mapped_bytes are multiples of the chunk size.
+   gmmvi_vmm_release waits for the context's stream, unmaps and frees the range. */
+int gmmvi_vmm_reserve(gmmvi_ctx* ctx, size_t max_bytes, void** base_out, size_t* chunk_bytes_out);
+int gmmvi_vmm_grow(gmmvi_ctx* ctx, void* base, size_t chunk_bytes, size_t mapped_bytes, size_t new_mapped_bytes);
+int gmmvi_vmm_release(gmmvi_ctx* ctx, void* base, size_t chunk_bytes, size_t mapped_bytes, size_t reserved_bytes);
+
 /* Per-kernel timing for bench.py's roofline leg: while enabled, every kernel-launching entry point brackets its
  * launches with HIP events on the context's stream.  gmmvi_profile_report synchronises, writes one line per kernel
  * name ("name count total_ms total_pairs\n"; total_pairs = (sample, component) pairs processed, 0 where not counted) into

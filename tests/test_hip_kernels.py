@@ -638,3 +638,33 @@ def test_small_uploads_through_the_staging_ring_keep_their_contents(ctx, rng):
             ops().exp_into(ctx, ctx.empty((1 << 16,)), ctx.zeros((1 << 16,)))
     for a, d in zip(host, dev):
         np.testing.assert_array_equal(d.numpy(), a)
+
+
+def test_database_buffers_grow_in_place(ctx, rng, monkeypatch):
+    """optimization/sample_db.py _Growable: doubling while small, then one move into a reserved address range that grows by
+    mapping chunks (gmmvi_vmm_*): appends across the move and across a chunk boundary keep every row; assign() re-fills it."""
+    from gmmvi_amd.optimization.sample_db import _Growable
+    monkeypatch.setattr(_Growable, "MAPPED_FROM", 8 << 20)
+    monkeypatch.setattr(_Growable, "FIRST_APPENDS", 2)
+    width = 1 << 16                                            # 256 KiB per row
+    g = _Growable(ctx, (width,))
+    rows = []
+    for i in range(9):                                          # 4 rows per append: 1 MiB; the buffer moves into a mapped range on the way
+        blk = rng.normal(size=(4, 8)).astype(np.float32)
+        rows.append(blk)
+        full = np.zeros((4, width), np.float32); full[:, :8] = blk; full[:, -1] = i
+        g.append(ctx.asarray(full))
+    assert g._range is not None and g.n == 36
+    chunk = g._range.chunk
+    big = ctx.zeros((chunk // (width * 4) + 8, width))          # one append that crosses the first chunk boundary
+    g.append(big)
+    assert g._range.mapped >= 2 * chunk and g.n == 36 + big.shape[0]
+    head = g.view(0, 36).numpy()
+    np.testing.assert_array_equal(head[:, :8], np.concatenate(rows))
+    np.testing.assert_array_equal(head[:, -1], np.repeat(np.arange(9, dtype=np.float32), 4))
+    tail = ctx.asarray(np.full((3, width), 7.0, np.float32))
+    g.append(tail)
+    np.testing.assert_array_equal(g.view(g.n - 3).numpy()[:, ::4096], 7.0)
+    g.assign(ctx.asarray(np.full((5, width), 2.0, np.float32)))
+    assert g.n == 5 and g._range is not None
+    np.testing.assert_array_equal(g.view().numpy()[:, ::4096], 2.0)
