@@ -74,11 +74,20 @@ class VipsComponentAdaptation(ComponentAdaptation):
     def adapt_number_of_components(self, iteration):
         """:177-190."""
         iteration = int(iteration)
+        add_due = iteration > 1 and iteration % self.add_iters == 0
+        # The candidate draw of the add heuristic (host generator, index upload, two gathers) depends neither on the deletions nor
+        # on anything the iteration's launches still compute, while the deletion rule has to wait for their rewards: draw first,
+        # so that the host works while the GPU finishes.  Same generator sequence as the reference order (the deletion rule draws
+        # nothing); only when K sits at max_components -- where a deletion decides whether the add happens at all -- the order
+        # of the reference is kept.
+        drawn = None
+        if add_due and self.model.num_components < self.max_components:
+            drawn = self.select_samples_for_adding_heuristic()
         if iteration > self.del_iters:
             self.delete_bad_components()
-        if iteration > 1 and iteration % self.add_iters == 0:
+        if add_due:
             if self.model.num_components < self.max_components:
-                self.add_new_component()
+                self.add_new_component(drawn)
 
     def add_at_best_location(self, samples, target_lnpdfs):
         """:192-226.  The candidate search runs on the device (gmmvi_add_heuristic_argmax: the same fp64 arithmetic, first
@@ -118,9 +127,9 @@ class VipsComponentAdaptation(ComponentAdaptation):
             self.sample_db.num_samples_written.assign_add(self.num_prior_samples)
         return samples, target_lnpdfs, prior_samples
 
-    def add_new_component(self):
-        """:251-259."""
-        samples, target_lnpdfs, prior_samples = self.select_samples_for_adding_heuristic()
+    def add_new_component(self, drawn=None):
+        """:251-259 (``drawn``: the candidates, when adapt_number_of_components selected them ahead of the deletion step)."""
+        samples, target_lnpdfs, prior_samples = drawn if drawn is not None else self.select_samples_for_adding_heuristic()
         if self.num_prior_samples > 0:
             ctx = self.model.ctx
             plp = self.target_lnpdf.log_density(ctx.asarray(prior_samples))

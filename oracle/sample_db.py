@@ -8,6 +8,30 @@ from scipy.special import logsumexp
 from . import philox
 
 
+def random_subset(rng, total, size):
+    """A uniformly random ``size``-subset of range(total), ascending -- the SET that shuffle(range(total))[:size] is
+    (sample_db.py:137-152); its order is irrelevant to the consumer, an arg-max over the candidates.  Oversampled independent
+    draws, sorted, duplicates dropped, surplus values removed at random: the distinct values of independent uniform draws form a
+    uniformly random subset of their number, and removing uniformly chosen members keeps it one.  Vectorised (NumPy's own
+    choice(replace=False) walks a hash set element by element: 1.9 ms against 0.85 ms for 1e5 of 3e6 here) and
+    ascending, so the gather that follows reads the database front to back."""
+    total, size = int(total), min(int(size), int(total))
+    if 4 * size > total or total >= 2 ** 31:                 # dense draws (small databases): NumPy's own algorithm
+        return np.sort(rng.choice(total, size=size, replace=False, shuffle=False)).astype(np.int32)
+    have = None
+    while have is None or have.shape[0] < size:
+        missing = size - (0 if have is None else have.shape[0])
+        draw = rng.integers(0, total, size=missing + max(64, missing // 16), dtype=np.int32)
+        have = np.sort(draw if have is None else np.concatenate([have, draw]))
+        keep = np.empty(have.shape[0], bool)
+        keep[0] = True
+        np.not_equal(have[1:], have[:-1], out=keep[1:])
+        have = have[keep]
+    if have.shape[0] > size:
+        have = np.delete(have, rng.choice(have.shape[0], size=have.shape[0] - size, replace=False, shuffle=False))
+    return have
+
+
 class SampleDB:
     def __init__(self, dim, diagonal_covariances, keep_samples, max_samples=None, dtype=np.float64):
         self.diagonal_covariances = bool(diagonal_covariances)                         # :32
@@ -69,12 +93,8 @@ class SampleDB:
             self.target_grads = np.asarray(target_grads, dt).copy()
 
     def get_random_sample(self, n, rng):
-        """sample_db.py:137-152 (tf.random.shuffle replaced by a NumPy Generator permutation)."""
-        total = self.samples.shape[0]
-        # a uniformly random n-subset, as shuffle(range(total))[:n] is; its ORDER is not shuffled (NumPy then draws it in O(n)
-        # instead of O(total): 1.6 ms against 8.6 ms at total = 3e6) -- the consumer, an arg-max over the candidates, does not
-        # depend on the order
-        idx = rng.choice(total, size=min(int(n), total), replace=False, shuffle=False)
+        """sample_db.py:137-152 (tf.random.shuffle + slice -> random_subset below: the same set law, NumPy generator)."""
+        idx = random_subset(rng, self.samples.shape[0], n)
         return self.samples[idx], self.target_lnpdfs[idx]
 
     def gaussian_log_pdf(self, mean, chol, inv_chol, x):
