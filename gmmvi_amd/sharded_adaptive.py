@@ -47,6 +47,20 @@ def partition_tables(owner, n_ranks, rank):
     return counts, np.nonzero(owner == rank)[0].astype(np.int32), (base[owner] + local_pos).astype(np.int32)
 
 
+def gather_layout(counts, widths, rank):
+    """Layout of one padded all-gather of per-component arrays: every rank sends its arrays back to back (``counts[r]`` rows of
+    ``widths[j]`` floats for array j) padded to the largest rank's size.  -> (floats per rank in the gathered buffer, padding this
+    rank appends, and for every array the (offset, length) of each rank's piece in the gathered buffer, rank by rank)."""
+    counts = [int(c) for c in counts]
+    total_w = sum(widths)
+    chunk = max(counts) * total_w
+    where = []
+    for j, w in enumerate(widths):
+        before = sum(widths[:j])
+        where.append([(r * chunk + counts[r] * before, counts[r] * w) for r in range(len(counts))])
+    return chunk, (max(counts) - counts[rank]) * total_w, where
+
+
 class _CandidateStore:
     """What the add heuristic needs of the sample database (sample_db.py:137-152): all samples so far with their target
     log-densities, replicated on every rank, and the counter of written samples."""
@@ -148,20 +162,15 @@ class ShardedAdaptiveGMMVI:
         if self.R == 1:
             return [a.reshape(-1) for a, _ in parts]
         ctx, t = self.ctx, self._tab()
-        kl, total_w = int(t.counts[self.rank]), sum(w for _, w in parts)
-        chunk = t.kmax * total_w
+        widths = [w for _, w in parts]
+        chunk, pad, where = gather_layout(t.counts, widths, self.rank)
         pieces = [a.reshape(-1) for a, _ in parts]
-        if kl < t.kmax:
-            pieces.append(ctx.zeros(((t.kmax - kl) * total_w,)))
+        if pad:
+            pieces.append(ctx.zeros((pad,)))
         gathered = self.exchange.allgather(hip_ops.concat(ctx, pieces))
         out = []
-        for j, (_, w) in enumerate(parts):
-            before = sum(wj for _, wj in parts[:j])
-            views = []
-            for r in range(self.R):
-                lo = r * chunk + int(t.counts[r]) * before
-                views.append(gathered.rows(lo, lo + int(t.counts[r]) * w))
-            rank_major = hip_ops.concat(ctx, views).reshape((self.num_components, w))
+        for j, w in enumerate(widths):
+            rank_major = hip_ops.concat(ctx, [gathered.rows(lo, lo + n) for lo, n in where[j]]).reshape((self.num_components, w))
             out.append(hip_ops.gather_rows(ctx, rank_major, t.rm_of_g_dev).reshape(-1))
         return out
 

@@ -269,3 +269,18 @@ def test_partition_tables_restore_the_global_order_through_adds_and_deletions():
             assert all(len(tables[r][1]) == counts[r] for r in range(n_ranks))
             np.testing.assert_array_equal(rank_major[rm_of_g], ids)
             assert np.all(np.diff(ids) > 0)
+            # the padded exchange itself, emulated on the host: every rank packs [values of width 3 | values of width 1] of its
+            # components, pads to the largest rank, the buffers are concatenated (= all-gather) and taken apart by gather_layout
+            from gmmvi_amd.sharded_adaptive import gather_layout
+            a_of = lambda i: np.stack([i * 10.0, i * 10.0 + 1, i * 10.0 + 2], axis=1).reshape(-1)      # width 3, from the id
+            sent = []
+            for r in range(n_ranks):
+                mine = ids[tables[r][1]].astype(np.float64)
+                chunk, pad, where = gather_layout(counts, [3, 1], r)
+                buf = np.concatenate([a_of(mine), -mine, np.zeros(pad)])
+                assert buf.shape[0] == chunk
+                sent.append(buf)
+            gathered = np.concatenate(sent)
+            for j, (w, expect) in enumerate([(3, a_of(ids.astype(np.float64))), (1, -ids.astype(np.float64))]):
+                rm = np.concatenate([gathered[lo:lo + n] for lo, n in where[j]]).reshape(len(ids), w)
+                np.testing.assert_array_equal(rm[rm_of_g].reshape(-1), expect)
