@@ -112,11 +112,17 @@ class _Growable:
             cap = max(cap, min(self.FIRST_APPENDS * m, self.FIRST_BYTES // max(1, row_bytes)))
         if cap * row_bytes >= self.MAPPED_FROM and np.dtype(self.dtype).itemsize == 4:
             old = self.buf
-            self._range = _MappedRange(self.ctx, max(self.RESERVE, 2 * (self.n + m) * row_bytes))
-            self._map_rows(self.n + m)
-            if self.n:
-                self.buf.rows(0, self.n).copy_from(old.rows(0, self.n))
-            return
+            try:
+                self._range = _MappedRange(self.ctx, max(self.RESERVE, 2 * (self.n + m) * row_bytes))
+            except Exception as e:                              # no virtual memory management on this stack: keep doubling
+                import warnings
+                warnings.warn(f"sample database: grow-in-place buffers are not available ({e}); large buffers will double by copy")
+                _Growable.MAPPED_FROM = float("inf")
+            else:
+                self._map_rows(self.n + m)
+                if self.n:
+                    self.buf.rows(0, self.n).copy_from(old.rows(0, self.n))
+                return
         new = self.ctx.empty((cap,) + self.inner, self.dtype)
         if self.buf.shape[0] == 0 and new.size and np.dtype(self.dtype).itemsize == 4:
             # touch the pages now (one fill on the stream) instead of while the appends walk through them

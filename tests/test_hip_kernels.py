@@ -668,3 +668,22 @@ def test_database_buffers_grow_in_place(ctx, rng, monkeypatch):
     g.assign(ctx.asarray(np.full((5, width), 2.0, np.float32)))
     assert g.n == 5 and g._range is not None
     np.testing.assert_array_equal(g.view().numpy()[:, ::4096], 2.0)
+
+
+def test_database_buffers_keep_doubling_without_virtual_memory_management(ctx, monkeypatch):
+    """A stack that cannot reserve / map address ranges: the buffer warns once and goes on doubling by copy."""
+    from gmmvi_amd.optimization import sample_db
+    monkeypatch.setattr(sample_db._Growable, "MAPPED_FROM", 8 << 20)
+    monkeypatch.setattr(sample_db._Growable, "FIRST_APPENDS", 2)
+
+    def refuse(self, ctx, reserve_bytes):
+        raise sample_db.hip_ops._lib.GmmviError("virtual memory management is not supported")
+    monkeypatch.setattr(sample_db._MappedRange, "__init__", refuse)
+    g = sample_db._Growable(ctx, (1 << 16,))
+    with pytest.warns(UserWarning, match="grow-in-place"):
+        for i in range(12):
+            g.append(ctx.asarray(np.full((4, 1 << 16), float(i), np.float32)))
+    assert g._range is None and g.n == 48
+    np.testing.assert_array_equal(g.view().numpy()[:, 0], np.repeat(np.arange(12, dtype=np.float32), 4))
+    assert sample_db._Growable.MAPPED_FROM == float("inf")
+    monkeypatch.setattr(sample_db._Growable, "MAPPED_FROM", 1 << 30)       # (the class attribute the fallback set: restored)
