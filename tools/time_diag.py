@@ -1,37 +1,34 @@
-"""Developer tool: the dedicated diagonal sweeps (csrc/diag_sweep.hip) against the dense kernels on the embedded factors
-diag(sigma) -- what DiagonalGMM ran on until round 3 -- at a few shapes."""
-import os, sys, numpy as np
+"""Developer tool: the north-star shape with a DIAGONAL mixture (module-by-module path: the single-call iteration takes
+full-covariance models only) -- ms per iteration and per-kernel HIP-event times."""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import bench
+from helpers import samtron_config
 from gmmvi_amd.device import get_context
-from gmmvi_amd import hip_ops
+from gmmvi_amd.models.diagonal_gmm import DiagonalGMM
 ctx = get_context()
-rng = np.random.default_rng(0)
-
-
-def timed(fn, reps):
-    for _ in range(3):
-        fn()
-    e0, e1 = ctx.event(), ctx.event()
-    ctx.record(e0)
-    for _ in range(reps):
-        fn()
-    ctx.record(e1)
-    return ctx.elapsed_ms(e0, e1) / reps * 1e3
-
-
-for K, D, N, reps in ((100, 20, 10000, 100), (100, 50, 10000, 50), (64, 300, 20000, 5)):
-    means = ctx.asarray(rng.normal(size=(K, D)) * 3)
-    sigma = ctx.asarray(rng.uniform(0.5, 2.0, size=(K, D)))
-    logw = ctx.asarray(np.full(K, -np.log(K)))
-    x = ctx.asarray(rng.normal(size=(N, D)) * 3)
-    tg = ctx.asarray(rng.normal(size=(N, D)))
-    pd = hip_ops.diag_pack(ctx, means, sigma)
-    dense = hip_ops.diag_embed(ctx, sigma)
-    pk, _ = hip_ops.pack_components(ctx, means, dense)
-    t_diag = timed(lambda: hip_ops.diag_mixture_eval(ctx, pd, logw, x, D, want_ld=True, want_lp=True, want_grad=True), reps)
-    t_dense = timed(lambda: hip_ops.mixture_eval(ctx, pk, logw, x, D, want_ld=True, want_lp=True, want_grad=True), reps)
-    ld, lp, grad = hip_ops.diag_mixture_eval(ctx, pd, logw, x, D, want_ld=True, want_lp=True, want_grad=True)
-    ts_diag = timed(lambda: hip_ops.diag_stein(ctx, pd, x, ld, grad, lp, tg, D), reps)
-    ts_dense = timed(lambda: hip_ops.stein(ctx, pk, x, ld, grad, lp, tg, D), reps)
-    print(f"K={K} D={D} N={N}: density+gradient sweep {t_diag:.0f} us (dense on diag(sigma): {t_dense:.0f}); "
-          f"Stein {ts_diag:.0f} us (dense: {ts_dense:.0f})", flush=True)
+w = bench.build("ns", 1, 0)
+cfg = samtron_config(w["s"], initial_stepsize=0.1, diag=True)
+cfg["model_initialization"].update(prior_mean=0.0, initial_cov=300.0)
+k, d = w["k_total"], w["d"]
+model = DiagonalGMM(np.ones(k) / k, w["means"], np.full((k, d), 300.0, np.float32))
+model.seed = w["seed"]
+wrapper = w["GmmWrapper"](model, 0.1, 1e-12, 10000)
+algo = w["GMMVI"].build_from_config(cfg, w["target"], wrapper)
+for _ in range(20):
+    algo.train_iter()
+ctx.sync()
+t0 = time.perf_counter()
+for _ in range(200):
+    algo.train_iter()
+ctx.sync()
+print(f"diagonal mixture, K = {k}, D = {d}, N = {k * w['s']}: {(time.perf_counter() - t0) * 5:.3f} ms per iteration "
+      f"(single-call path eligible: {algo._fast_path.eligible()})")
+ctx.check(ctx.lib.gmmvi_profile_enable(ctx.handle, 1))
+for _ in range(50):
+    algo.train_iter()
+prof = bench.parse_profile(ctx)
+for name, (c, ms, _) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+    print(f"  {name:28s} {c / 50:5.1f} launches/iter  {1e3 * ms / c:8.1f} us each")
