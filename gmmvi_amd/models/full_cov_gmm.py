@@ -61,8 +61,10 @@ class FullCovGMM(GMM):
         diffs = x[None, :, dim] - self.means.numpy()[:, dim, None]
         return -0.5 * diffs * diffs / var[:, None] - 0.5 * np.log(var)[:, None] - 0.5 * np.log(2 * np.pi)
 
-    def add_component(self, initial_weight, initial_mean, initial_cov):
-        """full_cov_gmm.py:64-68.  Device-side appends (nothing is read back); ``initial_mean`` may be a DeviceArray [1, D]."""
+    def add_component(self, initial_weight, initial_mean, initial_cov, pairs=None):
+        """full_cov_gmm.py:64-68.  Device-side appends (nothing is read back); ``initial_mean`` may be a DeviceArray [1, D].
+        ``pairs`` (GmmWrapper.add_component): the appends are queued there and the caller launches them together; the log
+        weights are then left UNnormalised for the caller to finish (``_renormalised``) behind that launch."""
         d = self.num_dimensions
         cov = np.asarray(initial_cov, np.float32).reshape(d, d)
         if np.count_nonzero(cov - np.diag(np.diagonal(cov))) == 0:
@@ -77,8 +79,9 @@ class FullCovGMM(GMM):
                 raise ValueError("add_component: covariance is not positive definite")
         if not isinstance(initial_mean, DeviceArray):
             initial_mean = self.ctx.asarray(np.asarray(initial_mean, np.float32).reshape(1, d))
-        self.means = self._append_rows(self.means, initial_mean.reshape((1, d)))
-        self.chol_cov = self._append_rows(self.chol_cov, chol)
+        self.means = self._append_rows(self.means, initial_mean.reshape((1, d)), pairs)
+        self.chol_cov = self._append_rows(self.chol_cov, chol, pairs)
         self._invalidate()
         new_lw = self.ctx.asarray(np.array([np.log(np.float64(initial_weight))], np.float32))
-        self.log_weights = self._renormalised(self._append_rows(self.log_weights, new_lw))
+        appended = self._append_rows(self.log_weights, new_lw, pairs)
+        self.log_weights = appended if pairs is not None else self._renormalised(appended)

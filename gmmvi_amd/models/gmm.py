@@ -178,11 +178,18 @@ class GMM:
         self.ctx.check(self.ctx.lib.gmmvi_normalize_logw(self.ctx.handle, log_weights_dev.ptr, int(log_weights_dev.shape[0]), out.ptr))
         return out
 
-    def _append_rows(self, arr, new_row):
-        """[K, ...] device array with one more row (device-side copy, nothing read back)."""
+    def _append_rows(self, arr, new_row, pairs=None):
+        """[K, ...] device array with one more row (device-side copy, nothing read back).  ``pairs``: the two copies are queued
+        there for ONE hip_ops.copy_batch launch of the caller (adding a component appends to seven arrays)."""
         inner = tuple(arr.shape[1:])
         new_row = self.ctx.asarray(new_row) if not isinstance(new_row, DeviceArray) else new_row
-        return hip_ops.concat(self.ctx, [arr, new_row]).reshape((arr.shape[0] + 1,) + inner)
+        if pairs is None:
+            return hip_ops.concat(self.ctx, [arr, new_row]).reshape((arr.shape[0] + 1,) + inner)
+        k = arr.shape[0]
+        out = self.ctx.empty((k + 1,) + inner, arr.dtype)
+        pairs.append((out.rows(0, k).reshape(-1), arr.reshape(-1)))
+        pairs.append((out.rows(k, k + 1).reshape(-1), new_row.reshape(-1)))
+        return out
 
     def remove_component(self, idx):
         """gmm.py:388-398 (device-side gathers: nothing is read back)."""

@@ -10,6 +10,7 @@ import numpy as np
 
 from .. import hip_ops
 from .gmm import GMM
+from .full_cov_gmm import FullCovGMM
 
 FLOAT32_MIN = float(np.finfo(np.float32).min)
 
@@ -138,16 +139,25 @@ class GmmWrapper:
         ctx = self.model.ctx
         k_old = self.model.num_components
         self._grow_rings(k_old + 1)
-        self.model.add_component(initial_weight, initial_mean, initial_cov)
+        # seven arrays get a row: all copies in two launches (hip_ops.copy_batch takes eight at a time) instead of one per array
+        pairs = []
+        batched = isinstance(self.model, FullCovGMM)
+        if batched:
+            self.model.add_component(initial_weight, initial_mean, initial_cov, pairs)
+        else:
+            self.model.add_component(initial_weight, initial_mean, initial_cov)
         self.max_component_id += 1
         self.unique_component_ids = np.append(self.unique_component_ids, np.int32(self.max_component_id))
-        # the four per-component vectors get their new entry on the device (one small upload, four copies: nothing read back)
+        # the four per-component vectors get their new entry on the device (one small upload: nothing read back)
         tail = ctx.asarray(np.array([self.initial_regularizer, self.initial_last_eta, 0.0, self.initial_stepsize], np.float32))
-        app = lambda dev, j: hip_ops.concat(ctx, [dev, tail.rows(j, j + 1)])
+        app = lambda dev, j: self.model._append_rows(dev, tail.rows(j, j + 1), pairs)
         self.l2_regularizers = app(self.l2_regularizers, 0)
         self.last_log_etas = app(self.last_log_etas, 1)
         self.num_received_updates = app(self.num_received_updates, 2)
         self.stepsizes = app(self.stepsizes, 3)
+        hip_ops.copy_batch(ctx, pairs)
+        if batched:
+            self.model.log_weights = self.model._renormalised(self.model.log_weights)
         h = self.max_reward_history_length
         # the new component's history column: rewards float32.min (:121-122), weights initial_weight (:123-124)
         ctx.check(ctx.lib.gmmvi_fill_strided_f32(ctx.handle, self._reward_ring.ptr + 4 * k_old, self._kcap, h,
