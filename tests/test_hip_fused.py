@@ -191,3 +191,27 @@ def test_early_draw_is_dropped_when_something_changes_in_between():
     both(lambda g: g.train_iter())
     both(lambda g: g.train_iter())
     check("after changing the samples per component")
+
+
+@pytest.mark.parametrize("reuse", [0.0, 2.0])
+def test_database_move_into_a_mapped_range_does_not_change_the_run(reuse, monkeypatch):
+    """The sample database's arrays move from a doubling allocation into a grow-in-place address range when they pass
+    _Growable.MAPPED_FROM (1 GiB; here 256 KiB, so that it happens within a few iterations): base pointers change under the
+    single-call iteration, the early draw and -- with reuse -- the prefetched window caches.  Same trajectory as without the move."""
+    from gmmvi_amd.optimization import sample_db
+    cfg = samtron_config(64, reuse_ratio=reuse)
+    o = make_oracle("gmm", 20, 8, 64, 31, cfg)
+    plain = make_device("gmm", 20, 8, 64, 31, cfg, o)
+    for _ in range(14):
+        plain.train_iter()
+    assert plain.sample_db._samples._range is None
+    monkeypatch.setattr(sample_db._Growable, "MAPPED_FROM", 256 << 10)
+    monkeypatch.setattr(sample_db._Growable, "FIRST_APPENDS", 2)
+    moved = make_device("gmm", 20, 8, 64, 31, cfg, o)
+    for _ in range(14):
+        moved.train_iter()
+    assert moved.sample_db._samples._range is not None and moved.sample_db._target_grads._range is not None
+    for name in ("means", "chol_cov", "log_weights", "stepsizes"):
+        np.testing.assert_array_equal(getattr(moved.model, name).numpy(), getattr(plain.model, name).numpy(), err_msg=name)
+    np.testing.assert_array_equal(moved.sample_db.samples.numpy(), plain.sample_db.samples.numpy())
+    np.testing.assert_array_equal(moved.sample_db.target_lnpdfs.numpy(), plain.sample_db.target_lnpdfs.numpy())
