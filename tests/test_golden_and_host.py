@@ -252,3 +252,26 @@ def test_bench_workload_spec_is_host_only():
     o = bench.make_oracle(bench.spec("tiny", 1), dtype=np.float32)
     o.train_iter()
     assert o.model.means.dtype == np.float32
+
+
+def test_random_subset_is_a_uniform_subset_and_the_same_in_oracle_and_product():
+    """The candidate draw of the add heuristic (sample_db.py:137-152: shuffle + slice): `random_subset` must return a strictly
+    ascending set of distinct indices of the requested size, consume the generator identically in the oracle and in the product
+    (the two are compared sample for sample in the adaptive tests), and pick every index with the same probability."""
+    import numpy as np
+    from oracle.sample_db import random_subset as oracle_subset
+    from gmmvi_amd.optimization.sample_db import random_subset as product_subset
+    for total, size in [(3_000_000, 100_000), (500, 300), (1000, 200), (10 ** 6, 2 * 10 ** 5), (50, 100), (10 ** 5, 10), (7, 7)]:
+        r1, r2 = np.random.default_rng(5), np.random.default_rng(5)
+        a, b = oracle_subset(r1, total, size), product_subset(r2, total, size)
+        assert a.dtype == np.int32 and np.array_equal(a, b)
+        assert a.shape[0] == min(size, total) and a.min() >= 0 and a.max() < total
+        assert a.shape[0] < 2 or np.all(np.diff(a) > 0)
+        assert r1.random() == r2.random()                      # same generator state behind the draw
+    rng, hits, trials = np.random.default_rng(1), np.zeros(2000), 3000
+    for _ in range(trials):
+        hits[product_subset(rng, 2000, 100)] += 1              # sparse branch (4 * size <= total)
+    p = 100 / 2000
+    assert abs(hits.mean() - trials * p) < 1e-9
+    assert abs(hits.std() - np.sqrt(trials * p * (1 - p))) < 0.15 * np.sqrt(trials * p * (1 - p))
+    assert hits.min() > trials * p - 6 * np.sqrt(trials * p) and hits.max() < trials * p + 6 * np.sqrt(trials * p)
